@@ -1,0 +1,215 @@
+"""Parameter-name contract of the drop-in boundary.
+
+``param_shapes(config)`` lists every tensor of the reference model's state dict
+(name -> shape) in the reference's own naming (reference
+modules: PhysDock/models/model.py:55-68, layers/transformers.py,
+layers/diffusion_conditioning.py, primitives/*.py).  ``Linear`` weights are
+``[out, in]``.  The fixture ``tests/golden/param_names_*.json`` (captured from
+the reference by tools/make_golden.py) pins this list.
+
+``seeded_state_dict`` is the documented weight-generation procedure used on both
+sides of every parity test (trained weights do not exist in this environment).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from .configs import ffn_hidden
+
+
+def _lin(d, name, cin, cout, bias=True):
+    d[name + ".weight"] = (cout, cin)
+    if bias:
+        d[name + ".bias"] = (cout,)
+
+
+def _rms(d, name, c):
+    d[name + ".weight"] = (c,)
+
+
+def _ffn(d, name, c):
+    h = ffn_hidden(c)
+    _lin(d, name + ".w1", c, h, False)
+    _lin(d, name + ".w2", h, c, False)
+    _lin(d, name + ".w3", c, h, False)
+
+
+def _transition(d, name, c):
+    _rms(d, name + ".ffn_norm", c)
+    _ffn(d, name + ".feed_forward", c)
+
+
+def _attn_pair_bias(d, name, c, cz, norm_name="norm_s"):
+    _rms(d, f"{name}.{norm_name}", c)
+    _rms(d, name + ".norm_z", cz)
+    _lin(d, name + ".linear_z", cz, c // 32, False)
+    for x in "qkv":
+        _lin(d, f"{name}.linear_{x}", c, c, False)
+    _lin(d, name + ".linear_g", c, c)
+    _lin(d, name + ".linear_o", c, c)
+
+
+def _tri_update(d, name, cz):
+    _rms(d, name + ".norm_in", cz)
+    _rms(d, name + ".norm_out", 32)
+    for x in ("q", "qx", "k", "kx"):
+        _lin(d, f"{name}.linear_{x}", cz, 32)
+    _lin(d, name + ".linear_g", cz, cz)
+    _lin(d, name + ".linear_z", 32, cz)
+
+
+def _tri_attn(d, name, cz):
+    _rms(d, name + ".norm", cz)
+    for x in "qkv":
+        _lin(d, f"{name}.linear_{x}", cz, cz, False)
+    _lin(d, name + ".linear_z", cz, cz // 32, False)
+    _lin(d, name + ".linear_g", cz, cz)
+    _lin(d, name + ".linear_o", cz, cz)
+
+
+def _triangle_block(d, name, cz):
+    _tri_update(d, name + ".triangle_row_update", cz)
+    _tri_update(d, name + ".triangle_col_update", cz)
+    _tri_attn(d, name + ".triangle_row_attention", cz)
+    _tri_attn(d, name + ".triangle_col_attention", cz)
+    _transition(d, name + ".pair_transition", cz)
+
+
+def _adaln(d, name, c):
+    _lin(d, name + ".linear", 256, 3 * c)
+
+
+def _dit_block(d, name, c, cz):
+    a = name + ".attention"
+    _adaln(d, a + ".norm_s", c)
+    d[a + ".norm_z.weight"] = (cz,)
+    d[a + ".norm_z.bias"] = (cz,)
+    for x in "qkv":
+        _lin(d, f"{a}.linear_{x}", c, c, False)
+    _lin(d, a + ".linear_z", cz, c // 32, False)
+    _rms(d, a + ".norm_q", 32)
+    _rms(d, a + ".norm_k", 32)
+    _lin(d, a + ".linear_o", c, c)
+    t = name + ".transition"
+    _adaln(d, t + ".ffn_norm", c)
+    _ffn(d, t + ".feed_forward", c)
+
+
+def param_shapes(config) -> "OrderedDict[str, tuple]":
+    dc = config.model.diffusion_conditioning
+    dt = config.model.dit
+    c_a, c_ap, c_s, c_m, c_z = dc.c_a, dc.c_ap, dc.c_s, dc.c_m, dc.c_z
+    d: "OrderedDict[str, tuple]" = OrderedDict()
+
+    # ---- diffusion_conditioning.atom_embedder (diffusion_conditioning.py:97-128)
+    p = "diffusion_conditioning.atom_embedder"
+    _lin(d, p + ".linear_c", dc.ref_dim, c_a, False)
+    _lin(d, p + ".linear_p", 3, c_ap, False)
+    _lin(d, p + ".linear_d", 1, c_ap, False)
+    _lin(d, p + ".linear_v", 1, c_ap, False)
+    _lin(d, p + ".linear_c_l", c_a, c_ap, False)
+    _lin(d, p + ".linear_c_m", c_a, c_ap, False)
+    _ffn(d, p + ".ffn", c_ap)
+    for b in range(dc.no_blocks_atom):
+        q = f"{p}.atom_transformer.blocks.{b}"
+        _attn_pair_bias(d, q + ".attention", c_a, c_ap)
+        _transition(d, q + ".transition", c_a)
+
+    # ---- token_embedder (diffusion_conditioning.py:131-202)
+    p = "diffusion_conditioning.token_embedder"
+    _lin(d, p + ".linear_a", c_a, c_s)
+    _lin(d, p + ".linear_target_feat", dc.target_dim, c_s, False)
+    _lin(d, p + ".linear_key_res_feat", 7, c_s, False)
+    _lin(d, p + ".linear_pocket_res_feat", 1, c_s, False)
+    _lin(d, p + ".linear_s_i", c_s, c_z)
+    _lin(d, p + ".linear_s_j", c_s, c_z)
+    _lin(d, p + ".rel_pos_embedder.linear", 115, c_z, False)
+    _lin(d, p + ".linear_bonds", 1, c_z, False)
+    _lin(d, p + ".linear_msa_feat", dc.msa_dim, c_m, False)
+    _lin(d, p + ".linear_s_input", c_s, c_m)
+    q = p + ".template_pair_embedder"
+    _rms(d, q + ".norm_in", c_z)
+    _lin(d, q + ".linear_in", c_z, c_z, False)
+    _lin(d, q + ".linear_templ_feat", 40, c_z, False)
+    for b in range(2):
+        _triangle_block(d, f"{q}.triangleformer.blocks.{b}", c_z)
+    _rms(d, q + ".norm_out", c_z)
+    _lin(d, q + ".linear_out", c_z, c_z, False)
+    for b in range(dc.no_blocks_evoformer):
+        q = f"{p}.evoformer.blocks.{b}"
+        _attn_pair_bias(d, q + ".msa_row_attention", c_m, c_z, norm_name="norm_m")
+        r = q + ".msa_col_attention"
+        _rms(d, r + ".norm_m", c_m)
+        for x in "qkv":
+            _lin(d, f"{r}.linear_{x}", c_m, c_m, False)
+        _lin(d, r + ".linear_g", c_m, c_m)
+        _lin(d, r + ".linear_o", c_m, c_m)
+        _transition(d, q + ".msa_transition", c_m)
+        r = q + ".opm"
+        _rms(d, r + ".norm_in", c_m)
+        _lin(d, r + ".linear_q", c_m, 32)
+        _lin(d, r + ".linear_k", c_m, 32)
+        _lin(d, r + ".linear_o", 32 * 32, c_z)
+        _rms(d, r + ".norm_out", c_z)
+        _triangle_block(d, q, c_z)
+    for b in range(dc.no_blocks_pairformer):
+        q = f"{p}.pairformer.blocks.{b}"
+        _triangle_block(d, q, c_z)
+        _attn_pair_bias(d, q + ".attention", c_s, c_z)
+        _transition(d, q + ".transition", c_s)
+    _lin(d, p + ".linear_m", c_m, c_s, False)
+    _lin(d, p + ".linear_s", c_s, c_s, False)
+
+    # ---- conditioning tail (diffusion_conditioning.py:226-229)
+    p = "diffusion_conditioning"
+    _rms(d, p + ".norm_s", c_s)
+    _lin(d, p + ".linear_s", c_s, c_a, False)
+    _rms(d, p + ".norm_z", c_z)
+    _lin(d, p + ".linear_z", c_z, c_ap, False)
+
+    # ---- dit (transformers.py:178-203)
+    c_a, c_ap, c_s, c_z = dt.c_a, dt.c_ap, dt.c_s, dt.c_z
+    _lin(d, "dit.linear_x", 3, c_a)
+    _lin(d, "dit.linear_downscale", c_a, c_s)
+    _lin(d, "dit.linear_upscale", c_s, c_a)
+    _lin(d, "dit.time_embedder.timestep_embedder.linear_1", 256, 256)
+    _lin(d, "dit.time_embedder.timestep_embedder.linear_2", 256, 256)
+    for b in range(dt.no_blocks_atom):
+        _dit_block(d, f"dit.atom_dit_encoder.blocks.{b}", c_a, c_ap)
+    for b in range(dt.no_blocks_dit):
+        _dit_block(d, f"dit.token_dit.blocks.{b}", c_s, c_z)
+    for b in range(dt.no_blocks_atom):
+        _dit_block(d, f"dit.atom_dit_decoder.blocks.{b}", c_a, c_ap)
+    d["dit.norm_r.weight"] = (c_a,)
+    d["dit.norm_r.bias"] = (c_a,)
+    _lin(d, "dit.linear_r", c_a, 3, False)
+
+    # ---- training head kept for state-dict compatibility (model.py:67)
+    _lin(d, "linear_distogram", config.model.c_z, 39)
+    return d
+
+
+def seeded_state_dict(shapes, seed: int = 0, dtype=torch.float32):
+    """Deterministic non-degenerate weights for parity tests.
+
+    One CPU generator, names visited in sorted order.  2-D tensors ~ N(0, 1/fan_in);
+    1-D ``*.weight`` (norm gains) ~ 1 + 0.1 N(0,1); 1-D ``*.bias`` ~ 0.1 N(0,1).
+    (The reference zero-initialises several layers - linear.py:129-137 - which would
+    hide them from a parity test, hence no layer is left at zero here.)
+    """
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    out = OrderedDict()
+    for name in sorted(shapes):
+        shape = tuple(shapes[name])
+        x = torch.randn(shape, generator=g, dtype=torch.float32)
+        if len(shape) == 2:
+            x = x / (shape[1] ** 0.5)
+        elif name.endswith(".weight"):
+            x = 1.0 + 0.1 * x
+        else:
+            x = 0.1 * x
+        out[name] = x.to(dtype)
+    return out

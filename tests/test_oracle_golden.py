@@ -1,0 +1,191 @@
+"""Pin the CPU oracle (oracle/physdock_oracle.py) to vectors captured from the reference
+(tools/make_golden.py; golden sets G1-G7 of SURVEY §8c).  CPU only."""
+import json
+import os
+
+import pytest
+import torch
+
+import physdock_oracle as orc
+from conftest import GOLDEN, golden_noise, golden_weights, load_golden, rmsd
+
+TOL = dict(rtol=2e-4, atol=2e-4)
+
+
+def close(a, b, **kw):
+    torch.testing.assert_close(a, b, **{**TOL, **kw})
+
+
+def pref(w, p="m"):
+    return {f"{p}.{k}": v for k, v in w.items()}
+
+
+# ------------------------------------------------------------------ boundary contract
+@pytest.mark.parametrize("tag", ["medium", "toy"])
+def test_param_names_match_reference(tag):
+    from physdock_amd.configs import PhysDockConfig
+    from physdock_amd.params import param_shapes
+    with open(os.path.join(GOLDEN, f"param_names_{tag}.json")) as f:
+        ref = json.load(f)
+    mine = {k: list(v) for k, v in param_shapes(PhysDockConfig(model_name=tag)).items()}
+    assert mine == ref
+    if tag == "medium":
+        assert len(ref) == 2353
+
+
+def test_config_fields_match_reference():
+    from physdock_amd.configs import PhysDockConfig
+    with open(os.path.join(GOLDEN, "config_medium.json")) as f:
+        ref = json.load(f)
+    c = PhysDockConfig(model_name="medium")
+    assert c.sigma_data == ref["sigma_data"] and c["sigma_data"] == ref["sigma_data"]
+    assert c.data.crop_size == ref["crop_size"] and c.data.atom_crop_size == ref["atom_crop_size"]
+    assert dict(c.model.diffusion_conditioning) == ref["dc"]
+    assert dict(c.model.dit) == ref["dit"]
+    assert c.model.c_z == ref["c_z"] and c.model.num_augmentation_sample == ref["num_aug"]
+
+
+# ------------------------------------------------------------------ G1 primitives
+def test_g1_rmsnorm():
+    g = load_golden("g1_rmsnorm")
+    close(orc.rms_norm(pref(golden_weights(g)), "m", g["x"], g["eps"]), g["y"])
+
+
+def test_g1_adaln():
+    g = load_golden("g1_adaln")
+    y, gate = orc.ada_ln_zero(pref(golden_weights(g)), "m", g["x"], g["t"], g["eps"])
+    close(y, g["y"]); close(gate, g["gate"])
+
+
+def test_g1_ffn_transitions():
+    g = load_golden("g1_feed_forward")
+    close(orc.feed_forward(pref(golden_weights(g)), "m", g["x"]), g["y"])
+    g = load_golden("g1_transition")
+    close(orc.transition(pref(golden_weights(g)), "m", g["x"], g["eps"]), g["y"])
+    g = load_golden("g1_dit_transition")
+    close(orc.dit_transition(pref(golden_weights(g)), "m", g["x"], g["t"], g["eps"]), g["y"])
+
+
+def test_g1_timestep_embeddings():
+    g = load_golden("g1_timestep_embeddings")
+    close(orc.timestep_embeddings(pref(golden_weights(g)), "m", g["tau"]), g["y"], atol=5e-4)
+
+
+def test_g1_attentions():
+    g = load_golden("g1_dit_attention")
+    close(orc.dit_attention(pref(golden_weights(g)), "m", g["x"], g["z"], g["t"], g["mask"], g["inf"], g["eps"]), g["y"])
+    g = load_golden("g1_attention_pair_bias")
+    close(orc.attention_pair_bias(pref(golden_weights(g)), "m", g["s"], g["z"], g["mask"], g["inf"], g["eps"]), g["y"])
+    g = load_golden("g1_msa_row_attention")
+    close(orc.attention_pair_bias(pref(golden_weights(g)), "m", g["m"], g["z"], g["mask"], g["inf"], g["eps"], "norm_m"), g["y"])
+    g = load_golden("g1_msa_col_attention")
+    close(orc.msa_column_attention(pref(golden_weights(g)), "m", g["m"], g["eps"]), g["y"])
+
+
+def test_g1_opm():
+    g = load_golden("g1_outer_product_mean")
+    close(orc.outer_product_mean(pref(golden_weights(g)), "m", g["m"], g["eps"]), g["y"])
+
+
+@pytest.mark.parametrize("tr", [0, 1])
+def test_g1_triangle(tr):
+    g = load_golden(f"g1_triangle_update_{tr}")
+    close(orc.triangle_update(pref(golden_weights(g)), "m", g["z"], g["mask"], g["eps"], bool(tr)), g["y"])
+    g = load_golden(f"g1_triangle_attention_{tr}")
+    close(orc.triangle_attention(pref(golden_weights(g)), "m", g["z"], g["mask"], g["inf"], g["eps"], bool(tr)), g["y"])
+
+
+def test_g1_rel_pos_and_mask():
+    g = load_golden("g1_rel_pos")
+    feats = orc.rel_pos_features(g)
+    assert feats.shape[-1] == 115
+    close(orc.linear(pref(golden_weights(g)), "m.linear", feats), g["y"])
+    g = load_golden("g1_attn_mask")
+    assert torch.equal(orc.attn_mask_bias(g["mask"], g["inf"]), g["y"])
+
+
+# ------------------------------------------------------------------ G2 modules
+def test_g2_conditioning(small_model_inputs):
+    cfg, P, batch = small_model_inputs
+    g = load_golden("g2_conditioning")
+    dc = cfg.model.diffusion_conditioning
+    a, ap = orc.atom_embedder(P, "diffusion_conditioning.atom_embedder", batch, dc.inf, dc.eps)
+    close(a, g["atom_embedder_a"]); close(ap, g["atom_embedder_ap"])
+    a, ap, s, z = orc.diffusion_conditioning(P, batch, dc.inf, dc.eps)
+    close(a, g["a"]); close(ap, g["ap"]); close(s, g["s"], atol=5e-4); close(z, g["z"], atol=1e-3)
+
+
+def test_g2_af3dit(small_model_inputs):
+    cfg, P, batch = small_model_inputs
+    g = load_golden("g2_af3dit")
+    y = orc.af3_dit(P, batch, g["x_hat"], g["t_hat"], g["a"], g["ap"], g["s"], g["z"])
+    close(y, g["x_denoised"])
+
+
+def test_g2_blocks(small_model_inputs):
+    cfg, P, batch = small_model_inputs
+    dc = cfg.model.diffusion_conditioning
+    te = "diffusion_conditioning.token_embedder"
+    g = load_golden("g2_pairformer_block")
+    s, z = orc.pairformer_block(P, te + ".pairformer.blocks.0", g["s"], g["z"], batch["z_mask"], dc.inf, dc.eps)
+    close(s, g["s_out"], atol=5e-4); close(z, g["z_out"], atol=5e-4)
+    g = load_golden("g2_evoformer_block")
+    m, z = orc.evoformer_block(P, te + ".evoformer.blocks.1", g["m"], g["z"], batch["z_mask"], dc.inf, dc.eps)
+    close(m, g["m_out"], atol=5e-4); close(z, g["z_out"], atol=5e-4)
+    g = load_golden("g2_template_pair_embedder")
+    close(orc.template_pair_embedder(P, te + ".template_pair_embedder", batch, g["z"], dc.inf, dc.eps), g["y"], atol=5e-4)
+
+
+# ------------------------------------------------------------------ G3 / G4
+def test_g3_schedules_bit_exact():
+    g = load_golden("g3_schedules")
+    assert torch.equal(orc.karras_noise_schedule(40, p=1000), g["s40_p1000"])
+    assert torch.equal(orc.karras_noise_schedule(10, p=1000), g["s10_p1000"])
+    assert torch.equal(orc.karras_noise_schedule(200, p=7), g["s200_p7"])
+    assert torch.equal(orc.karras_noise_schedule(40, p=7), g["s40_p7"])
+
+
+def test_g4_augmentation_and_align():
+    g = load_golden("g4_augment_align")
+    close(orc.centre_random_augmentation(g["x"], g["mask"], g["rot_u"], g["trans"]), g["y"], atol=1e-5)
+    close(orc.weighted_rigid_align(g["x_pred"], g["x_gt2d"], g["w"]), g["aligned2d"], atol=1e-4)
+    close(orc.weighted_rigid_align(g["x_pred"], g["x_gt3d"], g["w"]), g["aligned3d"], atol=1e-4)
+    close(orc.weighted_rigid_align(g["x_pred_refl"], g["x_pred"][0], g["w"]), g["aligned_refl"], atol=1e-4)
+
+
+# ------------------------------------------------------------------ G5 / G6 / G7 sampler
+@pytest.mark.parametrize("tag", ["10", "40"])
+def test_g5_trajectory(small_model_inputs, tag):
+    cfg, P, batch = small_model_inputs
+    g = load_golden(f"g5_trajectory_{tag}")
+    x = orc.sample_diffusion(P, batch, golden_noise(g), num_sample=3, steps=g["steps"],
+                             align_ref_pos=False, karras_noise_schedule_power=1000)
+    assert rmsd(x, g["x_pred"]) < 1e-3
+
+
+def test_g5_trajectory_align_refpos(small_model_inputs):
+    cfg, P, batch = small_model_inputs
+    g = load_golden("g5_trajectory_align_refpos")
+    x = orc.sample_diffusion(P, batch, golden_noise(g), num_sample=2, steps=g["steps"], align_ref_pos=True,
+                             ode_step_scale_eta=1.5, karras_noise_schedule_power=7)
+    assert rmsd(x, g["x_pred"]) < 1e-3
+
+
+def test_g6_template_branch(small_model_inputs):
+    cfg, P, batch = small_model_inputs
+    g = load_golden("g6_trajectory_template")
+    x = orc.sample_diffusion(P, batch, golden_noise(g), num_sample=3, steps=g["steps"],
+                             ref_mol_poses=g["ref_mol_poses"], mmff_gamma_0_factor=g["mmff_gamma_0_factor"],
+                             align_ref_pos=True, karras_noise_schedule_power=1000)
+    assert rmsd(x, g["x_pred"]) < 1e-3
+
+
+def test_g7_reselect():
+    g = load_golden("g7_reselect")
+    rd = torch.norm(g["ref_mol_poses"][:, :, None] - g["ref_mol_poses"][:, None], dim=-1)
+    e = orc.template_epsilon(g["ligand_poses"], rd)
+    close(e, g["eps_bc"], atol=1e-6)
+    assert torch.equal(torch.argmin(e, -1), g["argmin_b"])
+    order, e_c = orc.template_reselect(g["ligand_poses"], g["ref_mol_poses"], len(g["order"]))
+    close(e_c, g["eps_c"], atol=1e-6)
+    assert torch.equal(order, g["order"])
