@@ -1,0 +1,142 @@
+"""ctypes binding of libphysdock_hip.so (the C ABI of include/physdock_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a launcher returns an
+error the call raises.  Tensors are torch device tensors used as typed device memory; all
+launches go to the current torch HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphysdock_hip.so")
+
+ACT_NONE, ACT_SILU, ACT_SIGMOID, ACT_RELU = 0, 1, 2, 3
+OUT_ROWMAJOR, OUT_TRANSPOSED, OUT_OPM, OUT_BIASFRAG = 0, 1, 2, 3
+LOG2E = 1.4426950408889634
+
+_fp = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", _fp), ("W", _fp), ("Y", _fp),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int),
+        ("batch", C.c_int),
+        ("sA", C.c_longlong), ("sW", C.c_longlong), ("sY", C.c_longlong),
+        ("a_kmajor", C.c_int), ("w_kmajor", C.c_int),
+        ("stats", _fp), ("pro_w", _fp), ("pro_b", _fp),
+        ("pro_rows_per_group", C.c_int), ("pro_gstride", C.c_int), ("pro_act", C.c_int),
+        ("rowscale_acc", _fp), ("bias", _fp), ("sBias", C.c_longlong),
+        ("hn_w", _fp), ("hn_cols", C.c_int), ("hn_split", C.c_int), ("hn_eps", C.c_float),
+        ("act", C.c_int), ("glu", C.c_int),
+        ("rowscale", _fp), ("maskadd", _fp), ("maskval", C.c_float),
+        ("mul", _fp), ("ldmul", C.c_int), ("mul_rows_per_group", C.c_int), ("mul_gstride", C.c_int),
+        ("out_scale", C.c_float),
+        ("res", _fp), ("ldres", C.c_int), ("res_row_mod", C.c_int), ("sRes", C.c_longlong),
+        ("out_mode", C.c_int), ("T1", C.c_int), ("T2", C.c_int), ("frag_transpose", C.c_int),
+        ("vecA", C.c_int), ("vecW", C.c_int),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", _fp), ("K", _fp), ("V", _fp), ("O", _fp),
+        ("nq", C.c_int), ("nk", C.c_int), ("nbatch", C.c_int), ("nheads", C.c_int),
+        ("q_bs", C.c_longlong), ("q_ss", C.c_longlong), ("k_bs", C.c_longlong), ("k_ss", C.c_longlong),
+        ("v_bs", C.c_longlong), ("v_ss", C.c_longlong), ("o_bs", C.c_longlong), ("o_ss", C.c_longlong),
+        ("bias", _fp), ("scale", C.c_float),
+    ]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -m physdock_amd.build` "
+                "(there is no CPU or PyTorch fallback for the sampler kernels)")
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+        if _lib.pd_abi_version() != 1:
+            raise RuntimeError("libphysdock_hip.so ABI version mismatch")
+    return _lib
+
+
+#: every symbol include/physdock_hip.h declares (tests check the library exports all of them)
+SYMBOLS = {}
+
+
+def _declare(L):
+    def sig(name, *argtypes):
+        fn = getattr(L, name)
+        fn.argtypes = list(argtypes)
+        fn.restype = C.c_int
+        SYMBOLS[name] = fn
+
+    i, f, p, ll = C.c_int, C.c_float, C.c_void_p, C.c_longlong
+    sig("pd_abi_version")
+    sig("pd_init")
+    sig("pd_gemm", C.POINTER(GemmArgs), p)
+    sig("pd_rowstats", p, p, i, i, i, i, i, f, p)
+    sig("pd_rownorm", p, p, p, p, p, i, i, i, f, i, p)
+    sig("pd_attention", C.POINTER(AttnArgs), p)
+    sig("pd_graph_begin", p)
+    sig("pd_graph_end", p, C.POINTER(C.c_void_p))
+    sig("pd_graph_launch", p, p)
+    sig("pd_graph_destroy", p)
+    for name, args in _EXTRA_SIGS.items():
+        sig(name, *args)
+
+
+_EXTRA_SIGS = {}
+
+
+def register_sig(name, *argtypes):
+    """Used by the op modules to declare further launchers before the library is loaded."""
+    _EXTRA_SIGS[name] = argtypes
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.argtypes = list(argtypes)
+        fn.restype = C.c_int
+        SYMBOLS[name] = fn
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64), (t.device, t.dtype)
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")
+
+
+_inited = False
+
+
+def init():
+    global _inited
+    L = lib()
+    if not _inited:
+        check(L.pd_init(), "pd_init")
+        _inited = True
+    return L

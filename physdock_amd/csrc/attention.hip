@@ -1,0 +1,185 @@
+// Biased multi-head attention, head width 32, exact fp32 on v_mfma_f32_32x32x2_f32.
+//
+// Replaces F.scaled_dot_product_attention in every attention of the hot path
+// (reference primitives/attentions.py:48,92,130,211,259): DiT atom/token attention,
+// trunk atom attention, MSA row/column attention, triangle attention (row/col) and the
+// pair-biased single attention.
+//
+// Structure (flash style, one block = 4 waves = 128 queries of one (batch, head)):
+//   * K/V tiles of 64 keys are staged through LDS (double-buffered, register prefetch) and
+//     shared by the 4 waves; Q (32 rows per wave) lives in registers, pre-scaled by
+//     scale*log2(e).
+//   * Both MFMAs run "swapped": S^T = K.Q^T and O^T = V^T.P^T, so every lane owns ONE
+//     query (lane&31) and 16 of its keys / output channels.  The softmax row max/sum is then
+//     15 in-lane ops + one cross-half shuffle, P feeds the second MFMA straight from the
+//     accumulator registers (no LDS round trip), and the running rescale of O is lane-local.
+//   * The pair bias arrives in "fragment layout" [H][q-tile][k-tile][4][64][4] (written by
+//     pd_gemm PD_OUT_BIASFRAG, already multiplied by log2 e): each wave fetches its 32x32
+//     bias tile with four fully-coalesced 1 KiB loads.  The bias does not depend on the
+//     batch index; batch is the fastest grid dimension so the blocks that share a bias tile
+//     run together and the tile is served from L2 / Infinity Cache (the step- and
+//     sample-invariant biases of the DiT are hoisted out of the loop entirely).
+#include "common.h"
+#include "physdock_hip.h"
+
+namespace {
+
+constexpr int KT = 64;      // keys per LDS tile
+constexpr int LDKS = 36;    // K row stride (floats): conflict-free ds_read_b128
+constexpr int LDVS = 32;    // V row stride
+
+__global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args p) {
+    __shared__ __attribute__((aligned(16))) float sK[2][KT * LDKS];
+    __shared__ __attribute__((aligned(16))) float sV[2][KT * LDVS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.x, qb = blockIdx.y, h = blockIdx.z;
+    const int q0 = qb * 128 + wave * 32;
+    const int query = q0 + l31;
+    const bool wave_active = q0 < p.nq;
+
+    const float* Kb = p.K + (long long)b * p.k_bs + h * 32;
+    const float* Vb = p.V + (long long)b * p.v_bs + h * 32;
+
+    // Q fragment: lane (query, hh) holds dims 8t+4hh+e
+    f32x4 qf[4];
+    {
+        const float qs = p.scale * PD_LOG2E;
+        const float* qp = p.Q + (long long)b * p.q_bs + (long long)query * p.q_ss + h * 32 + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (query < p.nq) v = *reinterpret_cast<const f32x4*>(qp + 8 * t);
+            qf[t] = v * qs;
+        }
+    }
+
+    const int nkt32 = (p.nk + 31) >> 5;
+    const int nqt32 = (p.nq + 31) >> 5;
+    const float* bias_wave = nullptr;
+    if (p.bias && wave_active)
+        bias_wave = p.bias + (((long long)h * nqt32 + (q0 >> 5)) * nkt32) * 1024 + lane * 4;
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging: thread -> key row (tid>>3)+32*i, 16-byte chunk tid&7
+    const int srow = tid >> 3, schunk = (tid & 7) * 4;
+    f32x4 rk[2], rv[2];
+    auto gload = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = key0 + srow + 32 * i;
+            rk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (key < p.nk) {
+                rk[i] = *reinterpret_cast<const f32x4*>(Kb + (long long)key * p.k_ss + schunk);
+                rv[i] = *reinterpret_cast<const f32x4*>(Vb + (long long)key * p.v_ss + schunk);
+            }
+        }
+    };
+    auto sstore = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&sK[st][(srow + 32 * i) * LDKS + schunk]) = rk[i];
+            *reinterpret_cast<f32x4*>(&sV[st][(srow + 32 * i) * LDVS + schunk]) = rv[i];
+        }
+    };
+
+    const int nit = (p.nk + KT - 1) / KT;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    for (int it = 0; it < nit; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nit) gload((it + 1) * KT);
+        if (wave_active) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int kt32 = it * 2 + sub;
+                if (kt32 * 32 >= p.nk) break;
+                // bias tile first: its latency hides under the 16 QK^T MFMAs
+                f32x4 bf[4];
+                if (bias_wave) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        bf[g] = *reinterpret_cast<const f32x4*>(bias_wave + (long long)kt32 * 1024 + g * 256);
+                }
+                f32x16 s;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                const float* kbase = &sK[cur][(sub * 32 + l31) * LDKS + 4 * hh];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(kbase + 8 * t);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[t][e], s, 0, 0, 0);
+                }
+                if (bias_wave) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] += bf[r >> 2][r & 3];
+                }
+                if (kt32 * 32 + 32 > p.nk) {   // ragged last tile: padded keys drop out
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt32 * 32 + pd_frag_row(r, hh) >= p.nk) s[r] = -INFINITY;
+                }
+                float mloc = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+                const float m_new = fmaxf(m_run, mloc);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+                    psum += s[r];
+                }
+                l_run = l_run * alpha + psum;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] *= alpha;
+                const float* vbase = &sV[cur][(sub * 32 + 4 * hh) * LDVS + l31];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float vf = vbase[((r & 3) + 8 * (r >> 2)) * LDVS];
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o, 0, 0, 0);
+                }
+            }
+        }
+        if (it + 1 < nit) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (query < p.nq) {
+        const float l = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.0f / l;
+        float* op = p.O + (long long)b * p.o_bs + (long long)query * p.o_ss + h * 32 + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+            *reinterpret_cast<f32x4*>(op + 8 * g) = v;
+        }
+    }
+}
+
+}  // namespace
+
+PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
+    if (!a || !a->Q || !a->K || !a->V || !a->O) return PD_ERR_ARG;
+    if (a->nq <= 0 || a->nk <= 0 || a->nbatch <= 0 || a->nheads <= 0) return PD_ERR_ARG;
+    // 16-byte vector access on every row start
+    const long long strides[] = {a->q_bs, a->q_ss, a->k_bs, a->k_ss, a->v_bs, a->v_ss, a->o_bs, a->o_ss};
+    for (long long s : strides) if (s % 4) return PD_ERR_UNSUPPORTED;
+    if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O | (uintptr_t)a->bias) & 15)
+        return PD_ERR_UNSUPPORTED;
+    dim3 grid(a->nbatch, (a->nq + 127) / 128, a->nheads);
+    hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    return pd_check_launch();
+}

@@ -1,0 +1,48 @@
+// Shared device helpers for the PhysDock sampler kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PD_EXPORT extern "C" __attribute__((visibility("default")))
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// error codes of the C ABI (include/physdock_hip.h)
+enum { PD_OK = 0, PD_ERR_ARG = -1, PD_ERR_LAUNCH = -2, PD_ERR_UNSUPPORTED = -3 };
+
+static inline int pd_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PD_OK : PD_ERR_LAUNCH;
+}
+
+#define PD_LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ float pd_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float pd_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// activation ids shared by prologues/epilogues
+enum { PD_ACT_NONE = 0, PD_ACT_SILU = 1, PD_ACT_SIGMOID = 2, PD_ACT_RELU = 3 };
+
+__device__ __forceinline__ float pd_act(float x, int act) {
+    switch (act) {
+        case PD_ACT_SILU: return pd_silu(x);
+        case PD_ACT_SIGMOID: return pd_sigmoid(x);
+        case PD_ACT_RELU: return fmaxf(x, 0.0f);
+        default: return x;
+    }
+}
+
+// row index inside a 32x32 MFMA C fragment: lane half hh (=lane>>5), register r (0..15)
+__device__ __forceinline__ int pd_frag_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

@@ -1,0 +1,94 @@
+"""Thin Python launch wrappers over the C ABI (one function per launcher).
+
+These add no arithmetic: they fill the argument structs from tensor metadata and call
+libphysdock_hip.so on the current torch stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, OUT_BIASFRAG, OUT_OPM, OUT_ROWMAJOR,
+                   OUT_TRANSPOSED, AttnArgs, GemmArgs, check, ptr, stream)
+
+RMS, LN = 0, 1
+
+
+def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0, sY=0,
+         a_kmajor=False, w_kmajor=False, stats=None, pro_w=None, pro_b=None, pro_rows_per_group=0,
+         pro_gstride=0, pro_act=ACT_NONE, rowscale_acc=None, bias=None, sBias=0, hn_w=None, hn_cols=0,
+         hn_split=32, hn_eps=0.0, act=ACT_NONE, glu=0, rowscale=None, maskadd=None, maskval=0.0,
+         mul=None, ldmul=0, mul_rows_per_group=0, mul_gstride=0, out_scale=1.0, res=None, ldres=0,
+         res_row_mod=0, sRes=0, out_mode=OUT_ROWMAJOR, T1=0, T2=0, frag_transpose=False):
+    """Y = epilogue(prologue(A) @ W^T); see include/physdock_hip.h pd_gemm_args.
+    A/W/Y and the optional operands may be tensors or raw device addresses (ints)."""
+    def P(x):
+        return x if (x is None or isinstance(x, int)) else ptr(x)
+    n_out = N // 2 if glu else N
+    a = GemmArgs()
+    a.A, a.W, a.Y = P(A), P(W), P(Y)
+    a.M, a.N, a.K = M, N, K
+    a.lda = lda if lda is not None else (M if a_kmajor else K)
+    a.ldw = ldw if ldw is not None else (N if w_kmajor else K)
+    a.ldy = ldy if ldy is not None else (M if out_mode == OUT_TRANSPOSED else n_out)
+    a.batch, a.sA, a.sW, a.sY = batch, sA, sW, sY
+    a.a_kmajor, a.w_kmajor = int(a_kmajor), int(w_kmajor)
+    a.stats, a.pro_w, a.pro_b = P(stats), P(pro_w), P(pro_b)
+    a.pro_rows_per_group, a.pro_gstride, a.pro_act = pro_rows_per_group, pro_gstride, pro_act
+    a.rowscale_acc, a.bias, a.sBias = P(rowscale_acc), P(bias), sBias
+    a.hn_w, a.hn_cols, a.hn_split, a.hn_eps = P(hn_w), hn_cols, hn_split, hn_eps
+    a.act, a.glu = act, glu
+    a.rowscale, a.maskadd, a.maskval = P(rowscale), P(maskadd), maskval
+    a.mul, a.ldmul, a.mul_rows_per_group, a.mul_gstride = P(mul), ldmul, mul_rows_per_group, mul_gstride
+    a.out_scale = out_scale
+    a.res, a.ldres, a.res_row_mod, a.sRes = P(res), (ldres or n_out), res_row_mod, sRes
+    a.out_mode, a.T1, a.T2, a.frag_transpose = out_mode, T1, T2, int(frag_transpose)
+    check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm")
+
+
+def rowstats(x, stats, M, Cdim, *, ldx=None, kmajor=False, mode=RMS, eps=1e-8):
+    xp = x if isinstance(x, int) else ptr(x)
+    check(_lib.init().pd_rowstats(xp, ptr(stats), M, Cdim, ldx if ldx is not None else (M if kmajor else Cdim),
+                                  int(kmajor), mode, eps, stream()), "pd_rowstats")
+
+
+def rownorm(x, y, M, Cdim, *, res=None, w=None, b=None, mode=RMS, eps=1e-8, act=ACT_NONE):
+    check(_lib.init().pd_rownorm(ptr(x), ptr(y), ptr(res), ptr(w), ptr(b), M, Cdim, mode, eps, act, stream()),
+          "pd_rownorm")
+
+
+def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_strides, o_strides, bias=None,
+              scale=1.0 / math.sqrt(32.0)):
+    """strides = (batch_stride, seq_stride) in floats; Q/K/V/O tensors or raw addresses."""
+    def P(x):
+        return x if (x is None or isinstance(x, int)) else ptr(x)
+    a = AttnArgs()
+    a.Q, a.K, a.V, a.O = P(Q), P(K), P(V), P(O)
+    a.nq, a.nk, a.nbatch, a.nheads = nq, nk, nbatch, nheads
+    a.q_bs, a.q_ss = q_strides
+    a.k_bs, a.k_ss = k_strides
+    a.v_bs, a.v_ss = v_strides
+    a.o_bs, a.o_ss = o_strides
+    a.bias = P(bias)
+    a.scale = scale
+    check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention")
+
+
+def bias_frag_numel(nheads, nq, nk):
+    return nheads * ((nq + 31) // 32) * ((nk + 31) // 32) * 1024
+
+
+def bias_to_frag(bias):
+    """[H,nq,nk] dense bias (CPU or device tensor) -> fragment layout, scaled by log2(e).
+    Test helper mirroring the address map of pd_gemm's PD_OUT_BIASFRAG store."""
+    H, nq, nk = bias.shape
+    nqt, nkt = (nq + 31) // 32, (nk + 31) // 32
+    pad = torch.zeros(H, nqt * 32, nkt * 32, dtype=bias.dtype, device=bias.device)
+    pad[:, :nq, :nk] = bias * _lib.LOG2E
+    # [H, qt, q5, kt, k5] with k5 = 8*g + 4*hh + e ; frag index = g*256 + (q5 + 32*hh)*4 + e
+    x = pad.reshape(H, nqt, 32, nkt, 4, 2, 4)            # q5, kt, g, hh, e
+    x = x.permute(0, 1, 3, 4, 5, 2, 6)                    # H, qt, kt, g, hh, q5, e
+    return x.reshape(-1).contiguous()

@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the two dominant kernels at the hot-path shapes (GPU box)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from physdock_amd import ops
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    print(f"B={B}")
+    for (M, N, K, glu, tag) in [(B * 256, 1536, 512, 0, "token qkv"), (B * 256, 512, 512, 0, "token out"),
+                                (B * 256, 2816, 512, 1, "token ffn13"), (B * 256, 512, 1408, 0, "token ffn2"),
+                                (B * 2048, 384, 128, 0, "atom qkv"), (B * 2048, 128, 128, 0, "atom out"),
+                                (B * 2048, 768, 128, 1, "atom ffn13"), (B * 2048, 128, 384, 0, "atom ffn2"),
+                                (65536, 512, 128, 0, "pair qkvg"), (65536, 768, 128, 1, "pair ffn13"),
+                                (4096, 4096, 4096, 0, "square 4096")]:
+        A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda")
+        Y = torch.empty(M, N // 2 if glu else N, device="cuda")
+        t = timeit(lambda: ops.gemm(A, W, Y, M, N, K, glu=glu))
+        print(f"gemm {tag:14s} M={M:7d} N={N:5d} K={K:5d}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:7.1f} TF")
+    for (nb, H, n, tag) in [(B, 4, 2048, "dit atom"), (B, 16, 256, "dit token"), (256, 4, 256, "triangle"),
+                            (1, 4, 2048, "trunk atom"), (128, 8, 256, "msa row")]:
+        C = H * 32
+        q = torch.randn(nb, n, 3 * C, device="cuda")
+        o = torch.empty(nb, n, C, device="cuda")
+        bias = torch.randn(ops.bias_frag_numel(H, n, n), device="cuda")
+        st = (n * 3 * C, 3 * C)
+        f = lambda: ops.attention(q.data_ptr(), q.data_ptr() + 4 * C, q.data_ptr() + 8 * C, o, nq=n, nk=n, nbatch=nb,
+                                  nheads=H, q_strides=st, k_strides=st, v_strides=st, o_strides=(n * C, C), bias=bias)
+        t = timeit(f)
+        fl = 4.0 * nb * H * n * n * 32
+        print(f"attn {tag:12s} nb={nb:4d} H={H:2d} n={n:5d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF")
+
+
+if __name__ == "__main__":
+    main()
