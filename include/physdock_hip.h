@@ -68,7 +68,7 @@ typedef struct pd_gemm_args {
     int out_mode;                /* PD_OUT_*                                                 */
     int T1, T2;                  /* OPM: T2 = tokens; BIASFRAG: rows m = (i,j), i<T1, j<T2   */
     int frag_transpose;          /* BIASFRAG: query = j, key = i                             */
-    int vecA, vecW;              /* set by the launcher                                      */
+    int vecA, vecW, vecY;        /* set by the launcher                                      */
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
 

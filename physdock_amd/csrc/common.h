@@ -33,6 +33,21 @@ __device__ __forceinline__ float pd_act(float x, int act) {
     }
 }
 
+// activation on a float4 with ONE uniform branch (keeps unrolled callers compact)
+__device__ __forceinline__ void pd_act4(f32x4& v, int act) {
+    if (act == PD_ACT_NONE) return;
+    if (act == PD_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+    } else if (act == PD_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pd_silu(v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pd_sigmoid(v[e]);
+    }
+}
+
 // row index inside a 32x32 MFMA C fragment: lane half hh (=lane>>5), register r (0..15)
 __device__ __forceinline__ int pd_frag_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 

@@ -7,15 +7,21 @@
 //     RMSNorm / LayerNorm / AdaLN-Zero folded into the A-tile staging
 //     (rms_norm.py:14-19, adaptive_layer_norm_zero.py:18-21),
 //   * SwiGLU (feed_forward.py:30-31) and the sigmoid-gated triangle projections
-//     (attentions.py:161-162) as paired-tile "GLU" epilogues,
+//     (attentions.py:161-162) as paired-column "GLU" epilogues,
 //   * the triangle-multiplication einsum (attentions.py:164) as a 32-channel batched GEMM,
 //   * the outer-product-mean einsum (outer_product_mean.py:28),
 //   * pair-bias projections written straight into the attention kernel's fragment layout.
 //
 // Arithmetic is exact fp32 on v_mfma_f32_32x32x2_f32 (157 TF peak = the roofline of this
-// path; parity to 1e-3 A forbids reduced precision).  Block = 256 threads = 4 waves; LDS
-// tiles are [rows][32+4] floats so that one ds_read_b128 per lane feeds four MFMA k-steps
-// (lane half h takes k = 8*g + 4*h + e, the same permutation on both operands).
+// path; parity to 1e-3 A forbids reduced precision).  Block = 256 threads = 4 waves.
+//   main loop : global -> registers (branch-free, clamped addresses) is issued BEFORE the MFMA
+//               block of the current k-tile and written to the other LDS stage AFTER it (the
+//               norm prologue is applied in that write), one barrier per k-tile.  LDS tiles are
+//               [rows][32+4] floats so one ds_read_b128 per lane feeds four MFMA k-steps (lane
+//               half h takes k = 8g+4h+e, the same permutation on both operands).
+//   epilogue  : accumulators are parked in LDS (re-using the stage buffers) and re-read
+//               row-major, so bias / gate / residual / output traffic is 16-byte coalesced and
+//               the epilogue is one compact rolled loop whatever the fusion flags.
 #include "common.h"
 #include "physdock_hip.h"
 
@@ -24,15 +30,90 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;   // padded row (floats): 144 B, keeps ds_read_b128 conflict-free
 constexpr int NT = 256;
+constexpr int PADM = 4;
 
-struct RowStat { float mean, rstd; };
+template <int BM, int BN, bool AKM, bool WKM>
+struct Cfg {
+    static constexpr int A_TILE = AKM ? BK * (BM + PADM) : BM * LDK;
+    static constexpr int W_TILE = WKM ? BK * (BN + PADM) : BN * LDK;
+    static constexpr int LDC = BN + 4;
+    static constexpr int STAGE_FLOATS = 2 * (A_TILE + W_TILE);
+    static constexpr int C_FLOATS = BM * LDC;
+    static constexpr int LDS_BYTES = 4 * (STAGE_FLOATS > C_FLOATS ? STAGE_FLOATS : C_FLOATS);
+};
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool WKM>
+// One operand tile loader: R rows (m or n) x BK, either [R][K] (k contiguous) or k-major [K][R].
+template <int R, bool KM, bool VEC>
+struct TileLoader {
+    static constexpr int SLOTS = R / 32;               // float4 per thread per k-tile
+    static constexpr int CPR = R / 4;                  // k-major: 16-byte chunks per k-row
+    static constexpr int KSTEP = NT / CPR;
+    f32x4 reg[SLOTS];
+
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int r0, int rows, int k0, int K, int tid) {
+        if constexpr (!KM) {
+            const int kc = k0 + (tid & 7) * 4;
+            const int kcl = kc < K ? kc : 0;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                int r = r0 + (tid >> 3) + 32 * i;
+                r = r < rows ? r : rows - 1;
+                const float* src = base + (long long)r * ld + kcl;
+                if constexpr (VEC) reg[i] = *reinterpret_cast<const f32x4*>(src);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) reg[i][e] = src[kcl + e < K ? e : 0];
+                }
+            }
+        } else {
+            const int rc = r0 + (tid % CPR) * 4;
+            const int rcl = rc < rows ? rc : 0;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                int k = k0 + tid / CPR + KSTEP * i;
+                k = k < K ? k : K - 1;
+                reg[i] = *reinterpret_cast<const f32x4*>(base + (long long)k * ld + rcl);
+            }
+        }
+    }
+    // zero the out-of-range elements (rows >= rows_total, k >= K)
+    __device__ __forceinline__ void mask(int r0, int rows, int k0, int K, int tid) {
+        if constexpr (!KM) {
+            const int kc = k0 + (tid & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                const bool rok = r0 + (tid >> 3) + 32 * i < rows;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) reg[i][e] = (rok && kc + e < K) ? reg[i][e] : 0.f;
+            }
+        } else {
+            const int rc = r0 + (tid % CPR) * 4;
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i) {
+                const bool kok = k0 + tid / CPR + KSTEP * i < K;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) reg[i][e] = (kok && rc + e < rows) ? reg[i][e] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ s, int tid) const {
+        if constexpr (!KM) {
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i)
+                *reinterpret_cast<f32x4*>(s + ((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4) = reg[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < SLOTS; ++i)
+                *reinterpret_cast<f32x4*>(s + (tid / CPR + KSTEP * i) * (R + PADM) + (tid % CPR) * 4) = reg[i];
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool WKM, bool VEC, int PRO>
 __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
+    using C_ = Cfg<BM, BN, AKM, WKM>;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int PADM = 4;
-    constexpr int A_TILE = AKM ? BK * (BM + PADM) : BM * LDK;
-    constexpr int W_TILE = WKM ? BK * (BN + PADM) : BN * LDK;
+    constexpr int A_TILE = C_::A_TILE, W_TILE = C_::W_TILE, LDC = C_::LDC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                 // 2 stages
     float* sW = smem + 2 * A_TILE;    // 2 stages
@@ -46,144 +127,68 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     const float* __restrict__ W = p.W + (long long)bz * p.sW;
     float* __restrict__ Y = p.Y + (long long)bz * p.sY;
 
-    // ---- per-thread load slots -------------------------------------------------------
-    constexpr int A_SLOTS = BM / 32, W_SLOTS = BN / 32;   // float4 per thread per k-tile
-    // non-k-major: slot i -> row (tid>>3)+32*i, k-chunk (tid&7)
-    // k-major    : chunks per k-row = R/4; slot i -> k-row tid/(R/4) + (NT/(R/4))*i, m-chunk tid%(R/4)
-    f32x4 ra[A_SLOTS], rw[W_SLOTS];
+    TileLoader<BM, AKM, VEC> la;
+    TileLoader<BN, WKM, VEC> lw;
 
-    // prologue state for A (fixed rows per thread)
-    const bool pro = p.stats != nullptr;
-    RowStat st[AKM ? 4 : A_SLOTS];
-    int grp_off[AKM ? 4 : A_SLOTS];
-    if (pro) {
-        const int nst = AKM ? 4 : A_SLOTS;
+    // ---- prologue state: this thread always stages the same rows of A ------------------
+    // PRO 0: none   1: pro_w/pro_b shared by all rows   2: per row group (AdaLN with per-sample t)
+    constexpr int NST = AKM ? 4 : BM / 32;
+    float st_mean[NST], st_rstd[NST];
+    int grp_off[NST];
 #pragma unroll
-        for (int i = 0; i < nst; ++i) {
+    for (int i = 0; i < NST; ++i) { st_mean[i] = 0.f; st_rstd[i] = 1.f; grp_off[i] = 0; }
+    if constexpr (PRO != 0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
             int m = AKM ? bm0 + (tid % (BM / 4)) * 4 + i : bm0 + (tid >> 3) + 32 * i;
-            st[i].mean = 0.f; st[i].rstd = 0.f; grp_off[i] = 0;
-            if (m < p.M) {
-                st[i].mean = p.stats[2 * ((long long)bz * p.M + m)];
-                st[i].rstd = p.stats[2 * ((long long)bz * p.M + m) + 1];
-                if (p.pro_rows_per_group > 0) grp_off[i] = (m / p.pro_rows_per_group) * p.pro_gstride;
-            }
+            m = m < p.M ? m : p.M - 1;
+            st_mean[i] = p.stats[2 * ((long long)bz * p.M + m)];
+            st_rstd[i] = p.stats[2 * ((long long)bz * p.M + m) + 1];
+            if constexpr (PRO == 2) grp_off[i] = (m / p.pro_rows_per_group) * p.pro_gstride;
         }
     }
-
-    auto load_A = [&](int k0) {
-        if constexpr (!AKM) {
-            const int kc = k0 + (tid & 7) * 4;
-#pragma unroll
-            for (int i = 0; i < A_SLOTS; ++i) {
-                const int m = bm0 + (tid >> 3) + 32 * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < p.M) {
-                    const float* src = A + (long long)m * p.lda + kc;
-                    if (p.vecA && kc + 3 < p.K) v = *reinterpret_cast<const f32x4*>(src);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (kc + e < p.K) v[e] = src[e];
-                    }
-                    if (pro) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (kc + e < p.K) {
-                                float pw = p.pro_w ? p.pro_w[grp_off[i] + kc + e] : 1.f;
-                                float pb = p.pro_b ? p.pro_b[grp_off[i] + kc + e] : 0.f;
-                                v[e] = (v[e] - st[i].mean) * st[i].rstd * pw + pb;
-                            }
-                        }
-                    }
-                    if (p.pro_act) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = pd_act(v[e], p.pro_act);
-                    }
+    auto transform_A = [&](int k0) {
+        if constexpr (PRO != 0) {
+            if constexpr (!AKM) {
+                int kc = k0 + (tid & 7) * 4;
+                kc = kc < p.K ? kc : 0;
+                f32x4 pw, pb;
+                if constexpr (PRO == 1) {
+                    pw = *reinterpret_cast<const f32x4*>(p.pro_w + kc);
+                    pb = *reinterpret_cast<const f32x4*>(p.pro_b + kc);
                 }
-                ra[i] = v;
-            }
-        } else {
-            constexpr int CPR = BM / 4, KSTEP = NT / CPR;
-            const int mc = bm0 + (tid % CPR) * 4;
 #pragma unroll
-            for (int i = 0; i < A_SLOTS; ++i) {
-                const int k = k0 + tid / CPR + KSTEP * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < p.K) {
-                    const float* src = A + (long long)k * p.lda + mc;
-                    if (p.vecA && mc + 3 < p.M) v = *reinterpret_cast<const f32x4*>(src);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (mc + e < p.M) v[e] = src[e];
+                for (int i = 0; i < BM / 32; ++i) {
+                    if constexpr (PRO == 2) {
+                        pw = *reinterpret_cast<const f32x4*>(p.pro_w + grp_off[i] + kc);
+                        pb = *reinterpret_cast<const f32x4*>(p.pro_b + grp_off[i] + kc);
                     }
-                    if (pro) {
-                        float pw = p.pro_w ? p.pro_w[k] : 1.f;
-                        float pb = p.pro_b ? p.pro_b[k] : 0.f;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (v[e] - st[e].mean) * st[e].rstd * pw + pb;
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        la.reg[i][e] = (la.reg[i][e] - st_mean[i]) * st_rstd[i] * pw[e] + pb[e];
                 }
-                ra[i] = v;
+            } else {
+                constexpr int CPR = BM / 4, KSTEP = NT / CPR;
+#pragma unroll
+                for (int i = 0; i < BM / 32; ++i) {
+                    int k = k0 + tid / CPR + KSTEP * i;
+                    k = k < p.K ? k : 0;
+                    const float pw = p.pro_w[k], pb = p.pro_b[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) la.reg[i][e] = (la.reg[i][e] - st_mean[e]) * st_rstd[e] * pw + pb;
+                }
             }
         }
-    };
-    auto load_W = [&](int k0) {
-        if constexpr (!WKM) {
-            const int kc = k0 + (tid & 7) * 4;
+        if (p.pro_act == PD_ACT_RELU) {
 #pragma unroll
-            for (int i = 0; i < W_SLOTS; ++i) {
-                const int n = bn0 + (tid >> 3) + 32 * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < p.N) {
-                    const float* src = W + (long long)n * p.ldw + kc;
-                    if (p.vecW && kc + 3 < p.K) v = *reinterpret_cast<const f32x4*>(src);
-                    else {
+            for (int i = 0; i < BM / 32; ++i)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (kc + e < p.K) v[e] = src[e];
-                    }
-                }
-                rw[i] = v;
-            }
-        } else {
-            constexpr int CPR = BN / 4, KSTEP = NT / CPR;
-            const int nc = bn0 + (tid % CPR) * 4;
+                for (int e = 0; e < 4; ++e) la.reg[i][e] = fmaxf(la.reg[i][e], 0.f);
+        } else if (p.pro_act == PD_ACT_SILU) {
 #pragma unroll
-            for (int i = 0; i < W_SLOTS; ++i) {
-                const int k = k0 + tid / CPR + KSTEP * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < p.K) {
-                    const float* src = W + (long long)k * p.ldw + nc;
-                    if (p.vecW && nc + 3 < p.N) v = *reinterpret_cast<const f32x4*>(src);
-                    else {
+            for (int i = 0; i < BM / 32; ++i)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (nc + e < p.N) v[e] = src[e];
-                    }
-                }
-                rw[i] = v;
-            }
-        }
-    };
-    auto store_tiles = [&](int stage) {
-        float* a = sA + stage * A_TILE;
-        float* w = sW + stage * W_TILE;
-        if constexpr (!AKM) {
-#pragma unroll
-            for (int i = 0; i < A_SLOTS; ++i)
-                *reinterpret_cast<f32x4*>(a + ((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4) = ra[i];
-        } else {
-            constexpr int CPR = BM / 4, KSTEP = NT / CPR;
-#pragma unroll
-            for (int i = 0; i < A_SLOTS; ++i)
-                *reinterpret_cast<f32x4*>(a + (tid / CPR + KSTEP * i) * (BM + PADM) + (tid % CPR) * 4) = ra[i];
-        }
-        if constexpr (!WKM) {
-#pragma unroll
-            for (int i = 0; i < W_SLOTS; ++i)
-                *reinterpret_cast<f32x4*>(w + ((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4) = rw[i];
-        } else {
-            constexpr int CPR = BN / 4, KSTEP = NT / CPR;
-#pragma unroll
-            for (int i = 0; i < W_SLOTS; ++i)
-                *reinterpret_cast<f32x4*>(w + (tid / CPR + KSTEP * i) * (BN + PADM) + (tid % CPR) * 4) = rw[i];
+                for (int e = 0; e < 4; ++e) la.reg[i][e] = pd_silu(la.reg[i][e]);
         }
     };
 
@@ -196,13 +201,22 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    load_A(0); load_W(0);
-    store_tiles(0);
+    la.load(A, p.lda, bm0, p.M, 0, p.K, tid);
+    lw.load(W, p.ldw, bn0, p.N, 0, p.K, tid);
+    transform_A(0);
+    la.mask(bm0, p.M, 0, p.K, tid);
+    lw.mask(bn0, p.N, 0, p.K, tid);
+    la.store(sA, tid);
+    lw.store(sW, tid);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) { load_A((kt + 1) * BK); load_W((kt + 1) * BK); }
+        const bool more = kt + 1 < nk;
+        if (more) {
+            la.load(A, p.lda, bm0, p.M, (kt + 1) * BK, p.K, tid);
+            lw.load(W, p.ldw, bn0, p.N, (kt + 1) * BK, p.K, tid);
+        }
         const float* a = sA + cur * A_TILE;
         const float* w = sW + cur * W_TILE;
 #pragma unroll
@@ -234,152 +248,205 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fw[j][e], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        if (more) {
+            transform_A((kt + 1) * BK);
+            la.mask(bm0, p.M, (kt + 1) * BK, p.K, tid);
+            lw.mask(bn0, p.N, (kt + 1) * BK, p.K, tid);
+            la.store(sA + (cur ^ 1) * A_TILE, tid);
+            lw.store(sW + (cur ^ 1) * W_TILE, tid);
+        }
         __syncthreads();
     }
 
-    // ---- epilogue ------------------------------------------------------------------
+    // ---- park the accumulators in LDS (stage buffers are free after the last barrier) ---
+    float* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * (TM * 32) + i * 32 + pd_frag_row(r, hh)) * LDC + wn * (TN * 32) + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+
+    // ---- epilogue ------------------------------------------------------------------------
     const int glu = p.glu;
+    const int N_out = glu ? p.N / 2 : p.N;
+    const int BN_out = glu ? BN / 2 : BN;
+    const int bn_out0 = glu ? bn0 / 2 : bn0;
+    const float* biasp = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
+    const float* resp = p.res ? p.res + (long long)bz * p.sRes : nullptr;
+
+    if (p.out_mode == PD_OUT_ROWMAJOR) {
+        const int cpr = BN_out / 4;
+#pragma unroll 1
+        for (int idx = tid; idx < BM * cpr; idx += NT) {
+            const int row = idx / cpr, c = idx - row * cpr;
+            const int m = bm0 + row, n = bn_out0 + c * 4;
+            const bool ok = m < p.M && n < N_out;
+            const int pc = glu ? ((c * 4) >> 5) * 64 + ((c * 4) & 31) : c * 4;    // packed column in Cs / bias
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + pc);
+            if (p.rowscale_acc) v *= (m < p.M ? p.rowscale_acc[(long long)bz * p.M + m] : 0.f);
+            if (biasp) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (glu && (j & 1)) continue;
-            const int ncol_packed = bn0 + wn * (TN * 32) + j * 32;     // packed column base of this tile
-            const int n_in = ncol_packed + l31;                        // packed column (bias index)
-            int n_out = n_in;
-            if (glu) n_out = (bn0 + wn * (TN * 32)) / 2 + (j >> 1) * 32 + l31;
-            const int N_out = glu ? p.N / 2 : p.N;
-            const bool ncol_ok = n_out < N_out;
-            float bias_a = 0.f, bias_b = 0.f;
-            if (p.bias) {
-                const float* bp = p.bias + (long long)bz * p.sBias;
-                if (n_in < p.N) bias_a = bp[n_in];
-                if (glu && n_in + 32 < p.N) bias_b = bp[n_in + 32];
+                for (int e = 0; e < 4; ++e) if (bn0 + pc + e < p.N) v[e] += biasp[bn0 + pc + e];
             }
-            const bool headnorm = p.hn_w != nullptr && ncol_packed < p.hn_cols;
-            float hn_w = 0.f;
-            if (headnorm) hn_w = p.hn_w[(ncol_packed / p.hn_split) * 32 + l31];
-            float vals[16];
+            if (p.hn_w && bn0 + pc < p.hn_cols) {   // per-head RMSNorm: 8 consecutive lanes own one 32-wide head
+                float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+                const float rs = rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps);
+                const float* hw = p.hn_w + ((bn0 + pc) / p.hn_split) * 32 + ((bn0 + pc) & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = bm0 + wm * (TM * 32) + i * 32 + pd_frag_row(r, hh);
-                float v = acc[i][j][r];
-                if (p.rowscale_acc) v *= (m < p.M) ? p.rowscale_acc[(long long)bz * p.M + m] : 0.f;
-                v += bias_a;
-                if (headnorm) {
-                    float ss = v * v;
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * rs * hw[e];
+            }
+            if (glu) {
+                f32x4 b2 = *reinterpret_cast<const f32x4*>(Cs + row * LDC + pc + 32);
+                if (biasp) {
 #pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-                    v = v * rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps) * hn_w;
+                    for (int e = 0; e < 4; ++e) if (bn0 + pc + 32 + e < p.N) b2[e] += biasp[bn0 + pc + 32 + e];
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (glu == 1) ? pd_silu(v[e]) * b2[e] : v[e] * pd_sigmoid(b2[e]);
+            } else {
+                pd_act4(v, p.act);
+            }
+            if (!ok) continue;
+            if (p.rowscale) v *= p.rowscale[m];
+            if (p.maskadd && p.maskadd[m] == 0.f) v += p.maskval;
+            const bool full = p.vecY && n + 3 < N_out;
+            if (p.mul) {
+                const float* mp = p.mul + (p.mul_rows_per_group > 0
+                                               ? (long long)(m / p.mul_rows_per_group) * p.mul_gstride
+                                               : (long long)m * p.ldmul) + n;
+                if (full) v *= *reinterpret_cast<const f32x4*>(mp);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < N_out) v[e] *= mp[e];
+                }
+            }
+            v *= p.out_scale;
+            if (resp) {
+                const int mr = p.res_row_mod > 0 ? m % p.res_row_mod : m;
+                const float* rp = resp + (long long)mr * p.ldres + n;
+                if (full) v += *reinterpret_cast<const f32x4*>(rp);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < N_out) v[e] += rp[e];
+                }
+            }
+            float* yp = Y + (long long)m * p.ldy + n;
+            if (full) *reinterpret_cast<f32x4*>(yp) = v;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < N_out) yp[e] = v[e];
+            }
+        }
+    } else if (p.out_mode == PD_OUT_TRANSPOSED) {
+        // Y[n][m]: 4 consecutive m per thread.  Supports bias, glu/act, rowscale, out_scale.
+        const int mch = BM / 4;
+#pragma unroll 1
+        for (int idx = tid; idx < BN_out * mch; idx += NT) {
+            const int nl = idx / mch, mc = idx - nl * mch;
+            const int n = bn_out0 + nl, m0 = bm0 + mc * 4;
+            if (n >= N_out || m0 >= p.M) continue;
+            const int pc = glu ? (nl >> 5) * 64 + (nl & 31) : nl;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = Cs[(mc * 4 + e) * LDC + pc];
+                if (biasp && bn0 + pc < p.N) a += biasp[bn0 + pc];
                 if (glu) {
-                    float b2 = 0.f;
-                    if constexpr (TN >= 2) b2 = acc[i][j | 1][r] + bias_b;
-                    v = (glu == 1) ? pd_silu(v) * b2 : v * pd_sigmoid(b2);
-                } else {
-                    v = pd_act(v, p.act);
-                }
-                vals[r] = v;
+                    float b2 = Cs[(mc * 4 + e) * LDC + pc + 32];
+                    if (biasp && bn0 + pc + 32 < p.N) b2 += biasp[bn0 + pc + 32];
+                    a = (glu == 1) ? pd_silu(a) * b2 : a * pd_sigmoid(b2);
+                } else a = pd_act(a, p.act);
+                if (p.rowscale && m0 + e < p.M) a *= p.rowscale[m0 + e];
+                v[e] = a * p.out_scale;
             }
-            // row-dependent post-ops + store
-            if (p.out_mode == PD_OUT_ROWMAJOR || p.out_mode == PD_OUT_OPM || p.out_mode == PD_OUT_BIASFRAG) {
+            float* yp = Y + (long long)n * p.ldy + m0;
+            if (p.vecY && m0 + 3 < p.M) *reinterpret_cast<f32x4*>(yp) = v;
+            else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = bm0 + wm * (TM * 32) + i * 32 + pd_frag_row(r, hh);
-                    if (m >= p.M || !ncol_ok) continue;
-                    float v = vals[r];
-                    if (p.rowscale) v *= p.rowscale[m];
-                    if (p.maskadd && p.maskadd[m] == 0.f) v += p.maskval;
-                    if (p.mul) {
-                        long long mi = p.mul_rows_per_group > 0
-                            ? (long long)(m / p.mul_rows_per_group) * p.mul_gstride
-                            : (long long)m * p.ldmul;
-                        v *= p.mul[mi + n_out];
-                    }
-                    v *= p.out_scale;
-                    if (p.res) {
-                        const int mr = p.res_row_mod > 0 ? m % p.res_row_mod : m;
-                        v += p.res[(long long)bz * p.sRes + (long long)mr * p.ldres + n_out];
-                    }
-                    if (p.out_mode == PD_OUT_ROWMAJOR) {
-                        Y[(long long)m * p.ldy + n_out] = v;
-                    } else if (p.out_mode == PD_OUT_OPM) {
-                        // rows (i,c), cols (j,d) -> [i][j][c][d]   (outer_product_mean.py:28)
-                        const int ii = m >> 5, c = m & 31, jj = n_out >> 5, d = n_out & 31;
-                        Y[(((long long)ii * p.T2 + jj) * 32 + c) * 32 + d] = v;
-                    } else {
-                        // attention-bias fragment layout (see attention.hip); n_out = head
-                        int qi = m / p.T2, kj = m % p.T2, nq = p.T1, nkk = p.T2;
-                        if (p.frag_transpose) { int t = qi; qi = kj; kj = t; nq = p.T2; nkk = p.T1; }
-                        const int nqt = (nq + 31) >> 5, nkt = (nkk + 31) >> 5;
-                        const long long base = (((long long)n_out * nqt + (qi >> 5)) * nkt + (kj >> 5)) * 1024;
-                        const int k5 = kj & 31;
-                        Y[base + (k5 >> 3) * 256 + ((qi & 31) + 32 * ((k5 >> 2) & 1)) * 4 + (k5 & 3)] = v;
-                    }
-                }
-            } else {   // PD_OUT_TRANSPOSED: Y[n][m], 4 consecutive m per register group
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int m0 = bm0 + wm * (TM * 32) + i * 32 + 8 * g4 + 4 * hh;
-                    if (!ncol_ok) continue;
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = vals[4 * g4 + e];
-                        const int m = m0 + e;
-                        if (m < p.M) {
-                            if (p.rowscale) v *= p.rowscale[m];
-                            v *= p.out_scale;
-                        }
-                        o[e] = v;
-                    }
-                    float* dst = Y + (long long)n_out * p.ldy + m0;
-                    if (m0 + 3 < p.M && (p.ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0) *reinterpret_cast<f32x4*>(dst) = o;
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (m0 + e < p.M) dst[e] = o[e];
-                    }
-                }
+                for (int e = 0; e < 4; ++e) if (m0 + e < p.M) yp[e] = v[e];
+            }
+        }
+    } else {
+        // PD_OUT_OPM / PD_OUT_BIASFRAG: scalar scatter (bias, maskadd, out_scale)
+#pragma unroll 1
+        for (int idx = tid; idx < BM * BN; idx += NT) {
+            const int row = idx / BN, col = idx - row * BN;
+            const int m = bm0 + row, n = bn0 + col;
+            if (m >= p.M || n >= p.N) continue;
+            float v = Cs[row * LDC + col];
+            if (biasp) v += biasp[n];
+            if (p.maskadd && p.maskadd[m] == 0.f) v += p.maskval;
+            v *= p.out_scale;
+            if (p.out_mode == PD_OUT_OPM) {
+                // rows (i,c), cols (j,d) -> [i][j][c][d]   (outer_product_mean.py:28)
+                const int ii = m >> 5, c = m & 31, jj = n >> 5, d = n & 31;
+                Y[(((long long)ii * p.T2 + jj) * 32 + c) * 32 + d] = v;
+            } else {
+                // attention-bias fragment layout (attention.hip); n = head, m = (i, j)
+                int qi = m / p.T2, kj = m - qi * p.T2, nq = p.T1, nkk = p.T2;
+                if (p.frag_transpose) { const int t = qi; qi = kj; kj = t; nq = p.T2; nkk = p.T1; }
+                const int nqt = (nq + 31) >> 5, nkt = (nkk + 31) >> 5;
+                const long long base = (((long long)n * nqt + (qi >> 5)) * nkt + (kj >> 5)) * 1024;
+                const int k5 = kj & 31;
+                Y[base + (k5 >> 3) * 256 + ((qi & 31) + 32 * ((k5 >> 2) & 1)) * 4 + (k5 & 3)] = v;
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool WKM>
-int launch(const pd_gemm_args& p, hipStream_t s) {
-    constexpr int PADM = 4;
-    constexpr int A_TILE = AKM ? BK * (BM + PADM) : BM * LDK;
-    constexpr int W_TILE = WKM ? BK * (BN + PADM) : BN * LDK;
-    const size_t lds = 2 * (A_TILE + W_TILE) * sizeof(float);
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.batch > 0 ? p.batch : 1);
-    auto k = gemm_kernel<BM, BN, WM, WN, AKM, WKM>;
-    hipLaunchKernelGGL(k, grid, dim3(NT), lds, s, p);
+// op 0: launch, op 1: raise the dynamic-LDS limit of the instantiation (pd_init)
+template <int BM, int BN, int WM, int WN, bool AKM, bool WKM, bool VEC, int PRO>
+int run(int op, const pd_gemm_args* p, hipStream_t s) {
+    constexpr int lds = Cfg<BM, BN, AKM, WKM>::LDS_BYTES;
+    auto k = gemm_kernel<BM, BN, WM, WN, AKM, WKM, VEC, PRO>;
+    if (op == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    dim3 grid((p->M + BM - 1) / BM, (p->N + BN - 1) / BN, p->batch);
+    hipLaunchKernelGGL(k, grid, dim3(NT), lds, s, *p);
     return pd_check_launch();
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool WKM>
-int set_lds_limit() {
-    constexpr int PADM = 4;
-    constexpr int A_TILE = AKM ? BK * (BM + PADM) : BM * LDK;
-    constexpr int W_TILE = WKM ? BK * (BN + PADM) : BN * LDK;
-    const int lds = 2 * (A_TILE + W_TILE) * (int)sizeof(float);
-    auto k = gemm_kernel<BM, BN, WM, WN, AKM, WKM>;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
-               ? PD_OK : PD_ERR_LAUNCH;
+// tile / layout / prologue dispatch shared by pd_gemm (op 0) and pd_init (op 1, every variant)
+int dispatch(int op, int cfg, bool akm, bool wkm, bool vec, int pro, const pd_gemm_args* p, hipStream_t s) {
+#define PD_CASE(C, BM, BN, WM, WN, A, W, V, P) \
+    if (cfg == C && akm == A && wkm == W && vec == V && pro == P) return run<BM, BN, WM, WN, A, W, V, P>(op, p, s);
+    PD_CASE(0, 128, 128, 2, 2, false, false, true, 0)
+    PD_CASE(0, 128, 128, 2, 2, false, false, true, 1)
+    PD_CASE(0, 128, 128, 2, 2, false, false, true, 2)
+    PD_CASE(0, 128, 128, 2, 2, true, false, true, 0)
+    PD_CASE(0, 128, 128, 2, 2, true, false, true, 1)
+    PD_CASE(0, 128, 128, 2, 2, true, true, true, 0)
+    PD_CASE(1, 128, 64, 2, 2, false, false, true, 0)
+    PD_CASE(1, 128, 64, 2, 2, false, false, true, 1)
+    PD_CASE(2, 128, 32, 4, 1, false, false, true, 0)
+    PD_CASE(2, 128, 32, 4, 1, false, false, true, 1)
+    PD_CASE(3, 64, 64, 2, 2, false, false, true, 0)
+    PD_CASE(3, 64, 64, 2, 2, false, false, true, 1)
+    PD_CASE(3, 64, 64, 2, 2, false, false, true, 2)
+    PD_CASE(3, 64, 64, 2, 2, false, false, false, 0)
+#undef PD_CASE
+    return PD_ERR_UNSUPPORTED;
 }
+
+inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 }  // namespace
 
 PD_EXPORT int pd_init(void) {
     int rc = PD_OK;
-    rc |= set_lds_limit<128, 128, 2, 2, false, false>();
-    rc |= set_lds_limit<128, 128, 2, 2, true, false>();
-    rc |= set_lds_limit<128, 128, 2, 2, true, true>();
-    rc |= set_lds_limit<128, 64, 2, 2, false, false>();
-    rc |= set_lds_limit<128, 32, 4, 1, false, false>();
-    rc |= set_lds_limit<64, 64, 2, 2, false, false>();
-    return rc ? PD_ERR_LAUNCH : PD_OK;
+    for (int cfg = 0; cfg < 4; ++cfg)
+        for (int lay = 0; lay < 3; ++lay)
+            for (int vec = 0; vec < 2; ++vec)
+                for (int pro = 0; pro < 3; ++pro) {
+                    const int r = dispatch(1, cfg, lay >= 1, lay == 2, vec != 0, pro, nullptr, nullptr);
+                    if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
+                }
+    return rc;
 }
 
 PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
@@ -389,21 +456,31 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     if (p.batch <= 0) p.batch = 1;
     if (p.out_scale == 0.f) p.out_scale = 1.f;
     if (p.glu && (p.N % 64 != 0)) return PD_ERR_ARG;
-    if (p.hn_w && (p.hn_split % 32 != 0 || p.hn_cols % 32 != 0)) return PD_ERR_ARG;
+    if (p.hn_w && (p.hn_split % 32 != 0 || p.hn_cols % 32 != 0 || p.glu)) return PD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const bool akm = p.a_kmajor != 0, wkm = p.w_kmajor != 0;
-    // vector-load eligibility (16-byte alignment of every row start)
-    p.vecA = (((uintptr_t)p.A & 15) == 0) && (p.lda % 4 == 0) && (p.sA % 4 == 0) && ((akm ? 0 : p.K % 4) == 0);
-    p.vecW = (((uintptr_t)p.W & 15) == 0) && (p.ldw % 4 == 0) && (p.sW % 4 == 0) && ((wkm ? 0 : p.K % 4) == 0);
-    if (akm != wkm) {
-        if (akm && !wkm) return launch<128, 128, 2, 2, true, false>(p, s);
-        return PD_ERR_UNSUPPORTED;
+    // 16-byte vector loads need aligned row starts; tails are masked per element, so a row may
+    // end anywhere inside its (ld-padded) last chunk.
+    p.vecA = aligned16(p.A) && (p.lda % 4 == 0) && (p.sA % 4 == 0);
+    p.vecW = aligned16(p.W) && (p.ldw % 4 == 0) && (p.sW % 4 == 0);
+    p.vecY = aligned16(p.Y) && (p.ldy % 4 == 0) && (p.sY % 4 == 0) &&
+             (!p.res || (aligned16(p.res) && p.ldres % 4 == 0 && p.sRes % 4 == 0)) &&
+             (!p.mul || (aligned16(p.mul) && (p.mul_rows_per_group > 0 ? p.mul_gstride % 4 == 0 : p.ldmul % 4 == 0)));
+    const bool vec = p.vecA && p.vecW;
+    int pro = 0;
+    if (p.stats) {
+        if (!p.pro_w || !p.pro_b) return PD_ERR_ARG;      // pass ones / zeros explicitly
+        pro = p.pro_rows_per_group > 0 ? 2 : 1;
+        if (!akm && (!aligned16(p.pro_w) || !aligned16(p.pro_b) || p.pro_gstride % 4 != 0)) return PD_ERR_UNSUPPORTED;
     }
-    if (akm) return launch<128, 128, 2, 2, true, true>(p, s);
+    int cfg;
     const long long blocks128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
-    if (p.glu) return launch<128, 128, 2, 2, false, false>(p, s);
-    if (p.N <= 32) return launch<128, 32, 4, 1, false, false>(p, s);
-    if (blocks128 < 192) return launch<64, 64, 2, 2, false, false>(p, s);
-    if (p.N <= 64) return launch<128, 64, 2, 2, false, false>(p, s);
-    return launch<128, 128, 2, 2, false, false>(p, s);
+    if (akm || wkm || p.glu) cfg = 0;
+    else if (!vec) cfg = 3;
+    else if (p.N <= 32) cfg = 2;
+    else if (blocks128 < 192) cfg = 3;
+    else if (p.N <= 64) cfg = 1;
+    else cfg = 0;
+    if (pro == 2 && cfg != 0 && cfg != 3) cfg = 0;
+    return dispatch(0, cfg, akm, wkm, vec, pro, &p, s);
 }

@@ -16,6 +16,18 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, OUT_BIASFRAG, OUT_
 
 RMS, LN = 0, 1
 
+_CONST = {}
+
+
+def const_vec(val, n):
+    """Cached device vector of a constant (ones / zeros for an absent norm gain / shift)."""
+    key = (float(val), torch.cuda.current_device())
+    v = _CONST.get(key)
+    if v is None or v.numel() < n:
+        v = torch.full((max(n, 4096),), float(val), device="cuda", dtype=torch.float32)
+        _CONST[key] = v
+    return v
+
 
 def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0, sY=0,
          a_kmajor=False, w_kmajor=False, stats=None, pro_w=None, pro_b=None, pro_rows_per_group=0,
@@ -28,6 +40,11 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
     def P(x):
         return x if (x is None or isinstance(x, int)) else ptr(x)
     n_out = N // 2 if glu else N
+    if stats is not None:
+        if pro_w is None:
+            pro_w = const_vec(1.0, K)
+        if pro_b is None:
+            pro_b = const_vec(0.0, K)
     a = GemmArgs()
     a.A, a.W, a.Y = P(A), P(W), P(Y)
     a.M, a.N, a.K = M, N, K
