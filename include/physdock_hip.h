@@ -95,6 +95,64 @@ typedef struct pd_attn_args {
 } pd_attn_args;
 int pd_attention(const pd_attn_args* args, void* stream);
 
+/* ---- pair-representation / pooling kernels (pair.hip) ----------------------------------
+ * pd_atom_pair_init : ap = cl_l + cm_m + v*(Wp.d + Wd/(1+|d|) + Wv)   (diffusion_conditioning.py:116-124)
+ * pd_pair_gather_add: ap[l,m] += zt[a2t[l], a2t[m]]                    (diffusion_conditioning.py:237)
+ * pd_pair_init_z    : z = s_i + s_j + RelPos + bonds                   (diffusion_conditioning.py:65-94,187-189)
+ * pd_segment_pool   : token mean of contiguous atom rows (/(n+1e-3))   (transformers.py:205-212)
+ * pd_unpool_add     : ba[b,l] += us[b, a2t[l]]                         (transformers.py:214-216)
+ * pd_gather_rows_add: y[r] += x[idx[r]]                                (diffusion_conditioning.py:236)
+ * pd_axpby          : out = a*sa + b*(sb_ptr ? sb_ptr[0]*sb : sb)
+ * pd_template_mask  : z_mask * templ_feat[...,D-1] * same_chain        (diffusion_conditioning.py:41-42)
+ * Index tensors keep the loader's dtypes: int64 (uid, a2t, residue_index) / int32 (asym, sym, entity). */
+int pd_atom_pair_init(const float* pos, const long long* uid, const float* cl, const float* cm, const float* Wp,
+                      const float* Wd, const float* Wv, float* ap, int A, int c_ap, void* stream);
+int pd_pair_gather_add(float* ap, const float* zt, const long long* a2t, int A, int T, int c_ap, void* stream);
+int pd_pair_init_z(const float* si, const float* sj, const float* WT, const float* wb, const int* asym, const int* sym,
+                   const int* ent, const long long* res, const float* rel_tok_feat, const float* bonds, float* z, int T,
+                   int CZ, void* stream);
+int pd_segment_pool(const float* u, const int* tok_start, const float* add, float* out, int B, int A, int T, int C,
+                    void* stream);
+int pd_unpool_add(float* ba, const float* us, const long long* a2t, int B, int A, int T, int C, void* stream);
+int pd_gather_rows_add(float* y, const float* x, const long long* idx, int R, int C, void* stream);
+int pd_axpby(float* out, const float* a, float sa, const float* b, const float* sb_ptr, float sb, long long n, void* stream);
+int pd_template_mask(const float* z_mask, const float* templ_feat, const int* asym, float* out, int T, int D, void* stream);
+
+/* ---- per-step sampler kernels (sampler.hip) ------------------------------------------------
+ * pd_augment       : centre_random_augmentation + noise injection      (tensor_utils.py:576-586, model.py:70-85)
+ *                    parity mode: rot_u[4][B], trans[B][3], noise[B][A][3]; perf mode: Philox(seed, sample0+b, step)
+ * pd_init_noise    : x0 = sigma_0 * N(0,1) from Philox                  (model.py:148)
+ * pd_precond       : ba = Wx.(x_hat*c_in) + bx + a                      (transformers.py:218-223)
+ * pd_denoise       : x_den = c_skip*x_hat + c_out*Wr.LN(ba)             (transformers.py:228-233)
+ * pd_kabsch_align  : weighted_rigid_align (moves x_gt onto x_pred)      (tensor_utils.py:724-778)
+ * pd_template_match: eps metric, argmin, write template into ref_pos   (model.py:231-241; redocking.py:326-335)
+ * pd_pose_dist     : pairwise distances of conformers                   (model.py:186)
+ * pd_euler         : d_cur mix + Euler step                             (model.py:245-281)
+ * pd_timestep_embed: sinusoidal embedding                               (timestep_embeddings.py:64-81)   */
+int pd_augment(const float* x, float x_scale, const float* mask, const float* rot_u, const float* trans,
+               const float* noise, float lambda, float sdev, const unsigned long long* seed, int step, int sample0,
+               float* out, int B, int A, void* stream);
+int pd_init_noise(float* x, const unsigned long long* seed, int sample0, float sigma0, int B, int A, void* stream);
+int pd_precond(const float* x_hat, float c_in, const float* c_in_b, const float* Wx, const float* bx, const float* a,
+               float* ba, int B, int A, int C, void* stream);
+int pd_denoise(const float* ba, const float* x_hat, const float* nw, const float* nb, const float* Wr, float eps,
+               float c_skip, float c_out, const float* cs_b, const float* co_b, float* x_den, int B, int A, int C,
+               void* stream);
+int pd_kabsch_align(const float* x_pred, const float* pred_mask, const float* x_gt, long long gt_bstride, const float* w,
+                    float* out, int B, int A, void* stream);
+int pd_template_match(const float* x, const int* lig_idx, const float* ref_dist, const float* poses, float* batch_ref_pos,
+                      float* eps_out, int* sel_out, int B, int A, int L, int Cn, void* stream);
+int pd_pose_dist(const float* poses, float* D, int Cn, int L, void* stream);
+int pd_euler(const float* x_hat, const float* x_den, const float* x_proj, const float* w, float t_hat, float eta, float dt,
+             float* x_next, int B, int A, void* stream);
+int pd_timestep_embed(const float* tau, float* emb, int n, void* stream);
+
+/* ---- hipGraph helpers (api.hip): capture the host-deterministic step loop once, replay it */
+int pd_graph_begin(void* stream);
+int pd_graph_end(void* stream, void** exec_out);
+int pd_graph_launch(void* exec, void* stream);
+int pd_graph_destroy(void* exec);
+
 /* ---- library management ------------------------------------------------------------- */
 int pd_abi_version(void);
 int pd_init(void);            /* sets per-kernel LDS limits; call once before graph capture */

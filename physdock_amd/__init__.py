@@ -1,0 +1,13 @@
+"""physdock_amd - MI355X-native sampler for PhysDock's redocking hot path.
+
+    from physdock_amd import PhysDock, PhysDockConfig
+    model = PhysDock(PhysDockConfig(model_name="medium")).to("cuda")
+    model.load_state_dict(reference_state_dict)          # reference parameter names
+    x = model.sample_diffusion(batch, num_sample=64, steps=40, karras_noise_schedule_power=1000)
+
+Importing the package does not load the HIP library; the first kernel launch does, and
+raises if `physdock_amd/libphysdock_hip.so` has not been built (python -m physdock_amd.build).
+"""
+from .configs import PhysDockConfig, small_config  # noqa: F401
+from .model import PhysDock, weighted_rigid_align  # noqa: F401
+from .params import param_shapes, seeded_state_dict  # noqa: F401

@@ -97,21 +97,24 @@ def _declare(L):
     sig("pd_graph_end", p, C.POINTER(C.c_void_p))
     sig("pd_graph_launch", p, p)
     sig("pd_graph_destroy", p)
-    for name, args in _EXTRA_SIGS.items():
-        sig(name, *args)
-
-
-_EXTRA_SIGS = {}
-
-
-def register_sig(name, *argtypes):
-    """Used by the op modules to declare further launchers before the library is loaded."""
-    _EXTRA_SIGS[name] = argtypes
-    if _lib is not None:
-        fn = getattr(_lib, name)
-        fn.argtypes = list(argtypes)
-        fn.restype = C.c_int
-        SYMBOLS[name] = fn
+    ull = C.c_ulonglong
+    sig("pd_atom_pair_init", p, p, p, p, p, p, p, p, i, i, p)
+    sig("pd_pair_gather_add", p, p, p, i, i, i, p)
+    sig("pd_pair_init_z", p, p, p, p, p, p, p, p, p, p, p, i, i, p)
+    sig("pd_segment_pool", p, p, p, p, i, i, i, i, p)
+    sig("pd_unpool_add", p, p, p, i, i, i, i, p)
+    sig("pd_gather_rows_add", p, p, p, i, i, p)
+    sig("pd_axpby", p, p, f, p, p, f, ll, p)
+    sig("pd_template_mask", p, p, p, p, i, i, p)
+    sig("pd_augment", p, f, p, p, p, p, f, f, p, i, i, p, i, i, p)
+    sig("pd_init_noise", p, p, i, f, i, i, p)
+    sig("pd_precond", p, f, p, p, p, p, p, i, i, i, p)
+    sig("pd_denoise", p, p, p, p, p, f, f, f, p, p, p, i, i, i, p)
+    sig("pd_kabsch_align", p, p, p, ll, p, p, i, i, p)
+    sig("pd_template_match", p, p, p, p, p, p, p, i, i, i, i, p)
+    sig("pd_pose_dist", p, p, i, i, p)
+    sig("pd_euler", p, p, p, p, f, f, f, p, i, i, p)
+    sig("pd_timestep_embed", p, p, i, p)
 
 
 def ptr(t):

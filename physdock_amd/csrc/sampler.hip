@@ -1,0 +1,437 @@
+// Per-step sampler kernels: everything in the reverse-diffusion loop that is not a GEMM or
+// an attention (reference models/model.py:211-281, layers/transformers.py:218-233,
+// utils/tensor_utils.py:545-586,724-778).  Host-known schedule scalars (t_hat, c_in, ...)
+// are passed by value, so the whole loop is capturable into one hipGraph.
+#include "common.h"
+#include "physdock_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct Philox {
+    uint32_t k0, k1;
+    __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t ka, uint32_t kb) const {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ ka, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ kb, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    __device__ __forceinline__ void gen(uint32_t (&c)[4]) const {
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { round(c, a, b); a += 0x9E3779B9u; b += 0xBB67AE85u; }
+    }
+};
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ void normals4(const Philox& ph, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float (&n)[4]) {
+    uint32_t c[4] = {c0, c1, c2, c3};
+    ph.gen(c);
+    const float r0 = sqrtf(-2.f * logf(u01(c[0]))), r1 = sqrtf(-2.f * logf(u01(c[2])));
+    float s0, c0f, s1, c1f;
+    sincosf(6.283185307179586f * u01(c[1]), &s0, &c0f);
+    sincosf(6.283185307179586f * u01(c[3]), &s1, &c1f);
+    n[0] = r0 * c0f; n[1] = r0 * s0; n[2] = r1 * c1f; n[3] = r1 * s1;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threads
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------ augmentation + noise
+// x_hat = R (x - mu) + t + (lambda*noise)*sdev         (tensor_utils.py:576-586, model.py:70-85)
+// parity mode: rot_u[4][B], trans[B][3], noise[B][A][3] given; perf mode: Philox keyed by
+// (seed, global sample id, step).  x may be scaled on read (x0 = sigma_0 * init noise).
+__global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ x, float x_scale, const float* __restrict__ mask,
+                                                     const float* __restrict__ rot_u, const float* __restrict__ trans,
+                                                     const float* __restrict__ noise, float lambda, float sdev,
+                                                     const unsigned long long* __restrict__ seed, int step, int sample0,
+                                                     float* __restrict__ out, int B, int A) {
+    __shared__ float red[4];
+    __shared__ float sR[12];
+    const int b = blockIdx.x;
+    const float* xb = x + (long long)b * A * 3;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sm = 0.f;
+    for (int a = threadIdx.x; a < A; a += 256) {
+        const float m = mask[a];
+        sx += xb[3 * a] * x_scale * m; sy += xb[3 * a + 1] * x_scale * m; sz += xb[3 * a + 2] * x_scale * m; sm += m;
+    }
+    sx = block_sum(sx, red); sy = block_sum(sy, red); sz = block_sum(sz, red); sm = block_sum(sm, red);
+    Philox ph{0u, 0u};
+    if (seed) { const unsigned long long s = seed[0]; ph.k0 = (uint32_t)s; ph.k1 = (uint32_t)(s >> 32); }
+    if (threadIdx.x == 0) {
+        float u[4], t[3];
+        if (rot_u) {
+            for (int k = 0; k < 4; ++k) u[k] = rot_u[k * B + b];
+            for (int k = 0; k < 3; ++k) t[k] = trans[b * 3 + k];
+        } else {
+            uint32_t c[4] = {0u, (uint32_t)(sample0 + b), (uint32_t)step, 1u};
+            ph.gen(c);
+            for (int k = 0; k < 4; ++k) u[k] = u01(c[k]);
+            float n[4];
+            normals4(ph, 1u, (uint32_t)(sample0 + b), (uint32_t)step, 1u, n);
+            t[0] = n[0]; t[1] = n[1]; t[2] = n[2];
+        }
+        const float pi = 3.14159274f;
+        float e0[3], e1[3];
+        {
+            const float phi = u[0] * 2.f * pi, th = acosf(u[1] * 2.f - 1.f);
+            e0[0] = cosf(phi) * sinf(th); e0[1] = sinf(phi) * sinf(th); e0[2] = cosf(th);
+        }
+        {
+            const float phi = u[2] * 2.f * pi, th = acosf(u[3] * 2.f - 1.f);
+            e1[0] = cosf(phi) * sinf(th); e1[1] = sinf(phi) * sinf(th); e1[2] = cosf(th);
+        }
+        const float d = e1[0] * e0[0] + e1[1] * e0[1] + e1[2] * e0[2];
+        for (int k = 0; k < 3; ++k) e1[k] = e1[k] - e0[k] * d;
+        const float nrm = sqrtf(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+        for (int k = 0; k < 3; ++k) e1[k] /= nrm;
+        const float e2[3] = {e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2], e0[0] * e1[1] - e0[1] * e1[0]};
+        for (int k = 0; k < 3; ++k) { sR[k] = e0[k]; sR[3 + k] = e1[k]; sR[6 + k] = e2[k]; sR[9 + k] = t[k]; }
+    }
+    __syncthreads();
+    const float mx = sx / sm, my = sy / sm, mz = sz / sm;
+    float* ob = out + (long long)b * A * 3;
+    for (int a = threadIdx.x; a < A; a += 256) {
+        const float px = xb[3 * a] * x_scale - mx, py = xb[3 * a + 1] * x_scale - my, pz = xb[3 * a + 2] * x_scale - mz;
+        float o[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o[i] = (sR[3 * i] * px + sR[3 * i + 1] * py + sR[3 * i + 2] * pz) + sR[9 + i];
+        if (sdev != 0.f) {
+            float n[4];
+            if (noise) { const float* nb = noise + ((long long)b * A + a) * 3; n[0] = nb[0]; n[1] = nb[1]; n[2] = nb[2]; }
+            else normals4(ph, (uint32_t)a, (uint32_t)(sample0 + b), (uint32_t)step, 2u, n);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) o[i] += (lambda * n[i]) * sdev;
+        }
+        ob[3 * a] = o[0]; ob[3 * a + 1] = o[1]; ob[3 * a + 2] = o[2];
+    }
+}
+
+// x0[b,a,:] = normal * sigma0 from Philox (perf mode initial noise, model.py:148)
+__global__ __launch_bounds__(256) void init_noise_kernel(float* __restrict__ x, const unsigned long long* __restrict__ seed,
+                                                        int sample0, float sigma0, int B, int A) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * A) return;
+    const int b = idx / A, a = idx % A;
+    const unsigned long long s = seed[0];
+    Philox ph{(uint32_t)s, (uint32_t)(s >> 32)};
+    float n[4];
+    normals4(ph, (uint32_t)a, (uint32_t)(sample0 + b), 0xFFFFFFFFu, 0u, n);
+    x[idx * 3] = n[0] * sigma0; x[idx * 3 + 1] = n[1] * sigma0; x[idx * 3 + 2] = n[2] * sigma0;
+}
+
+// ------------------------------------------------------------------ precond / denoise
+// ba[b,l,:] = Wx.(x_hat*c_in) + bx + a[l,:]                     (transformers.py:218-223)
+__global__ __launch_bounds__(256) void precond_kernel(const float* __restrict__ x_hat, float c_in, const float* __restrict__ c_in_b,
+                                                     const float* __restrict__ Wx, const float* __restrict__ bx,
+                                                     const float* __restrict__ a, float* __restrict__ ba, int A, int C,
+                                                     long long n4) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    const int c4 = idx % (C / 4);
+    const long long row = idx / (C / 4);
+    const int l = row % A;
+    const float ci = c_in_b ? c_in_b[row / A] : c_in;
+    const float x0 = x_hat[row * 3] * ci, x1 = x_hat[row * 3 + 1] * ci, x2 = x_hat[row * 3 + 2] * ci;
+    const f32x4 av = *reinterpret_cast<const f32x4*>(a + (long long)l * C + c4 * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c4 * 4 + e;
+        o[e] = ((Wx[c * 3] * x0 + Wx[c * 3 + 1] * x1 + Wx[c * 3 + 2] * x2) + bx[c]) + av[e];
+    }
+    *reinterpret_cast<f32x4*>(ba + row * C + c4 * 4) = o;
+}
+
+// x_den = c_skip*x_hat + c_out * Wr.LN(ba)                         (transformers.py:228-233)
+// 32 lanes per atom row (C <= 512)
+__global__ __launch_bounds__(256) void denoise_kernel(const float* __restrict__ ba, const float* __restrict__ x_hat,
+                                                     const float* __restrict__ nw, const float* __restrict__ nb,
+                                                     const float* __restrict__ Wr, float eps, float c_skip, float c_out,
+                                                     const float* __restrict__ cs_b, const float* __restrict__ co_b,
+                                                     float* __restrict__ x_den, int A, int C, long long rows) {
+    const int sub = threadIdx.x & 31;
+    const long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool ok = row < rows;
+    f32x4 v[4];
+    float s1 = 0.f;
+    const int nchunk = C / 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub + 32 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok && c < nchunk) v[i] = *reinterpret_cast<const f32x4*>(ba + row * C + c * 4);
+        s1 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s1 += __shfl_xor(s1, o);
+    const float mean = s1 / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (sub + 32 * i < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub + 32 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = c * 4 + e;
+                const float y = (v[i][e] - mean) * rstd * nw[k] + nb[k];
+                r0 += y * Wr[k]; r1 += y * Wr[C + k]; r2 += y * Wr[2 * C + k];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); r2 += __shfl_xor(r2, o); }
+    if (ok && sub == 0) {
+        const float cs = cs_b ? cs_b[row / A] : c_skip, co = co_b ? co_b[row / A] : c_out;
+        x_den[row * 3] = cs * x_hat[row * 3] + co * r0;
+        x_den[row * 3 + 1] = cs * x_hat[row * 3 + 1] + co * r1;
+        x_den[row * 3 + 2] = cs * x_hat[row * 3 + 2] + co * r2;
+    }
+}
+
+// ------------------------------------------------------------------ weighted Kabsch (Horn quaternion, fp64 core)
+// out = R (G - mu_G) + mu_P with R the optimal proper rotation of G onto P      (tensor_utils.py:724-778)
+__device__ void horn_rotation(const double S[3][3], double R[3][3]) {
+    double N[4][4] = {
+        {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+        {0, S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+        {0, 0, -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+        {0, 0, 0, -S[0][0] - S[1][1] + S[2][2]}};
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < i; ++j) N[i][j] = N[j][i];
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 24; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += N[i][j] * N[i][j];
+        if (off < 1e-30) break;
+        for (int p = 0; p < 3; ++p) for (int q = p + 1; q < 4; ++q) {
+            if (fabs(N[p][q]) < 1e-300) continue;
+            const double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 4; ++k) { const double a = N[k][p], b = N[k][q]; N[k][p] = c * a - s * b; N[k][q] = s * a + c * b; }
+            for (int k = 0; k < 4; ++k) { const double a = N[p][k], b = N[q][k]; N[p][k] = c * a - s * b; N[q][k] = s * a + c * b; }
+            for (int k = 0; k < 4; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+        }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; ++i) if (N[i][i] > N[best][best]) best = i;
+    double qw = V[0][best], qx = V[1][best], qy = V[2][best], qz = V[3][best];
+    const double nn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw /= nn; qx /= nn; qy /= nn; qz /= nn;
+    R[0][0] = 1 - 2 * (qy * qy + qz * qz); R[0][1] = 2 * (qx * qy - qz * qw); R[0][2] = 2 * (qx * qz + qy * qw);
+    R[1][0] = 2 * (qx * qy + qz * qw); R[1][1] = 1 - 2 * (qx * qx + qz * qz); R[1][2] = 2 * (qy * qz - qx * qw);
+    R[2][0] = 2 * (qx * qz - qy * qw); R[2][1] = 2 * (qy * qz + qx * qw); R[2][2] = 1 - 2 * (qx * qx + qy * qy);
+}
+
+// P = x_pred * pmask (pmask may be null), G = x_gt (per sample if g_bstride != 0), weights w[A]
+__global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ xp, const float* __restrict__ pmask,
+                                                    const float* __restrict__ xg, long long g_bstride,
+                                                    const float* __restrict__ w, float* __restrict__ out, int A) {
+    __shared__ float red[4];
+    __shared__ float sT[18];     // R(9) muG(3) muP(3)
+    const int b = blockIdx.x;
+    const float* P = xp + (long long)b * A * 3;
+    const float* G = xg + (long long)b * g_bstride;
+    float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int a = threadIdx.x; a < A; a += 256) {
+        const float wa = w[a], pm = pmask ? pmask[a] : 1.f;
+        acc[0] += wa;
+        for (int k = 0; k < 3; ++k) { acc[1 + k] += P[3 * a + k] * pm * wa; acc[4 + k] += G[3 * a + k] * wa; }
+    }
+    float tot[7];
+    for (int k = 0; k < 7; ++k) tot[k] = block_sum(acc[k], red);
+    const float muP[3] = {tot[1] / tot[0], tot[2] / tot[0], tot[3] / tot[0]};
+    const float muG[3] = {tot[4] / tot[0], tot[5] / tot[0], tot[6] / tot[0]};
+    float h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = threadIdx.x; a < A; a += 256) {
+        const float wa = w[a], pm = pmask ? pmask[a] : 1.f;
+        if (wa == 0.f) continue;
+        float g[3], pp[3];
+        for (int k = 0; k < 3; ++k) { g[k] = G[3 * a + k] - muG[k]; pp[k] = P[3 * a + k] * pm - muP[k]; }
+        for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) h[3 * j + k] += wa * g[j] * pp[k];
+    }
+    float H[9];
+    for (int k = 0; k < 9; ++k) H[k] = block_sum(h[k], red);
+    if (threadIdx.x == 0) {
+        double S[3][3], R[3][3];
+        for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) S[j][k] = H[3 * j + k];
+        horn_rotation(S, R);
+        for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) sT[3 * j + k] = (float)R[j][k];
+        for (int k = 0; k < 3; ++k) { sT[9 + k] = muG[k]; sT[12 + k] = muP[k]; }
+    }
+    __syncthreads();
+    float* ob = out + (long long)b * A * 3;
+    for (int a = threadIdx.x; a < A; a += 256) {
+        const float g0 = G[3 * a] - sT[9], g1 = G[3 * a + 1] - sT[10], g2 = G[3 * a + 2] - sT[11];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ob[3 * a + i] = (sT[3 * i] * g0 + sT[3 * i + 1] * g1 + sT[3 * i + 2] * g2) + sT[12 + i];
+    }
+}
+
+// ------------------------------------------------------------------ template matching (model.py:231-241)
+// eps[b,c] = mean_ij 1/4 sum_k sigmoid(|D_b,ij - Dref_c,ij| - {.5,1,2,4}); c* = argmin; ref_pos[b, lig] = poses[c*]
+__global__ __launch_bounds__(256) void template_match_kernel(const float* __restrict__ x, const int* __restrict__ lig_idx,
+                                                            const float* __restrict__ ref_dist, const float* __restrict__ poses,
+                                                            float* __restrict__ batch_ref_pos, float* __restrict__ eps_out,
+                                                            int* __restrict__ sel_out, int A, int L, int Cn) {
+    extern __shared__ float sm[];     // L*3 coords
+    __shared__ float red[4];
+    __shared__ int best;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < L * 3; i += 256) sm[i] = x[((long long)b * A + lig_idx[i / 3]) * 3 + i % 3];
+    __syncthreads();
+    float best_e = INFINITY; int best_c = 0;
+    for (int c = 0; c < Cn; ++c) {
+        float acc = 0.f;
+        const float* rd = ref_dist + (long long)c * L * L;
+        for (int ij = threadIdx.x; ij < L * L; ij += 256) {
+            const int i = ij / L, j = ij % L;
+            const float dx = sm[3 * i] - sm[3 * j], dy = sm[3 * i + 1] - sm[3 * j + 1], dz = sm[3 * i + 2] - sm[3 * j + 2];
+            const float delta = fabsf(sqrtf(dx * dx + dy * dy + dz * dz) - rd[ij]);
+            acc += 0.25f * (1.f / (1.f + expf(0.5f - delta)) + 1.f / (1.f + expf(1.f - delta)) +
+                            1.f / (1.f + expf(2.f - delta)) + 1.f / (1.f + expf(4.f - delta)));
+        }
+        const float e = block_sum(acc, red) / (float)(L * L);
+        if (eps_out && threadIdx.x == 0) eps_out[(long long)b * Cn + c] = e;
+        if (e < best_e) { best_e = e; best_c = c; }
+    }
+    if (threadIdx.x == 0) { best = best_c; if (sel_out) sel_out[b] = best_c; }
+    __syncthreads();
+    if (batch_ref_pos) {
+        const float* ps = poses + (long long)best * L * 3;
+        for (int i = threadIdx.x; i < L * 3; i += 256)
+            batch_ref_pos[((long long)b * A + lig_idx[i / 3]) * 3 + i % 3] = ps[i];
+    }
+}
+
+// pairwise distance matrices of conformers: D[c,i,j] = |p_ci - p_cj|          (model.py:186)
+__global__ __launch_bounds__(256) void pose_dist_kernel(const float* __restrict__ poses, float* __restrict__ D, int L, long long n) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int j = idx % L, i = (idx / L) % L;
+    const long long c = idx / ((long long)L * L);
+    const float* p = poses + c * L * 3;
+    const float dx = p[3 * i] - p[3 * j], dy = p[3 * i + 1] - p[3 * j + 1], dz = p[3 * i + 2] - p[3 * j + 2];
+    D[idx] = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+// ------------------------------------------------------------------ Euler update (model.py:245-281)
+// d = (x_hat - x_den)/t_hat [mixed with the projected ligand by w];  x_next = x_hat + (eta*dt)*d
+__global__ __launch_bounds__(256) void euler_kernel(const float* __restrict__ x_hat, const float* __restrict__ x_den,
+                                                   const float* __restrict__ x_proj, const float* __restrict__ w,
+                                                   float t_hat, float eta, float dt, float* __restrict__ x_next, int A,
+                                                   long long n) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const float xh = x_hat[idx];
+    float d = (xh - x_den[idx]) / t_hat;
+    if (x_proj) {
+        const float wa = w[(idx / 3) % A];
+        const float dl = (xh - x_proj[idx]) / t_hat * wa;
+        d = d * (1.f - wa) + dl;
+    }
+    x_next[idx] = xh + (eta * dt) * d;
+}
+
+// emb[n,:] = [cos(tau f_k) | sin(tau f_k)], f_k = exp(-ln(1e4) k/128)      (timestep_embeddings.py:64-81)
+__global__ void timestep_embed_kernel(const float* __restrict__ tau, float* __restrict__ emb, int n) {
+    const int i = blockIdx.x, k = threadIdx.x;          // 128 threads
+    if (i >= n) return;
+    const float f = expf((-9.210340371976184f * (float)k) / 128.f);
+    const float arg = tau[i] * f;
+    emb[i * 256 + k] = cosf(arg);
+    emb[i * 256 + 128 + k] = sinf(arg);
+}
+
+}  // namespace
+
+PD_EXPORT int pd_augment(const float* x, float x_scale, const float* mask, const float* rot_u, const float* trans,
+                         const float* noise, float lambda, float sdev, const unsigned long long* seed, int step,
+                         int sample0, float* out, int B, int A, void* stream) {
+    if (!x || !mask || !out || B <= 0 || A <= 0) return PD_ERR_ARG;
+    if (!rot_u && !seed) return PD_ERR_ARG;
+    if (rot_u && !trans) return PD_ERR_ARG;
+    if (sdev != 0.f && !noise && !seed) return PD_ERR_ARG;
+    hipLaunchKernelGGL(augment_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, x_scale, mask, rot_u, trans, noise,
+                       lambda, sdev, seed, step, sample0, out, B, A);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_init_noise(float* x, const unsigned long long* seed, int sample0, float sigma0, int B, int A, void* stream) {
+    if (!x || !seed) return PD_ERR_ARG;
+    hipLaunchKernelGGL(init_noise_kernel, dim3((unsigned)(((long long)B * A + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       seed, sample0, sigma0, B, A);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_precond(const float* x_hat, float c_in, const float* c_in_b, const float* Wx, const float* bx,
+                         const float* a, float* ba, int B, int A, int C, void* stream) {
+    if (!x_hat || !Wx || !bx || !a || !ba || C % 4) return PD_ERR_ARG;
+    const long long n4 = (long long)B * A * (C / 4);
+    hipLaunchKernelGGL(precond_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_hat, c_in,
+                       c_in_b, Wx, bx, a, ba, A, C, n4);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_denoise(const float* ba, const float* x_hat, const float* nw, const float* nb, const float* Wr, float eps,
+                         float c_skip, float c_out, const float* cs_b, const float* co_b, float* x_den, int B, int A, int C,
+                         void* stream) {
+    if (!ba || !x_hat || !nw || !nb || !Wr || !x_den || C % 4 || C > 512) return PD_ERR_ARG;
+    const long long rows = (long long)B * A;
+    hipLaunchKernelGGL(denoise_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, ba, x_hat, nw, nb,
+                       Wr, eps, c_skip, c_out, cs_b, co_b, x_den, A, C, rows);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_kabsch_align(const float* x_pred, const float* pred_mask, const float* x_gt, long long gt_bstride,
+                              const float* w, float* out, int B, int A, void* stream) {
+    if (!x_pred || !x_gt || !w || !out) return PD_ERR_ARG;
+    hipLaunchKernelGGL(kabsch_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x_pred, pred_mask, x_gt, gt_bstride, w, out, A);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_template_match(const float* x, const int* lig_idx, const float* ref_dist, const float* poses,
+                                float* batch_ref_pos, float* eps_out, int* sel_out, int B, int A, int L, int Cn, void* stream) {
+    if (!x || !lig_idx || !ref_dist || L <= 0 || Cn <= 0) return PD_ERR_ARG;
+    if (batch_ref_pos && !poses) return PD_ERR_ARG;
+    hipLaunchKernelGGL(template_match_kernel, dim3(B), dim3(256), L * 3 * sizeof(float), (hipStream_t)stream, x, lig_idx,
+                       ref_dist, poses, batch_ref_pos, eps_out, sel_out, A, L, Cn);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_pose_dist(const float* poses, float* D, int Cn, int L, void* stream) {
+    if (!poses || !D) return PD_ERR_ARG;
+    const long long n = (long long)Cn * L * L;
+    hipLaunchKernelGGL(pose_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, poses, D, L, n);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_euler(const float* x_hat, const float* x_den, const float* x_proj, const float* w, float t_hat, float eta,
+                       float dt, float* x_next, int B, int A, void* stream) {
+    if (!x_hat || !x_den || !x_next || (x_proj && !w)) return PD_ERR_ARG;
+    const long long n = (long long)B * A * 3;
+    hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_hat, x_den, x_proj,
+                       w, t_hat, eta, dt, x_next, A, n);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_timestep_embed(const float* tau, float* emb, int n, void* stream) {
+    if (!tau || !emb || n <= 0) return PD_ERR_ARG;
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, tau, emb, n);
+    return pd_check_launch();
+}

@@ -1,0 +1,413 @@
+"""Kernel orchestration for the conditioning trunk and the AF3DiT denoiser.
+
+This module owns no arithmetic: every number is produced by a launcher of
+libphysdock_hip.so (ops.py).  It mirrors, call for call, the module tree of the reference
+(layers/diffusion_conditioning.py, layers/transformers.py, primitives/*.py) but with the
+algebraic levers of SURVEY §7 applied:
+
+* norms are folded into the GEMM that consumes them (row statistics + A-tile transform),
+* q/k/v(/g) projections are one GEMM, SwiGLU / sigmoid-gated pairs are one GEMM,
+* pair biases are written directly in the attention kernel's fragment layout; the DiT's 18
+  step- and sample-invariant bias projections are hoisted out of the loop (one GEMM over
+  ``ap`` and one over ``z`` per call),
+* AdaLN (shift, 1+scale, gate) tables for all steps are two GEMMs per call.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from ._lib import ACT_RELU, ACT_SIGMOID, ACT_SILU, LOG2E
+from .ops import LN, OUT_BIASFRAG, OUT_OPM, OUT_TRANSPOSED, RMS
+
+
+def off(t, n):
+    """device address of element n of tensor t (fp32 / int32 alike: 4-byte elements)"""
+    return t.data_ptr() + 4 * n
+
+
+class Workspace:
+    """Named, shape-keyed scratch buffers (torch tensors used as raw device memory)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, name, *shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class Engine:
+    def __init__(self, packed, config, device):
+        self.P = packed            # PackedWeights
+        self.cfg = config
+        self.device = device
+        self.ws = Workspace(device)
+        dc = config.model.diffusion_conditioning
+        self.inf, self.eps = float(dc.inf), float(dc.eps)
+
+    # ------------------------------------------------------------------ small helpers
+    def stats(self, x, M, C, mode, eps, name="stats", kmajor=False, ldx=None):
+        st = self.ws.get(name, M, 2)
+        ops.rowstats(x, st, M, C, mode=mode, eps=eps, kmajor=kmajor, ldx=ldx)
+        return st
+
+    def lin(self, x, wname, M, out=None, **kw):
+        """plain Linear by packed-weight name; returns the output tensor"""
+        W, b, N, K, ldw = self.P.linear(wname)
+        if out is None:
+            out = self.ws.get("lin:" + wname, M, N)
+        lda = kw.pop("lda", K)
+        ops.gemm(x, W, out, M, N, K, lda=lda, ldw=ldw, bias=b, **kw)
+        return out
+
+    # ------------------------------------------------------------------ shared blocks
+    def pair_bias(self, prefix, z, T1, T2, C, mask, norm_w, out, transpose=False, norm="norm_z", st=None):
+        """bias[h, q, k] = (W_z . RMSNorm(z))[h] + maskbias -> fragment layout (x log2 e)"""
+        P = self.P
+        W, _, H, K, ldw = P.linear(prefix + ".linear_z")
+        if st is None:
+            st = self.stats(z, T1 * T2, C, RMS, self.eps, "stats_pb")
+        ops.gemm(z, W, out, T1 * T2, H, C, ldw=ldw, stats=st, pro_w=norm_w, out_mode=OUT_BIASFRAG, T1=T1, T2=T2,
+                 frag_transpose=transpose, maskadd=mask, maskval=-self.inf, out_scale=LOG2E)
+        return H
+
+    def attention_pair_bias(self, prefix, s, nbatch, N, C, bias, norm_name="norm_s"):
+        """s += (W_o . Attn(RMSNorm(s)) + b_o) * (W_g RMSNorm(s) + b_g)   (attentions.py:32-53,76-97)"""
+        P = self.P
+        rows = nbatch * N
+        H = C // 32
+        st = self.stats(s, rows, C, RMS, self.eps)
+        W, b = P.qkvg(prefix)
+        qkvg = self.ws.get("qkvg", rows, 4 * C)
+        ops.gemm(s, W, qkvg, rows, 4 * C, C, stats=st, pro_w=P[f"{prefix}.{norm_name}.weight"], bias=b)
+        o = self.ws.get("attn_o", rows, C)
+        st4 = (N * 4 * C, 4 * C)
+        ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=N, nbatch=nbatch, nheads=H,
+                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias)
+        Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
+        ops.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s)
+
+    def transition(self, prefix, x, rows, C):
+        """x += W2(silu(W1 RMSNorm(x)) * W3 RMSNorm(x))                    (transitions.py:15-18)"""
+        P = self.P
+        st = self.stats(x, rows, C, RMS, self.eps)
+        W13, hidden = P.glu(prefix + ".feed_forward")
+        h = self.ws.get("ffn_h", rows, hidden)
+        ops.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_w=P[prefix + ".ffn_norm.weight"], glu=1)
+        W2, _, _, _, ldw = P.linear(prefix + ".feed_forward.w2")
+        ops.gemm(h, W2, x, rows, C, hidden, ldw=ldw, res=x)
+
+    def triangle_update(self, prefix, z, T, C, mask, transpose):
+        """z += TriangleUpdate(z)                                          (attentions.py:157-171)"""
+        P = self.P
+        M = T * T
+        st = self.stats(z, M, C, RMS, self.eps)
+        nw = P[prefix + ".norm_in.weight"]
+        Wqk, bqk = P.tri_qk(prefix)                       # packed [qx|q|kx|k] -> 64 outputs (q 32 | k 32)
+        qk = self.ws.get("tri_qk", 64, M)
+        ops.gemm(z, Wqk, qk, M, 128, C, stats=st, pro_w=nw, bias=bqk, glu=2, rowscale=mask,
+                 out_mode=OUT_TRANSPOSED, ldy=M)
+        Wg, bg, _, _, ldw = P.linear(prefix + ".linear_g")
+        g = self.ws.get("tri_g", M, C)
+        ops.gemm(z, Wg, g, M, C, C, ldw=ldw, stats=st, pro_w=nw, bias=bg, act=ACT_SIGMOID)
+        o = self.ws.get("tri_o", 32, M)
+        if not transpose:   # o[c,i,I] = sum_j q[c,i,j] k[c,I,j]
+            ops.gemm(off(qk, 0), off(qk, 32 * M), o, T, T, T, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M)
+        else:               # o[c,a,b] = sum_j k[c,j,a] q[c,j,b]
+            ops.gemm(off(qk, 32 * M), off(qk, 0), o, T, T, T, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M,
+                     a_kmajor=True, w_kmajor=True)
+        st2 = self.stats(o, M, 32, RMS, self.eps, "stats_tri", kmajor=True, ldx=M)
+        Wz, bz, _, _, ldw = P.linear(prefix + ".linear_z")
+        ops.gemm(o, Wz, z, M, C, 32, a_kmajor=True, lda=M, ldw=ldw, stats=st2, pro_w=P[prefix + ".norm_out.weight"],
+                 bias=bz, mul=g, ldmul=C, res=z)
+
+    def triangle_attention(self, prefix, z, T, C, mask, transpose):
+        """z += TriangleAttention(z)                                       (attentions.py:194-217)"""
+        P = self.P
+        M = T * T
+        H = C // 32
+        st = self.stats(z, M, C, RMS, self.eps)
+        nw = P[prefix + ".norm.weight"]
+        W, b = P.qkvg(prefix)
+        qkvg = self.ws.get("qkvg", M, 4 * C)
+        ops.gemm(z, W, qkvg, M, 4 * C, C, stats=st, pro_w=nw, bias=b)
+        bias = self.ws.get("tri_bias", ops.bias_frag_numel(H, T, T), zero=True)
+        self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, st=st)
+        o = self.ws.get("attn_o", M, C)
+        if not transpose:
+            st4, sto = (T * 4 * C, 4 * C), (T * C, C)
+        else:
+            st4, sto = (4 * C, T * 4 * C), (C, T * C)
+        ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=T, nbatch=T, nheads=H,
+                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias)
+        Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
+        ops.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z)
+
+    def triangle_block(self, prefix, z, T, C, mask):
+        """layers/transformers.py:48-54"""
+        self.triangle_update(prefix + ".triangle_row_update", z, T, C, mask, False)
+        self.triangle_update(prefix + ".triangle_col_update", z, T, C, mask, True)
+        self.triangle_attention(prefix + ".triangle_row_attention", z, T, C, mask, False)
+        self.triangle_attention(prefix + ".triangle_col_attention", z, T, C, mask, True)
+        self.transition(prefix + ".pair_transition", z, T * T, C)
+
+    # ------------------------------------------------------------------ conditioning trunk
+    def conditioning(self, batch):
+        """DiffusionConditioning.forward (diffusion_conditioning.py:232-238) -> a, ap, s, z (workspace tensors)"""
+        P, ws, eps = self.P, self.ws, self.eps
+        dc = self.cfg.model.diffusion_conditioning
+        Ca, Cap, Cs, Cm, Cz = dc.c_a, dc.c_ap, dc.c_s, dc.c_m, dc.c_z
+        A = batch["ref_pos"].shape[0]
+        T = batch["target_feat"].shape[0]
+        S = batch["msa_feat"].shape[0]
+        a2t = batch["atom_id_to_token_id"]
+        ap_mask = batch["ap_mask"]
+        z_mask = batch["z_mask"]
+        pre = "diffusion_conditioning"
+
+        # ---------------- AtomEmbedder (:110-128)
+        ae = pre + ".atom_embedder"
+        a = ws.get("a", A, Ca)
+        self.lin(batch["ref_feat"], ae + ".linear_c", A, out=a, lda=batch["ref_feat"].shape[1])
+        cl = self.lin(a, ae + ".linear_c_l", A, pro_act=ACT_RELU)
+        cm = self.lin(a, ae + ".linear_c_m", A, pro_act=ACT_RELU)
+        ap = ws.get("ap", A * A, Cap)
+        ops.check(ops._lib.init().pd_atom_pair_init(
+            ops.ptr(batch["ref_pos"]), ops.ptr(batch["ref_space_uid"]), ops.ptr(cl), ops.ptr(cm),
+            ops.ptr(P[ae + ".linear_p.weight"]), ops.ptr(P[ae + ".linear_d.weight"]), ops.ptr(P[ae + ".linear_v.weight"]),
+            ops.ptr(ap), A, Cap, ops.stream()), "pd_atom_pair_init")
+        # ap += FFN(ap) (no norm), chunked over rows so the hidden tile stays cache-sized
+        W13, hidden = P.glu(ae + ".ffn")
+        W2, _, _, _, ldw2 = P.linear(ae + ".ffn.w2")
+        chunk = min(A * A, 1 << 20)
+        h = ws.get("ap_ffn_h", chunk, hidden)
+        for r0 in range(0, A * A, chunk):
+            rows = min(chunk, A * A - r0)
+            ops.gemm(off(ap, r0 * Cap), W13, h, rows, 2 * hidden, Cap, glu=1)
+            ops.gemm(h, W2, off(ap, r0 * Cap), rows, Cap, hidden, ldw=ldw2, res=off(ap, r0 * Cap), ldres=Cap)
+        Ha = Ca // 32
+        abias = ws.get("atom_bias", ops.bias_frag_numel(Ha, A, A), zero=True)
+        for b in range(dc.no_blocks_atom):
+            blk = f"{ae}.atom_transformer.blocks.{b}"
+            self.pair_bias(blk + ".attention", ap, A, A, Cap, ap_mask, P[blk + ".attention.norm_z.weight"], abias)
+            self.attention_pair_bias(blk + ".attention", a, 1, A, Ca, abias)
+            self.transition(blk + ".transition", a, A, Ca)
+
+        # ---------------- TokenEmbedder (:178-202)
+        te = pre + ".token_embedder"
+        u = self.lin(a, te + ".linear_a", A, act=ACT_SILU)
+        tok_start = batch["_tok_start"]
+        s = ws.get("s", T, Cs)
+        L = ops._lib.init()
+        ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(tok_start), None, ops.ptr(s), 1, A, T, Cs, ops.stream()), "pool")
+        self.lin(batch["target_feat"], te + ".linear_target_feat", T, out=s, lda=batch["target_feat"].shape[1], res=s)
+        self.lin(batch["key_res_feat"], te + ".linear_key_res_feat", T, out=s, lda=batch["key_res_feat"].shape[1], res=s)
+        self.lin(batch["pocket_res_feat"], te + ".linear_pocket_res_feat", T, out=s, lda=1, res=s)
+        si = self.lin(s, te + ".linear_s_i", T)
+        sj = self.lin(s, te + ".linear_s_j", T)
+        z = ws.get("z", T * T, Cz)
+        ops.check(L.pd_pair_init_z(ops.ptr(si), ops.ptr(sj), ops.ptr(P.relpos_T()), ops.ptr(P[te + ".linear_bonds.weight"]),
+                                   ops.ptr(batch["asym_id"]), ops.ptr(batch["sym_id"]), ops.ptr(batch["entity_id"]),
+                                   ops.ptr(batch["residue_index"]), ops.ptr(batch["rel_tok_feat"]),
+                                   ops.ptr(batch["token_bonds_feature"]), ops.ptr(z), T, Cz, ops.stream()), "pair_init_z")
+        sm = self.lin(s, te + ".linear_s_input", T)
+        m = ws.get("m", S * T, Cm)
+        self.lin(batch["msa_feat"], te + ".linear_msa_feat", S * T, out=m, lda=batch["msa_feat"].shape[2], res=sm,
+                 res_row_mod=T)
+
+        Hm = Cm // 32
+        mbias = ws.get("msa_bias", ops.bias_frag_numel(Hm, T, T), zero=True)
+        for b in range(dc.no_blocks_evoformer):
+            blk = f"{te}.evoformer.blocks.{b}"
+            # MSA row attention with pair bias (attentions.py:76-97)
+            self.pair_bias(blk + ".msa_row_attention", z, T, T, Cz, z_mask, P[blk + ".msa_row_attention.norm_z.weight"], mbias)
+            self.attention_pair_bias(blk + ".msa_row_attention", m, S, T, Cm, mbias, norm_name="norm_m")
+            self.msa_column_attention(blk + ".msa_col_attention", m, S, T, Cm)
+            self.transition(blk + ".msa_transition", m, S * T, Cm)
+            self.outer_product_mean(blk + ".opm", m, z, S, T, Cm, Cz)
+            self.triangle_block(blk, z, T, Cz, z_mask)
+
+        # ---------------- TemplatePairEmbedder (:38-50)
+        tp = te + ".template_pair_embedder"
+        tmask = ws.get("templ_mask", T * T)
+        D = batch["templ_feat"].shape[-1]
+        ops.check(L.pd_template_mask(ops.ptr(z_mask), ops.ptr(batch["templ_feat"]), ops.ptr(batch["asym_id"]), ops.ptr(tmask),
+                                     T, D, ops.stream()), "template_mask")
+        uu = ws.get("templ_u", T * T, Cz)
+        st = self.stats(z, T * T, Cz, RMS, 1e-6)
+        self.lin(z, tp + ".linear_in", T * T, out=uu, stats=st, pro_w=P[tp + ".norm_in.weight"])
+        self.lin(batch["templ_feat"], tp + ".linear_templ_feat", T * T, out=uu, res=uu)
+        for b in range(2):
+            self.triangle_block(f"{tp}.triangleformer.blocks.{b}", uu, T, Cz, tmask)
+        st = self.stats(uu, T * T, Cz, RMS, eps)
+        tpo = self.lin(uu, tp + ".linear_out", T * T, stats=st, pro_w=P[tp + ".norm_out.weight"], pro_act=ACT_RELU)
+        ops.check(L.pd_axpby(ops.ptr(z), ops.ptr(z), 1.0, ops.ptr(tpo), ops.ptr(batch["t_mask"]), 1.0, T * T * Cz,
+                             ops.stream()), "axpby")
+
+        # ---------------- single representation + Pairformer
+        s2 = ws.get("s2", T, Cs)
+        self.lin(m, te + ".linear_m", T, out=s2)                  # m[0] = first T rows
+        self.lin(s, te + ".linear_s", T, out=s2, res=s2)
+        s = s2
+        Hs = Cs // 32
+        sbias = ws.get("single_bias", ops.bias_frag_numel(Hs, T, T), zero=True)
+        for b in range(dc.no_blocks_pairformer):
+            blk = f"{te}.pairformer.blocks.{b}"
+            self.triangle_block(blk, z, T, Cz, z_mask)
+            self.pair_bias(blk + ".attention", z, T, T, Cz, z_mask, P[blk + ".attention.norm_z.weight"], sbias)
+            self.attention_pair_bias(blk + ".attention", s, 1, T, Cs, sbias)
+            self.transition(blk + ".transition", s, T, Cs)
+
+        # ---------------- tail (:236-237)
+        st = self.stats(s, T, Cs, RMS, eps)
+        ta = self.lin(s, pre + ".linear_s", T, stats=st, pro_w=P[pre + ".norm_s.weight"])
+        ops.check(L.pd_gather_rows_add(ops.ptr(a), ops.ptr(ta), ops.ptr(a2t), A, Ca, ops.stream()), "gather_rows_add")
+        st = self.stats(z, T * T, Cz, RMS, eps)
+        zt = self.lin(z, pre + ".linear_z", T * T, stats=st, pro_w=P[pre + ".norm_z.weight"])
+        ops.check(L.pd_pair_gather_add(ops.ptr(ap), ops.ptr(zt), ops.ptr(a2t), A, T, Cap, ops.stream()), "pair_gather_add")
+        return a, ap, s, z
+
+    def msa_column_attention(self, prefix, m, S, T, C):
+        """m += MSAColumnAttention(m): attention along the MSA-row axis, no bias (attentions.py:117-136)"""
+        P = self.P
+        rows = S * T
+        H = C // 32
+        st = self.stats(m, rows, C, RMS, self.eps)
+        W, b = P.qkvg(prefix)
+        qkvg = self.ws.get("qkvg", rows, 4 * C)
+        ops.gemm(m, W, qkvg, rows, 4 * C, C, stats=st, pro_w=P[prefix + ".norm_m.weight"], bias=b)
+        o = self.ws.get("attn_o", rows, C)
+        st4 = (4 * C, T * 4 * C)
+        ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=S, nk=S, nbatch=T, nheads=H,
+                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(C, T * C), bias=None)
+        Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
+        ops.gemm(o, Wo, m, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=m)
+
+    def outer_product_mean(self, prefix, m, z, S, T, Cm, Cz):
+        """z += RMSNorm(W_o . sum_s q_s (x) k_s + b)                       (outer_product_mean.py:23-31)"""
+        P = self.P
+        rows = S * T
+        st = self.stats(m, rows, Cm, RMS, self.eps)
+        nw = P[prefix + ".norm_in.weight"]
+        q = self.lin(m, prefix + ".linear_q", rows, stats=st, pro_w=nw)
+        k = self.lin(m, prefix + ".linear_k", rows, stats=st, pro_w=nw)
+        outer = self.ws.get("opm_outer", T * T, 1024)
+        ops.gemm(q, k, outer, T * 32, T * 32, S, a_kmajor=True, w_kmajor=True, lda=T * 32, ldw=T * 32,
+                 out_mode=OUT_OPM, T2=T)
+        raw = self.lin(outer, prefix + ".linear_o", T * T)
+        ops.rownorm(raw, z, T * T, Cz, res=z, w=P[prefix + ".norm_out.weight"], mode=RMS, eps=self.eps)
+
+    # ------------------------------------------------------------------ denoiser
+    def prepare_dit(self, a, ap, s, z, batch, tau):
+        """Per-call, step-invariant preparation: hoisted pair biases (attentions.py:246,254 executed once
+        instead of 18 x steps times) and the AdaLN tables of every step (adaptive_layer_norm_zero.py:19)."""
+        P, ws = self.P, self.ws
+        dt = self.cfg.model.dit
+        Ca, Cap, Cs, Cz = dt.c_a, dt.c_ap, dt.c_s, dt.c_z
+        A, T = a.shape[0], s.shape[0]
+        n = tau.shape[0]
+        L = ops._lib.init()
+        # --- hoisted biases
+        Wa, ba_, na = P.dit_bias("atom")                  # [2*nb_atom*H, Cap] with LN affine folded
+        st = self.stats(ap, A * A, Cap, LN, 1e-5, "stats_pb")
+        fa = ws.get("dit_atom_bias", ops.bias_frag_numel(na, A, A), zero=True)
+        ops.gemm(ap, Wa, fa, A * A, na, Cap, stats=st, bias=ba_, out_mode=OUT_BIASFRAG, T1=A, T2=A,
+                 maskadd=batch["ap_mask"], maskval=-self.inf, out_scale=LOG2E)
+        Wt, bt_, nt = P.dit_bias("token")
+        st = self.stats(z, T * T, Cz, LN, 1e-5, "stats_pb")
+        ft = ws.get("dit_token_bias", ops.bias_frag_numel(nt, T, T), zero=True)
+        ops.gemm(z, Wt, ft, T * T, nt, Cz, stats=st, bias=bt_, out_mode=OUT_BIASFRAG, T1=T, T2=T,
+                 maskadd=batch["z_mask"], maskval=-self.inf, out_scale=LOG2E)
+        # --- AdaLN tables: t = MLP(sincos(tau)); table = Linear(silu(t)) with 1 folded into the scale bias
+        emb = ws.get("t_emb", n, 256)
+        ops.check(L.pd_timestep_embed(ops.ptr(tau), ops.ptr(emb), n, ops.stream()), "timestep_embed")
+        t1 = self.lin(emb, "dit.time_embedder.timestep_embedder.linear_1", n, act=ACT_SILU)
+        t = self.lin(t1, "dit.time_embedder.timestep_embedder.linear_2", n)
+        Wta, bta = P.adaln("atom")
+        Wtt, btt = P.adaln("token")
+        tab_a = ws.get("adaln_atom", n, Wta.shape[0])
+        tab_t = ws.get("adaln_token", n, Wtt.shape[0])
+        ops.gemm(t, Wta, tab_a, n, Wta.shape[0], 256, bias=bta, pro_act=ACT_SILU)
+        ops.gemm(t, Wtt, tab_t, n, Wtt.shape[0], 256, bias=btt, pro_act=ACT_SILU)
+        return {"atom_bias": fa, "token_bias": ft, "tab_atom": tab_a, "tab_token": tab_t}
+
+    def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample):
+        """DiTBlock (transformers.py:155-159; attentions.py:241-265; transitions.py:27-30).
+        tab: AdaLN table row(s) [shift | 1+scale | gate] x (attention, transition) for this block."""
+        P, eps = self.P, self.eps
+        rows = B * N
+        H = C // 32
+        grp = dict(pro_rows_per_group=N, pro_gstride=tab_ld) if per_sample else {}
+        mgrp = dict(mul_rows_per_group=N if per_sample else rows, mul_gstride=tab_ld if per_sample else 0)
+        st = self.stats(x, rows, C, LN, eps)
+        qkv = self.ws.get("dit_qkv", rows, 3 * C)
+        ops.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
+                 pro_w=off(tab, tab_off + C), hn_w=P.headnorm(prefix + ".attention"), hn_cols=2 * C, hn_split=C,
+                 hn_eps=eps, **grp)
+        o = self.ws.get("dit_o", rows, C)
+        st3 = (N * 3 * C, 3 * C)
+        ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, nq=N, nk=N, nbatch=B, nheads=H,
+                      q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias)
+        Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
+        ops.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)
+        st = self.stats(x, rows, C, LN, eps)
+        W13, hidden = P.glu(prefix + ".transition.feed_forward")
+        h = self.ws.get("dit_h", rows, hidden)
+        o2 = tab_off + 3 * C
+        ops.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, o2), pro_w=off(tab, o2 + C), glu=1, **grp)
+        W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
+        ops.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, o2 + 2 * C), res=x, **mgrp)
+
+    def af3_dit(self, batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=False):
+        """AF3DiT.forward (transformers.py:235-262) for one noise level.
+        scal: dict(c_in, c_skip, c_out) floats, or per-sample device arrays when per_sample."""
+        P, ws = self.P, self.ws
+        dt = self.cfg.model.dit
+        Ca, Cs = dt.c_a, dt.c_s
+        A, T = a.shape[0], s.shape[0]
+        Ha, Hs = Ca // 32, Cs // 32
+        L = ops._lib.init()
+        sp = ops.stream()
+        ba = ws.get("dit_ba", B * A, Ca)
+        cin_b = ops.ptr(scal["c_in"]) if per_sample else None
+        ops.check(L.pd_precond(ops.ptr(x_hat), 0.0 if per_sample else scal["c_in"], cin_b, ops.ptr(P["dit.linear_x.weight"]),
+                               ops.ptr(P["dit.linear_x.bias"]), ops.ptr(a), ops.ptr(ba), B, A, Ca, sp), "precond")
+        tab_a, tab_t = prep["tab_atom"], prep["tab_token"]
+        lda_, ldt_ = tab_a.shape[1], tab_t.shape[1]
+        fa_stride = ops.bias_frag_numel(Ha, A, A)
+        ft_stride = ops.bias_frag_numel(Hs, T, T)
+        nb_a, nb_t = dt.no_blocks_atom, dt.no_blocks_dit
+        for b in range(nb_a):
+            self.dit_block(f"dit.atom_dit_encoder.blocks.{b}", ba, B, A, Ca, off(prep["atom_bias"], b * fa_stride),
+                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample)
+        u = ws.get("dit_u", B * A, Cs)
+        self.lin(ba, "dit.linear_downscale", B * A, out=u, act=ACT_SILU)
+        bs = ws.get("dit_bs", B * T, Cs)
+        ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs), B, A, T, Cs, sp), "pool")
+        for b in range(nb_t):
+            self.dit_block(f"dit.token_dit.blocks.{b}", bs, B, T, Cs, off(prep["token_bias"], b * ft_stride),
+                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample)
+        us = ws.get("dit_us", B * T, Ca)
+        self.lin(bs, "dit.linear_upscale", B * T, out=us)
+        ops.check(L.pd_unpool_add(ops.ptr(ba), ops.ptr(us), ops.ptr(batch["atom_id_to_token_id"]), B, A, T, Ca, sp), "unpool")
+        for b in range(nb_a):
+            self.dit_block(f"dit.atom_dit_decoder.blocks.{b}", ba, B, A, Ca,
+                           off(prep["atom_bias"], (nb_a + b) * fa_stride), tab_a, row * lda_ + (nb_a + b) * 6 * Ca, lda_,
+                           per_sample)
+        cs_b = ops.ptr(scal["c_skip"]) if per_sample else None
+        co_b = ops.ptr(scal["c_out"]) if per_sample else None
+        ops.check(L.pd_denoise(ops.ptr(ba), ops.ptr(x_hat), ops.ptr(P["dit.norm_r.weight"]), ops.ptr(P["dit.norm_r.bias"]),
+                               ops.ptr(P["dit.linear_r.weight"]), self.eps, 0.0 if per_sample else scal["c_skip"],
+                               0.0 if per_sample else scal["c_out"], cs_b, co_b, ops.ptr(x_den), B, A, Ca, sp), "denoise")
+        return x_den

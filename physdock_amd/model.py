@@ -1,0 +1,320 @@
+"""`PhysDock` - drop-in for the reference model class on the sampling hot path.
+
+Mirrors ``PhysDock.models.model.PhysDock`` (reference models/model.py:55-68): same
+constructor (a config from ``PhysDockConfig``), same parameter names (strict
+``load_state_dict`` of a reference checkpoint works, see params.py), same
+``sample_diffusion(...)`` / ``forward(batch)`` signatures and return values.  Everything
+between "feature tensors on the device" and "coordinates on the device" runs in the HIP
+kernels of libphysdock_hip.so; there is no PyTorch compute fallback - on a machine
+without the built library or without a GPU the calls raise.
+
+Extensions (keyword-only, not in the reference): ``noise=`` injects pre-drawn random
+numbers (parity mode; same draw order as the reference, see oracle), ``seed=`` /
+``sample_offset=`` select the on-device Philox streams (perf / multi-GPU mode),
+``use_graph=`` replays the step loop from a hipGraph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .engine import Engine, off
+from .packing import PackedWeights
+from .params import param_shapes
+
+
+def _register(root: nn.Module, name: str, tensor: torch.Tensor):
+    parts = name.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+def karras_noise_schedule(num_steps=200, sigma_data=16, s_max=160, s_min=4 * 10e-4, p=7):
+    """reference models/model.py:117-129; same fp32 torch op order (host side, p=1000 amplifies rounding)"""
+    idx = torch.arange(num_steps, dtype=torch.float32)
+    t = sigma_data * (s_max ** (1 / p) + idx / (num_steps - 1) * (s_min ** (1 / p) - s_max ** (1 / p))) ** p
+    return torch.cat([t, torch.zeros_like(t[:1])])
+
+
+class PhysDock(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.num_augmentation_sample = config.model.num_augmentation_sample
+        self.sigma_data = config.sigma_data
+        for name, shape in param_shapes(config).items():
+            # weights are expected to come from load_state_dict; start from zeros like an un-initialised buffer
+            _register(self, name, torch.zeros(shape))
+        self._packed: Optional[PackedWeights] = None
+        self._engine: Optional[Engine] = None
+        self._graphs = {}
+        self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
+
+    # ------------------------------------------------------------------ plumbing
+    def _invalidate(self):
+        self._packed = None
+        self._engine = None
+        for g in self._graphs.values():
+            ops._lib.lib().pd_graph_destroy(g["exec"])
+        self._graphs = {}
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return r
+
+    def engine(self, device) -> Engine:
+        if self._engine is None or self._engine.device != device:
+            if device.type != "cuda":
+                raise RuntimeError("physdock_amd.PhysDock runs its sampler on an MI355X (HIP) device only; "
+                                   "there is no CPU path (the CPU oracle lives in oracle/ and is test-only)")
+            params = {k: v for k, v in self.state_dict().items()}
+            if any(v.device != device for v in params.values()):
+                raise RuntimeError("model parameters and batch must be on the same device")
+            self._packed = PackedWeights(params, self.config)
+            self._engine = Engine(self._packed, self.config, device)
+        return self._engine
+
+    @staticmethod
+    def _prepare_batch(batch):
+        """index bookkeeping the kernels need (int32 token start offsets) - metadata only"""
+        if "_tok_start" not in batch:
+            chunk = batch["token_id_to_chunk_sizes"]
+            ts = torch.zeros(chunk.shape[0] + 1, dtype=torch.int32, device=chunk.device)
+            ts[1:] = torch.cumsum(chunk, 0).to(torch.int32)
+            batch = dict(batch)
+            batch["_tok_start"] = ts
+        A, T = batch["ref_pos"].shape[0], batch["target_feat"].shape[0]
+        if A % 4 or T % 4:
+            raise NotImplementedError("token / atom counts must be multiples of 4 (pad with masked entries)")
+        for k in ("ref_feat", "ref_pos", "a_mask", "ap_mask", "target_feat", "key_res_feat", "pocket_res_feat",
+                  "token_bonds_feature", "rel_tok_feat", "msa_feat", "templ_feat", "z_mask", "x_gt", "is_ligand"):
+            v = batch[k]
+            if v.dtype != torch.float32 or not v.is_contiguous():
+                batch = dict(batch)
+                batch[k] = v.float().contiguous()
+        return batch
+
+    # ------------------------------------------------------------------ reference API
+    def karras_noise_schedule(self, num_steps=200, sigma_data=16, s_max=160, s_min=4 * 10e-4, p=7):
+        return karras_noise_schedule(num_steps, sigma_data, s_max, s_min, p)
+
+    def _step_plan(self, steps, gamma_0, gamma_min, step_scale_eta, ode_step_scale_eta, mmff_gamma_0_factor,
+                   align_ref_pos, p):
+        """Host-side resolution of every per-step scalar and branch of reference model.py:211-281
+        (all t-dependent branches depend only on the schedule, so none needs a device sync)."""
+        sig = karras_noise_schedule(steps, p=p)
+        sd = float(self.sigma_data)
+        plan = []
+        for i in range(steps):
+            t_cur, t_next = sig[i], sig[i + 1]
+            noisy = bool(t_cur > gamma_min)
+            t_hat = t_cur * (gamma_0 + 1) if noisy else t_cur
+            sdev = torch.sqrt(t_hat ** 2 - t_cur ** 2) if noisy else torch.zeros(())
+            c_in = 1 / torch.sqrt(t_hat ** 2 + sd ** 2)
+            c_noise = torch.log(t_hat / sd) / 4.0
+            plan.append(dict(
+                t_hat=float(t_hat), sdev=float(sdev), noisy=noisy, c_in=float(c_in), tau=float(t_hat * c_noise),
+                c_skip=float(sd ** 2 / (sd ** 2 + t_hat ** 2)), c_out=float(sd * t_hat / torch.sqrt(sd ** 2 + t_hat ** 2)),
+                dt=float(t_next - t_hat), eta=float(step_scale_eta if noisy else ode_step_scale_eta),
+                align=bool(align_ref_pos and t_cur > gamma_min * mmff_gamma_0_factor),
+                mmff=bool(t_cur <= gamma_min * mmff_gamma_0_factor)))
+        return sig, plan
+
+    @torch.no_grad()
+    def sample_diffusion(
+            self,
+            batch: Dict[str, torch.Tensor],
+            num_sample: int = 5,
+            steps: int = 200,
+            gamma_0: float = 0.8,
+            gamma_min: float = 1.0,
+            noise_scale_lambda: float = 1.003,
+            step_scale_eta: float = 1.5,
+            ode_step_scale_eta=1.0,
+            ref_mol=None,
+            ref_mol_poses=None,
+            use_ref_mol_poses=False,
+            mmff_gamma_0_factor=1.0,
+            mmff_iters=5,
+            align_ref_pos=True,
+            karras_noise_schedule_power=7,
+            *,
+            noise=None,
+            seed: int = 0,
+            sample_offset: int = 0,
+            use_graph: bool = True,
+            conditioning=None,
+            return_conditioning: bool = False,
+    ) -> torch.Tensor:
+        """reference models/model.py:157-282.  Returns x_next [num_sample, A, 3] on the batch device."""
+        device = batch["x_gt"].device
+        eng = self.engine(device)
+        batch = self._prepare_batch(batch)
+        L = ops._lib.init()
+        ws = eng.ws
+        B = num_sample
+        A = batch["ref_pos"].shape[0]
+        sp = ops.stream()
+
+        if ref_mol is not None:
+            raise NotImplementedError(
+                "ref_mol (RDKit MMFF94 relaxation on the host, reference model.py:26-52,252-261) needs RDKit, which "
+                "is not available in this build; pass ref_mol=None (template projection via ref_mol_poses is supported)")
+        if ref_mol_poses is None and use_ref_mol_poses:
+            raise NotImplementedError("conformer generation (RDKit ETKDG, model.py:188-203) is not available; pass ref_mol_poses")
+
+        sig, plan = self._step_plan(steps, gamma_0, gamma_min, step_scale_eta, ode_step_scale_eta, mmff_gamma_0_factor,
+                                    align_ref_pos, karras_noise_schedule_power)
+
+        # ---- per-call setup: conditioning trunk, hoisted biases, AdaLN tables
+        a, ap, s, z = conditioning if conditioning is not None else eng.conditioning(batch)
+        tau = ws.get("tau", steps)
+        tau.copy_(torch.tensor([p["tau"] for p in plan], dtype=torch.float32))
+        prep = eng.prepare_dit(a, ap, s, z, batch, tau)
+
+        lig_w = ws.get("lig_w", A)
+        lig_w.copy_(batch["a_mask"] * batch["is_ligand"][batch["atom_id_to_token_id"]])   # index gather: metadata
+        any_align = any(p["align"] for p in plan)
+        ref_dist = poses = lig_idx = None
+        n_conf = n_lig = 0
+        if any_align:
+            bref = ws.get("batch_ref_pos", B, A, 3)
+            bref.copy_(batch["ref_pos"][None].expand(B, A, 3))
+            if ref_mol_poses is not None:
+                lig_idx = torch.nonzero(batch["is_ligand"][batch["atom_id_to_token_id"]] > 0).flatten().to(torch.int32)
+                n_lig = int(lig_idx.numel())
+                if ref_mol_poses.shape[1] == n_lig:      # mismatch: reference silently keeps ref_pos (model.py:229-243)
+                    poses = ref_mol_poses.to(device).float().contiguous()
+                    n_conf = poses.shape[0]
+                    ref_dist = ws.get("ref_dist", n_conf, n_lig, n_lig)
+                    ops.check(L.pd_pose_dist(ops.ptr(poses), ops.ptr(ref_dist), n_conf, n_lig, sp), "pose_dist")
+
+        # ---- random numbers: parity mode copies the caller's draws into fixed buffers
+        x_a = ws.get("x_a", B, A, 3)
+        x_hat = ws.get("x_hat", B, A, 3)
+        x_den = ws.get("x_den", B, A, 3)
+        x_proj = ws.get("x_proj", B, A, 3)
+        n_noisy = sum(p["noisy"] for p in plan)
+        if noise is not None:
+            n_init = ws.get("n_init", B, A, 3); n_init.copy_(noise["init"])
+            n_rot = ws.get("n_rot", steps, 4, B); n_rot.copy_(noise["rot_u"])
+            n_tr = ws.get("n_trans", steps, B, 3); n_tr.copy_(noise["trans"])
+            n_dif = ws.get("n_diffuse", max(n_noisy, 1), B, A, 3)
+            if n_noisy:
+                n_dif[:n_noisy].copy_(noise["diffuse"])
+            seed_buf = None
+        else:
+            seed_buf = ws.get("seed", 1, dtype=torch.int64)
+            seed_buf.fill_(int(seed))
+
+        def run_loop():
+            """the hot loop (reference model.py:211-281): no host sync, no allocation -> graph-capturable"""
+            sp_ = ops.stream()
+            if noise is None:
+                ops.check(L.pd_init_noise(ops.ptr(x_a), ops.ptr(seed_buf), sample_offset, float(sig[0]), B, A, sp_), "init_noise")
+            src, x_scale = (n_init, float(sig[0])) if noise is not None else (x_a, 1.0)
+            k_noisy = 0
+            for i, p in enumerate(plan):
+                if noise is not None:
+                    ru, tr = off(n_rot, i * 4 * B), off(n_tr, i * B * 3)
+                    nz = off(n_dif, k_noisy * B * A * 3) if p["noisy"] else None
+                    sd_ptr = None
+                else:
+                    ru = tr = nz = None
+                    sd_ptr = ops.ptr(seed_buf)
+                ops.check(L.pd_augment(ops.ptr(src), x_scale, ops.ptr(batch["a_mask"]), ru, tr, nz, float(noise_scale_lambda),
+                                       p["sdev"], sd_ptr, i, sample_offset, ops.ptr(x_hat), B, A, sp_), "augment")
+                k_noisy += int(p["noisy"])
+                eng.af3_dit(batch, x_hat, x_den, a, s, prep, B, p, row=i)
+                if p["align"]:
+                    if poses is not None:
+                        ops.check(L.pd_template_match(ops.ptr(x_den), ops.ptr(lig_idx), ops.ptr(ref_dist), ops.ptr(poses),
+                                                      ops.ptr(bref), None, None, B, A, n_lig, n_conf, sp_), "template_match")
+                    ops.check(L.pd_kabsch_align(ops.ptr(x_den), ops.ptr(batch["a_mask"]), ops.ptr(bref), A * 3, ops.ptr(lig_w),
+                                                ops.ptr(x_proj), B, A, sp_), "kabsch")
+                    ops.check(L.pd_euler(ops.ptr(x_hat), ops.ptr(x_den), ops.ptr(x_proj), ops.ptr(lig_w), p["t_hat"], p["eta"],
+                                         p["dt"], ops.ptr(x_a), B, A, sp_), "euler")
+                else:
+                    ops.check(L.pd_euler(ops.ptr(x_hat), ops.ptr(x_den), None, None, p["t_hat"], p["eta"], p["dt"],
+                                         ops.ptr(x_a), B, A, sp_), "euler")
+                src, x_scale = x_a, 1.0
+
+        if use_graph:
+            key = (B, A, batch["target_feat"].shape[0], steps, noise is not None, poses is not None and n_conf,
+                   tuple((p["t_hat"], p["align"], p["eta"]) for p in plan), float(noise_scale_lambda), sample_offset)
+            g = self._graphs.get(key)
+            if g is None:
+                run_loop()                      # eager warm-up: allocates every workspace buffer before capture
+                torch.cuda.synchronize()
+                cap = torch.cuda.Stream()
+                with torch.cuda.stream(cap):
+                    ops.check(L.pd_graph_begin(ops.stream()), "graph_begin")
+                    run_loop()
+                    ex = C.c_void_p()
+                    ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
+                g = {"exec": ex}
+                self._graphs[key] = g
+                if any_align:                   # the warm-up run modified batch_ref_pos
+                    bref.copy_(batch["ref_pos"][None].expand(B, A, 3))
+            ops.check(L.pd_graph_launch(g["exec"], sp), "graph_launch")
+        else:
+            run_loop()
+        out = x_a.clone()
+        if return_conditioning:
+            return out, (a, ap, s, z)
+        return out
+
+    @torch.no_grad()
+    def forward(self, batch):
+        """reference models/model.py:99-115 (training-time forward; kept for API completeness):
+        conditioning -> 48 noised copies (per-sample noise level) -> denoiser -> distogram logits."""
+        device = batch["x_gt"].device
+        eng = self.engine(device)
+        batch = self._prepare_batch(batch)
+        L = ops._lib.init()
+        ws = eng.ws
+        B = self.num_augmentation_sample
+        A, T = batch["ref_pos"].shape[0], batch["target_feat"].shape[0]
+        sd = float(self.sigma_data)
+        a, ap, s, z = eng.conditioning(batch)
+        # augmentation_diffuse (model.py:87-97): per-sample noise levels; RNG on the host generator
+        t_hat = (torch.exp(torch.normal(0, 1, (B,)) * 1.5 - 1.2) * sd).to(device)
+        x_noisy = ws.get("fw_xn", B, A, 3)
+        x_noisy.copy_(batch["x_gt"][None] + torch.normal(0, 1, (B, A, 3)).to(device) * t_hat[:, None, None])
+        x_hat = ws.get("fw_xhat", B, A, 3)
+        rot = torch.rand(4, B).to(device).contiguous()
+        tr = torch.normal(0, 1, (B, 3)).to(device).contiguous()
+        ops.check(L.pd_augment(ops.ptr(x_noisy), 1.0, ops.ptr(batch.get("x_exists", batch["a_mask"])), ops.ptr(rot), ops.ptr(tr),
+                               None, 1.0, 0.0, None, 0, 0, ops.ptr(x_hat), B, A, ops.stream()), "augment")
+        th = t_hat.cpu()
+        scal = {"c_in": (1 / torch.sqrt(th ** 2 + sd ** 2)).to(device), "c_skip": (sd ** 2 / (sd ** 2 + th ** 2)).to(device),
+                "c_out": (sd * th / torch.sqrt(sd ** 2 + th ** 2)).to(device)}
+        tau = (th * (torch.log(th / sd) / 4.0)).to(device)
+        prep = eng.prepare_dit(a, ap, s, z, batch, tau)
+        x_den = ws.get("fw_xden", B, A, 3)
+        eng.af3_dit(batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=True)
+        pd = eng.lin(z, "linear_distogram", T * T).reshape(T, T, -1)
+        return {"x_denoised": x_den.clone(), "x_hat": x_hat.clone(), "t_hat": t_hat,
+                "p_distogram": pd + pd.transpose(0, 1)}
+
+
+def weighted_rigid_align(x_pred, x_gt, weights):
+    """reference utils/tensor_utils.py:724-778: returns x_gt moved onto x_pred (second argument moves)."""
+    L = ops._lib.init()
+    xp = x_pred.float().contiguous()
+    B, A = xp.shape[0], xp.shape[1]
+    xg = x_gt.float().contiguous()
+    out = torch.empty_like(xp)
+    ops.check(L.pd_kabsch_align(ops.ptr(xp), None, ops.ptr(xg), 0 if xg.dim() == 2 else A * 3,
+                                ops.ptr(weights.float().contiguous()), ops.ptr(out), B, A, ops.stream()), "kabsch")
+    return out

@@ -1,5 +1,6 @@
-"""Weight re-packing done once at load time (pure layout changes, no arithmetic on values
-except folding a norm gain / LayerNorm affine into the following projection)."""
+"""Weight re-packing done once at load time (pure layout changes, plus folding a LayerNorm
+affine / the AdaLN "+1" into the projection that follows them).  Runs on whatever device
+the parameters live on; results are cached until the parameters change."""
 from __future__ import annotations
 
 import torch
@@ -17,3 +18,114 @@ def pack_glu(Wa, Wb, ba=None, bb=None):
         bb = bb if bb is not None else torch.zeros(H, dtype=Wa.dtype, device=Wa.device)
         b = torch.stack([ba.reshape(H // 32, 32), bb.reshape(H // 32, 32)], dim=1).reshape(2 * H)
     return W.contiguous(), (b.contiguous() if b is not None else None)
+
+
+def pad_k(W):
+    """[N,K] -> [N, ceil4(K)] zero padded so every row start is 16-byte aligned."""
+    N, K = W.shape
+    Kp = (K + 3) // 4 * 4
+    if Kp == K:
+        return W.contiguous()
+    out = torch.zeros(N, Kp, dtype=W.dtype, device=W.device)
+    out[:, :K] = W
+    return out
+
+
+class PackedWeights:
+    """Device-resident fp32 views of a reference-named state dict + cached packed forms."""
+
+    def __init__(self, params, config):
+        self.p = {k: v.detach().float().contiguous() for k, v in params.items()}
+        self.cfg = config
+        self.cache = {}
+
+    def __getitem__(self, name):
+        return self.p[name]
+
+    def _c(self, key, fn):
+        v = self.cache.get(key)
+        if v is None:
+            v = fn()
+            self.cache[key] = v
+        return v
+
+    def linear(self, name):
+        def mk():
+            W = self.p[name + ".weight"]
+            N, K = W.shape
+            Wp = pad_k(W)
+            return (Wp, self.p.get(name + ".bias"), N, K, Wp.shape[1])
+        return self._c(("lin", name), mk)
+
+    def qkvg(self, prefix):
+        def mk():
+            W = torch.cat([self.p[f"{prefix}.linear_{c}.weight"] for c in "qkvg"], 0).contiguous()
+            C = W.shape[1]
+            b = torch.cat([torch.zeros(3 * C, device=W.device), self.p[prefix + ".linear_g.bias"]]).contiguous()
+            return (W, b)
+        return self._c(("qkvg", prefix), mk)
+
+    def qkv(self, prefix):
+        return self._c(("qkv", prefix), lambda: torch.cat(
+            [self.p[f"{prefix}.linear_{c}.weight"] for c in "qkv"], 0).contiguous())
+
+    def headnorm(self, prefix):
+        return self._c(("hn", prefix), lambda: torch.stack(
+            [self.p[prefix + ".norm_q.weight"], self.p[prefix + ".norm_k.weight"]]).contiguous())
+
+    def glu(self, prefix):
+        def mk():
+            W1, W3 = self.p[prefix + ".w1.weight"], self.p[prefix + ".w3.weight"]
+            W, _ = pack_glu(W1, W3)
+            return (pad_k(W), W1.shape[0])
+        return self._c(("glu", prefix), mk)
+
+    def tri_qk(self, prefix):
+        def mk():
+            g = lambda n: (self.p[f"{prefix}.linear_{n}.weight"], self.p[f"{prefix}.linear_{n}.bias"])
+            (Wqx, bqx), (Wq, bq), (Wkx, bkx), (Wk, bk) = g("qx"), g("q"), g("kx"), g("k")
+            Wa, ba = pack_glu(Wqx, Wq, bqx, bq)
+            Wb, bb = pack_glu(Wkx, Wk, bkx, bk)
+            return (torch.cat([Wa, Wb], 0).contiguous(), torch.cat([ba, bb]).contiguous())
+        return self._c(("triqk", prefix), mk)
+
+    def relpos_T(self):
+        name = "diffusion_conditioning.token_embedder.rel_pos_embedder.linear.weight"
+        return self._c(("relposT",), lambda: self.p[name].t().contiguous())
+
+    def _dit_blocks(self, kind):
+        dt = self.cfg.model.dit
+        if kind == "atom":
+            return [f"dit.atom_dit_encoder.blocks.{b}" for b in range(dt.no_blocks_atom)] + \
+                   [f"dit.atom_dit_decoder.blocks.{b}" for b in range(dt.no_blocks_atom)]
+        return [f"dit.token_dit.blocks.{b}" for b in range(dt.no_blocks_dit)]
+
+    def dit_bias(self, kind):
+        """Concatenated linear_z of every DiT block with that block's LayerNorm affine folded in:
+        Wz.(xhat*w + b) = (Wz*w).xhat + Wz.b            (attentions.py:232,242,254)"""
+        def mk():
+            Ws, bs = [], []
+            for blk in self._dit_blocks(kind):
+                Wz = self.p[blk + ".attention.linear_z.weight"]
+                w, b = self.p[blk + ".attention.norm_z.weight"], self.p[blk + ".attention.norm_z.bias"]
+                Ws.append(Wz * w[None, :])
+                bs.append((Wz * b[None, :]).sum(1))
+            W = pad_k(torch.cat(Ws, 0))
+            return (W, torch.cat(bs).contiguous(), W.shape[0])
+        return self._c(("ditbias", kind), mk)
+
+    def adaln(self, kind):
+        """All AdaLN-Zero projections of one DiT family stacked: per block
+        [attention.norm_s (shift|scale|gate), transition.ffn_norm (shift|scale|gate)], with +1 folded
+        into the scale bias so the table holds (shift, 1+scale, gate)   (adaptive_layer_norm_zero.py:19-20)"""
+        def mk():
+            Ws, bs = [], []
+            for blk in self._dit_blocks(kind):
+                for sub in (".attention.norm_s.linear", ".transition.ffn_norm.linear"):
+                    W, b = self.p[blk + sub + ".weight"], self.p[blk + sub + ".bias"].clone()
+                    C = W.shape[0] // 3
+                    b[C:2 * C] += 1.0
+                    Ws.append(W)
+                    bs.append(b)
+            return (torch.cat(Ws, 0).contiguous(), torch.cat(bs).contiguous())
+        return self._c(("adaln", kind), mk)

@@ -1,0 +1,132 @@
+"""End-to-end parity of the HIP path (through the PhysDock class and the C ABI) against the
+CPU oracle and the golden vectors captured from the reference.  GPU only (-m gpu)."""
+import pytest
+import torch
+
+from conftest import golden_noise, load_golden, rmsd
+
+pytestmark = pytest.mark.gpu
+
+
+def to_dev(batch):
+    return {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+
+@pytest.fixture(scope="module")
+def small(small_model_inputs):
+    from physdock_amd import PhysDock
+    cfg, P, batch = small_model_inputs
+    model = PhysDock(cfg)
+    model.load_state_dict(P, strict=True)
+    return model.cuda().eval(), cfg, P, batch, to_dev(batch)
+
+
+def rel(a, b):
+    return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def test_conditioning_small_vs_golden(small):
+    model, cfg, P, batch, dbatch = small
+    g = load_golden("g2_conditioning")
+    eng = model.engine(torch.device("cuda", torch.cuda.current_device()))
+    a, ap, s, z = eng.conditioning(model._prepare_batch(dbatch))
+    T, A = batch["target_feat"].shape[0], batch["ref_pos"].shape[0]
+    assert rel(a, g["a"]) < 2e-4
+    assert rel(ap.reshape(A, A, -1), g["ap"]) < 2e-4
+    assert rel(s, g["s"]) < 2e-4
+    assert rel(z.reshape(T, T, -1), g["z"]) < 2e-4
+
+
+def test_af3dit_small_vs_golden(small):
+    import physdock_oracle as orc
+    from physdock_amd import ops
+    model, cfg, P, batch, dbatch = small
+    g = load_golden("g2_af3dit")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = model.engine(dev)
+    pb = model._prepare_batch(dbatch)
+    T, A = batch["target_feat"].shape[0], batch["ref_pos"].shape[0]
+    a, ap, s, z = (g[k].cuda().contiguous() for k in ("a", "ap", "s", "z"))
+    x_hat, t_hat = g["x_hat"], g["t_hat"]
+    sd = 16.0
+    outs = []
+    for i in range(len(t_hat)):
+        th = t_hat[i]
+        tau = (th * (torch.log(th / sd) / 4.0)).reshape(1).cuda()
+        prep = eng.prepare_dit(a, ap.reshape(A * A, -1), s, z.reshape(T * T, -1), pb, tau)
+        scal = dict(c_in=float(1 / torch.sqrt(th ** 2 + sd ** 2)), c_skip=float(sd ** 2 / (sd ** 2 + th ** 2)),
+                    c_out=float(sd * th / torch.sqrt(sd ** 2 + th ** 2)))
+        xd = torch.empty(1, A, 3, device="cuda")
+        eng.af3_dit(pb, x_hat[i:i + 1].cuda().contiguous(), xd, a, s, prep, 1, scal, row=0)
+        outs.append(xd.cpu())
+    y = torch.cat(outs)
+    assert float((y - g["x_denoised"]).abs().max()) < 2e-4 * float(g["x_denoised"].abs().max())
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("g5_trajectory_10", dict(align_ref_pos=False, karras_noise_schedule_power=1000)),
+    ("g5_trajectory_40", dict(align_ref_pos=False, karras_noise_schedule_power=1000)),
+    ("g5_trajectory_align_refpos", dict(align_ref_pos=True, ode_step_scale_eta=1.5, karras_noise_schedule_power=7)),
+])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_trajectory_vs_reference_golden(small, tag, kw, use_graph):
+    """north_star bar: <= 1e-3 A RMSD on final coordinates with identical inputs and noise"""
+    model, cfg, P, batch, dbatch = small
+    g = load_golden(tag)
+    nz = golden_noise(g)
+    B = nz["init"].shape[0]
+    x = model.sample_diffusion(dbatch, num_sample=B, steps=g["steps"], noise=nz, use_graph=use_graph, **kw)
+    assert x.shape == g["x_pred"].shape
+    assert rmsd(x.cpu(), g["x_pred"]) < 1e-3
+    if use_graph:   # replay must reproduce itself
+        x2 = model.sample_diffusion(dbatch, num_sample=B, steps=g["steps"], noise=nz, use_graph=True, **kw)
+        assert torch.equal(x, x2)
+
+
+def test_template_branch_vs_reference_golden(small):
+    model, cfg, P, batch, dbatch = small
+    g = load_golden("g6_trajectory_template")
+    nz = golden_noise(g)
+    for use_graph in (False, True):
+        x = model.sample_diffusion(dbatch, num_sample=3, steps=g["steps"], ref_mol_poses=g["ref_mol_poses"],
+                                   use_ref_mol_poses=True, mmff_gamma_0_factor=g["mmff_gamma_0_factor"],
+                                   align_ref_pos=True, karras_noise_schedule_power=1000, noise=nz, use_graph=use_graph)
+        assert rmsd(x.cpu(), g["x_pred"]) < 1e-3
+
+
+def test_reselect_and_align_kernels():
+    import ctypes as C
+    from physdock_amd import ops, weighted_rigid_align
+    L = ops._lib.init()
+    g = load_golden("g7_reselect")
+    lp, poses = g["ligand_poses"].cuda().contiguous(), g["ref_mol_poses"].cuda().contiguous()
+    Bn, Ln, Cn = lp.shape[0], lp.shape[1], poses.shape[0]
+    rd = torch.empty(Cn, Ln, Ln, device="cuda")
+    ops.check(L.pd_pose_dist(ops.ptr(poses), ops.ptr(rd), Cn, Ln, ops.stream()), "pose_dist")
+    eps = torch.empty(Bn, Cn, device="cuda"); sel = torch.empty(Bn, dtype=torch.int32, device="cuda")
+    idx = torch.arange(Ln, dtype=torch.int32, device="cuda")
+    ops.check(L.pd_template_match(ops.ptr(lp), ops.ptr(idx), ops.ptr(rd), None, None, ops.ptr(eps), ops.ptr(sel),
+                                  Bn, Ln, Ln, Cn, ops.stream()), "template_match")
+    torch.testing.assert_close(eps.cpu(), g["eps_bc"], atol=2e-6, rtol=1e-5)
+    assert torch.equal(sel.cpu().long(), g["argmin_b"])
+    assert torch.equal(torch.argsort(eps.mean(0)).cpu(), g["order"])       # redocking.py:326-335
+    g = load_golden("g4_augment_align")
+    for xg, ref in ((g["x_gt2d"], g["aligned2d"]), (g["x_gt3d"], g["aligned3d"])):
+        y = weighted_rigid_align(g["x_pred"].cuda(), xg.cuda(), g["w"].cuda())
+        torch.testing.assert_close(y.cpu(), ref, atol=2e-4, rtol=1e-4)
+    y = weighted_rigid_align(g["x_pred_refl"].cuda(), g["x_pred"][0].cuda(), g["w"].cuda())
+    torch.testing.assert_close(y.cpu(), g["aligned_refl"], atol=2e-4, rtol=1e-4)
+
+
+def test_philox_mode_is_seeded_and_shard_invariant(small):
+    """perf mode: on-device Philox keyed by (seed, global sample id, step) - same poses whatever the sharding"""
+    model, cfg, P, batch, dbatch = small
+    kw = dict(steps=8, align_ref_pos=False, karras_noise_schedule_power=1000, use_graph=False)
+    full = model.sample_diffusion(dbatch, num_sample=4, seed=7, **kw)
+    again = model.sample_diffusion(dbatch, num_sample=4, seed=7, **kw)
+    other = model.sample_diffusion(dbatch, num_sample=4, seed=8, **kw)
+    assert torch.equal(full, again) and not torch.equal(full, other)
+    lo = model.sample_diffusion(dbatch, num_sample=2, seed=7, sample_offset=0, **kw)
+    hi = model.sample_diffusion(dbatch, num_sample=2, seed=7, sample_offset=2, **kw)
+    assert rmsd(torch.cat([lo, hi]).cpu(), full.cpu()) < 1e-4
+    assert torch.isfinite(full).all()
