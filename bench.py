@@ -64,14 +64,27 @@ def build_inputs(args, device):
     return cfg, P, batch, dbatch, confs, model
 
 
+def usable_cores():
+    """CPUs this process may actually use: min(affinity mask, cgroup quota) - NOT os.cpu_count()
+    (the GPU box shows 256 logical CPUs but grants a 16-CPU quota; 256 threads there thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg, P, batch, confs, args):
-    """The CPU oracle on the host cores, bounded sample: trunk once + 2 denoiser steps at B=4,
+    """The CPU oracle on the host cores, bounded sample: trunk once + 2 denoiser steps at B=16,
     scaled to a full call (poses/s = B / (t_trunk + n_steps * t_step))."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import physdock_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    B = 4
+    B = 16
     with torch.no_grad():
         t0 = time.perf_counter()
         a, ap, s, z = orc.diffusion_conditioning(P, batch)
@@ -90,39 +103,57 @@ def cpu_baseline(cfg, P, batch, confs, args):
                       f"steps at B={B} ({t_step:.2f}s/step), scaled to {n} steps: {B}/(t_trunk+{n}*t_step)"}
 
 
-class KernelTimer:
-    """Brackets every launch of one kernel family with HIP events on the launch stream."""
+class LaunchTimer:
+    """Brackets every GEMM / attention launch of one eager pass with HIP events on the launch stream
+    (the torch current stream = the stream the C ABI launches on) and aggregates per kernel symbol."""
 
-    def __init__(self, ops, which, pred):
-        self.ops, self.which, self.pred = ops, which, pred
-        self.events, self.flops = [], 0.0
+    GEMM_NAMES = {0: "128, 128, 2, 2", 1: "128, 64, 2, 2", 2: "128, 32, 4, 1", 3: "64, 64, 2, 2"}
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.rec = {}      # kernel symbol -> [events, flops]
+
+    def _add(self, name, e0, e1, flops):
+        r = self.rec.setdefault(name, [[], 0.0])
+        r[0].append((e0, e1))
+        r[1] += flops
 
     def __enter__(self):
-        self.orig = getattr(self.ops, self.which)
+        ops = self.ops
+        L = ops._lib.init()
+        import ctypes as C
 
-        def wrapped(*a, **k):
-            fl = self.pred(a, k)
-            if fl is None:
-                return self.orig(*a, **k)
+        def gemm_hook(a, launch):
+            v = L.pd_gemm_variant(C.byref(a))
+            cfg, lay, pro, scalar = (v % 1000) // 100, (v % 100) // 10, v % 10, v >= 1000
+            name = "gemm_kernel<%s, %s, %s, %s, %d>" % (self.GEMM_NAMES[cfg], "true" if lay >= 1 else "false",
+                                                         "true" if lay == 2 else "false", "false" if scalar else "true", pro)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = self.orig(*a, **k)
-            e1.record()
-            self.events.append((e0, e1))
-            self.flops += fl
+            e0.record(); launch(); e1.record()
+            self._add(name, e0, e1, 2.0 * a.M * a.N * a.K * max(a.batch, 1))
+        self._orig_attn = ops.attention
+
+        def attn(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); r = self._orig_attn(*a, **k); e1.record()
+            self._add("attn_kernel", e0, e1, 4.0 * k["nbatch"] * k["nheads"] * k["nq"] * k["nk"] * 32)
             return r
-        setattr(self.ops, self.which, wrapped)
+        ops.GEMM_HOOK = gemm_hook
+        ops.attention = attn
         return self
 
     def __exit__(self, *e):
-        setattr(self.ops, self.which, self.orig)
+        self.ops.GEMM_HOOK = None
+        self.ops.attention = self._orig_attn
 
-    def result(self):
+    def summary(self):
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in self.events]
-        n = len(ms)
-        tot = sum(ms) * 1e-3
-        return n, tot / max(n, 1), self.flops / max(n, 1)
+        out = []
+        for name, (ev, fl) in self.rec.items():
+            t = sum(a.elapsed_time(b) for a, b in ev) * 1e-3
+            out.append(dict(kernel=name, launches=len(ev), total_s=t, avg_launch_ms=1e3 * t / len(ev),
+                            flop_per_launch=fl / len(ev), tflops=fl / t / 1e12))
+        return sorted(out, key=lambda d: -d["total_s"])
 
 
 def main():
@@ -196,24 +227,21 @@ def main():
             out["path_tflops_per_gpu"] = flop_per_call * args.steps / elapsed / 1e12
             out["path_frac_of_fp32_mfma_peak"] = out["path_tflops_per_gpu"] / PEAK_FP32_MFMA_TFLOPS
 
-    # ---- roofline of the dominant kernel: instrumented eager pass, HIP events around each launch
+    # ---- roofline of the dominant kernel: instrumented eager pass of the SAME call, HIP events around
+    #      every GEMM / attention launch; the kernel symbol with the largest total time is reported
     if rank == 0 and not args.no_roofline:
         from physdock_amd import ops
-        Ha = cfg.model.dit.c_a // 32
-
-        def is_atom_attn(a, k):      # the DiT atom attention launches (B x H x A x A), 6 per diffusion step
-            if k.get("nbatch") == B and k.get("nq") == A and k.get("nheads") == Ha:
-                return 4.0 * B * Ha * A * A * 32
-            return None
         kw2 = dict(kw); kw2["use_graph"] = False
-        with KernelTimer(ops, "attention", is_atom_attn) as kt:
-            import physdock_amd.engine as eng_mod
+        with LaunchTimer(ops) as lt:
             model.sample_diffusion(dbatch, seed=99, sample_offset=0, **kw2)
-            n, avg_s, flops = kt.result()
-        out["roofline"] = {"kernel": "attn_kernel (DiT atom attention, fp32 MFMA flash attention with pair bias)",
-                           "bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                           "launches": n, "avg_launch_ms": avg_s * 1e3, "flop_per_launch": flops, "traffic": None}
+            summ = lt.summary()
+        dom = summ[0]
+        out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
+                           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
+                           "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+                           "flop_per_launch": dom["flop_per_launch"], "traffic": None,
+                           "note": "algorithmic flops = 2*M*N*K per GEMM launch (4*B*H*Nq*Nk*32 per attention launch)"}
+        out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in summ[:4]]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, P, batch, confs, args)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -71,6 +71,8 @@ typedef struct pd_gemm_args {
     int vecA, vecW, vecY;        /* set by the launcher                                      */
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
+/* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling) */
+int pd_gemm_variant(const pd_gemm_args* args);
 
 /* ---- pd_rowstats: per-row (mean, rstd) for the GEMM prologue --------------------------
  * mode 0: RMS  -> (0, rsqrt(mean(x^2)+eps));  mode 1: LayerNorm -> (mean, rsqrt(var+eps)).

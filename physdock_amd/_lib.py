@@ -90,6 +90,7 @@ def _declare(L):
     sig("pd_abi_version")
     sig("pd_init")
     sig("pd_gemm", C.POINTER(GemmArgs), p)
+    sig("pd_gemm_variant", C.POINTER(GemmArgs))
     sig("pd_rowstats", p, p, i, i, i, i, i, f, p)
     sig("pd_rownorm", p, p, p, p, p, i, i, i, f, i, p)
     sig("pd_attention", C.POINTER(AttnArgs), p)

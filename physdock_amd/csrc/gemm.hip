@@ -449,16 +449,16 @@ PD_EXPORT int pd_init(void) {
     return rc;
 }
 
-PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
-    if (!args || !args->A || !args->W || !args->Y) return PD_ERR_ARG;
-    pd_gemm_args p = *args;
+// shared argument normalisation + variant selection; returns <0 on error, else variant id
+// id = cfg*100 + layout*10 + pro  (cfg 0:128x128 1:128x64 2:128x32 3:64x64; layout 0:NN 1:A k-major 2:both; +1000 scalar loads)
+static int select_variant(pd_gemm_args& p, int& cfg, bool& akm, bool& wkm, bool& vec, int& pro) {
+    if (!p.A || !p.W || !p.Y) return PD_ERR_ARG;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return PD_ERR_ARG;
     if (p.batch <= 0) p.batch = 1;
     if (p.out_scale == 0.f) p.out_scale = 1.f;
     if (p.glu && (p.N % 64 != 0)) return PD_ERR_ARG;
     if (p.hn_w && (p.hn_split % 32 != 0 || p.hn_cols % 32 != 0 || p.glu)) return PD_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    const bool akm = p.a_kmajor != 0, wkm = p.w_kmajor != 0;
+    akm = p.a_kmajor != 0; wkm = p.w_kmajor != 0;
     // 16-byte vector loads need aligned row starts; tails are masked per element, so a row may
     // end anywhere inside its (ld-padded) last chunk.
     p.vecA = aligned16(p.A) && (p.lda % 4 == 0) && (p.sA % 4 == 0);
@@ -466,14 +466,16 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     p.vecY = aligned16(p.Y) && (p.ldy % 4 == 0) && (p.sY % 4 == 0) &&
              (!p.res || (aligned16(p.res) && p.ldres % 4 == 0 && p.sRes % 4 == 0)) &&
              (!p.mul || (aligned16(p.mul) && (p.mul_rows_per_group > 0 ? p.mul_gstride % 4 == 0 : p.ldmul % 4 == 0)));
-    const bool vec = p.vecA && p.vecW;
-    int pro = 0;
+    vec = p.vecA && p.vecW;
+    pro = 0;
     if (p.stats) {
         if (!p.pro_w || !p.pro_b) return PD_ERR_ARG;      // pass ones / zeros explicitly
         pro = p.pro_rows_per_group > 0 ? 2 : 1;
         if (!akm && (!aligned16(p.pro_w) || !aligned16(p.pro_b) || p.pro_gstride % 4 != 0)) return PD_ERR_UNSUPPORTED;
     }
-    int cfg;
+    if ((akm || wkm) && !vec) return PD_ERR_UNSUPPORTED;
+    if (wkm && !akm) return PD_ERR_UNSUPPORTED;
+    if (!vec && p.glu) return PD_ERR_UNSUPPORTED;
     const long long blocks128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     if (akm || wkm || p.glu) cfg = 0;
     else if (!vec) cfg = 3;
@@ -482,5 +484,21 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     else if (p.N <= 64) cfg = 1;
     else cfg = 0;
     if (pro == 2 && cfg != 0 && cfg != 3) cfg = 0;
-    return dispatch(0, cfg, akm, wkm, vec, pro, &p, s);
+    return cfg * 100 + (akm ? (wkm ? 2 : 1) : 0) * 10 + pro + (vec ? 0 : 1000);
+}
+
+PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
+    if (!args) return PD_ERR_ARG;
+    pd_gemm_args p = *args;
+    int cfg, pro; bool akm, wkm, vec;
+    return select_variant(p, cfg, akm, wkm, vec, pro);
+}
+
+PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
+    if (!args) return PD_ERR_ARG;
+    pd_gemm_args p = *args;
+    int cfg, pro; bool akm, wkm, vec;
+    const int v = select_variant(p, cfg, akm, wkm, vec, pro);
+    if (v < 0) return v;
+    return dispatch(0, cfg, akm, wkm, vec, pro, &p, (hipStream_t)stream);
 }

@@ -63,7 +63,13 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
     a.out_scale = out_scale
     a.res, a.ldres, a.res_row_mod, a.sRes = P(res), (ldres or n_out), res_row_mod, sRes
     a.out_mode, a.T1, a.T2, a.frag_transpose = out_mode, T1, T2, int(frag_transpose)
+    if GEMM_HOOK is not None:
+        return GEMM_HOOK(a, lambda: check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm"))
     check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm")
+
+
+#: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
+GEMM_HOOK = None
 
 
 def rowstats(x, stats, M, Cdim, *, ldx=None, kmajor=False, mode=RMS, eps=1e-8):
