@@ -1,0 +1,48 @@
+"""Sample-parallel multi-GPU helpers (one process per GPU, torch.distributed; backend "nccl" is
+RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+Diffusion samples are independent given the conditioning (reference model.py:211-281 has no
+cross-sample op), so ranks own contiguous blocks of global sample ids, recompute the trunk
+redundantly (no data-path collective) and send their poses to rank 0 with ONE gather for
+ranking (the consumer of the poses is redocking.py:357-423)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_sample: int, rank: int, world: int):
+    """contiguous block [lo, hi) of global sample ids for `rank` (sizes differ by at most one)"""
+    base, rem = divmod(num_sample, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_poses(x_local: torch.Tensor, num_sample: int, dst: int = 0):
+    """Gather per-rank pose blocks [B_r, A, 3] to `dst`; returns [num_sample, A, 3] there, None elsewhere.
+    Blocks may differ in size by one sample, so every rank pads to the largest block."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x_local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    bmax = max(shard_range(num_sample, r, world)[1] - shard_range(num_sample, r, world)[0] for r in range(world))
+    pad = x_local.new_zeros((bmax,) + tuple(x_local.shape[1:]))
+    pad[: x_local.shape[0]] = x_local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = []
+    for r in range(world):
+        lo, hi = shard_range(num_sample, r, world)
+        out.append(bufs[r][: hi - lo])
+    return torch.cat(out, 0)
+
+
+def sample_diffusion_parallel(model, batch, num_sample: int, **kw):
+    """Strong-scaling form of `model.sample_diffusion`: the `num_sample` poses of one call are split
+    over the ranks; rank 0 gets all of them back (others get None)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return model.sample_diffusion(batch, num_sample=num_sample, **kw)
+    lo, hi = shard_range(num_sample, dist.get_rank(), dist.get_world_size())
+    x = model.sample_diffusion(batch, num_sample=hi - lo, sample_offset=kw.pop("sample_offset", 0) + lo, **kw)
+    return gather_poses(x, num_sample)

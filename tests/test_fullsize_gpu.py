@@ -1,0 +1,75 @@
+"""Full-size parity (BASELINE.json configs[1] shapes: medium model, T=256, A=2048, S=128):
+HIP path vs the CPU oracle on the same seeded weights / inputs / noise.  GPU only; the oracle
+side takes ~1 minute of host CPU."""
+import pytest
+import torch
+
+import physdock_oracle as orc
+from conftest import rmsd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    from physdock_amd import PhysDock, PhysDockConfig, param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import cfg1_batch, reference_conformers
+    cfg = PhysDockConfig(model_name="medium")
+    P = seeded_state_dict(param_shapes(cfg), seed=0)
+    batch = cfg1_batch(0)
+    model = PhysDock(cfg)
+    model.load_state_dict(P, strict=True)
+    model = model.cuda().eval()
+    dbatch = {k: v.cuda() for k, v in batch.items()}
+    with torch.no_grad():
+        cond = orc.diffusion_conditioning(P, batch)
+    return cfg, P, batch, dbatch, model, cond, reference_conformers(batch, n_conf=8, seed=1)
+
+
+def relmax(a, b):
+    return float((a.cpu().reshape(b.shape) - b).abs().max() / b.abs().max())
+
+
+def test_trunk_cfg1_vs_oracle(full):
+    cfg, P, batch, dbatch, model, cond, confs = full
+    eng = model.engine(torch.device("cuda", torch.cuda.current_device()))
+    a, ap, s, z = eng.conditioning(model._prepare_batch(dbatch))
+    errs = dict(a=relmax(a, cond[0]), ap=relmax(ap, cond[1]), s=relmax(s, cond[2]), z=relmax(z, cond[3]))
+    print("trunk relative max errors:", errs)
+    assert max(errs.values()) < 1e-3, errs
+
+
+@pytest.mark.parametrize("physics", [False, True])
+def test_trajectory_cfg1_vs_oracle(full, physics):
+    """north_star bar: final coordinates within 1e-3 A RMSD of the fp32 CPU path, identical noise"""
+    cfg, P, batch, dbatch, model, cond, confs = full
+    B, steps = 2, 4
+    A = batch["ref_pos"].shape[0]
+    g = torch.Generator().manual_seed(11)
+    n_noisy = int((orc.karras_noise_schedule(steps, p=1000)[:-1] > 1.0).sum())
+    noise = {"init": torch.randn(B, A, 3, generator=g), "rot_u": torch.rand(steps, 4, B, generator=g),
+             "trans": torch.randn(steps, B, 3, generator=g), "diffuse": torch.randn(n_noisy, B, A, 3, generator=g)}
+    kw = dict(num_sample=B, steps=steps, karras_noise_schedule_power=1000, align_ref_pos=physics)
+    if physics:
+        kw.update(ref_mol_poses=confs, mmff_gamma_0_factor=6.0)
+    with torch.no_grad():
+        ref = orc.sample_diffusion(P, batch, noise, conditioning=cond, **kw)
+    if physics:
+        kw.update(use_ref_mol_poses=True)
+    x = model.sample_diffusion(dbatch, noise=noise, use_graph=True, **kw)
+    r = rmsd(x.cpu(), ref)
+    print(f"cfg1 {steps}-step trajectory (physics={physics}) RMSD vs oracle: {r:.3e} A")
+    assert r < 1e-3
+
+
+def test_bench_workload_properties(full):
+    """size-independent properties at the bench configuration: finite poses, graph replay is
+    bit-reproducible for a seed, different seeds differ, re-centred (augmentation removes the centroid)"""
+    cfg, P, batch, dbatch, model, cond, confs = full
+    kw = dict(num_sample=16, steps=6, karras_noise_schedule_power=1000, align_ref_pos=True,
+              ref_mol_poses=confs.cuda(), use_ref_mol_poses=True, mmff_gamma_0_factor=6.0)
+    x1 = model.sample_diffusion(dbatch, seed=5, **kw)
+    x2 = model.sample_diffusion(dbatch, seed=5, **kw)
+    x3 = model.sample_diffusion(dbatch, seed=6, **kw)
+    assert x1.shape == (16, 2048, 3) and torch.isfinite(x1).all()
+    assert torch.equal(x1, x2) and not torch.equal(x1, x3)
