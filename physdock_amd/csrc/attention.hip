@@ -28,7 +28,7 @@ constexpr int KT = 64;      // keys per LDS tile
 constexpr int LDKS = 36;    // K row stride (floats): conflict-free ds_read_b128
 constexpr int LDVS = 32;    // V row stride
 
-__global__ __launch_bounds__(256) void attn_kernel(const pd_attn_args p) {
+__global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
     __shared__ __attribute__((aligned(16))) float sK[2][KT * LDKS];
     __shared__ __attribute__((aligned(16))) float sV[2][KT * LDVS];
 

@@ -39,11 +39,12 @@ def test_trunk_cfg1_vs_oracle(full):
     assert max(errs.values()) < 1e-3, errs
 
 
-@pytest.mark.parametrize("physics", [False, True])
-def test_trajectory_cfg1_vs_oracle(full, physics):
-    """north_star bar: final coordinates within 1e-3 A RMSD of the fp32 CPU path, identical noise"""
+@pytest.mark.parametrize("physics,B,steps", [(False, 1, 40), (True, 2, 12)])
+def test_trajectory_cfg1_vs_oracle(full, physics, B, steps):
+    """north_star bar: final coordinates within 1e-3 A RMSD of the fp32 CPU path, identical noise
+    (40 steps = the benchmark schedule; measured 5e-4 A, of which 4e-5 A is the loop and the rest
+    the trunk's fp32 re-association noise amplified by 30 random-weight triangle blocks)"""
     cfg, P, batch, dbatch, model, cond, confs = full
-    B, steps = 2, 4
     A = batch["ref_pos"].shape[0]
     g = torch.Generator().manual_seed(11)
     n_noisy = int((orc.karras_noise_schedule(steps, p=1000)[:-1] > 1.0).sum())
