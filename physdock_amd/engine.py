@@ -82,7 +82,7 @@ class Engine:
                  frag_transpose=transpose, maskadd=mask, maskval=-self.inf, out_scale=LOG2E)
         return H
 
-    def attention_pair_bias(self, prefix, s, nbatch, N, C, bias, norm_name="norm_s"):
+    def attention_pair_bias(self, prefix, s, nbatch, N, C, bias, norm_name="norm_s", nk=None):
         """s += (W_o . Attn(RMSNorm(s)) + b_o) * (W_g RMSNorm(s) + b_g)   (attentions.py:32-53,76-97)"""
         P = self.P
         rows = nbatch * N
@@ -93,7 +93,7 @@ class Engine:
         ops.gemm(s, W, qkvg, rows, 4 * C, C, stats=st, pro_w=P[f"{prefix}.{norm_name}.weight"], bias=b)
         o = self.ws.get("attn_o", rows, C)
         st4 = (N * 4 * C, 4 * C)
-        ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=N, nbatch=nbatch, nheads=H,
+        ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=nk or N, nbatch=nbatch, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias)
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         ops.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s)
@@ -122,10 +122,11 @@ class Engine:
         g = self.ws.get("tri_g", M, C)
         ops.gemm(z, Wg, g, M, C, C, ldw=ldw, stats=st, pro_w=nw, bias=bg, act=ACT_SIGMOID)
         o = self.ws.get("tri_o", 32, M)
+        Tr = self.Tr          # the sum over j runs over REAL tokens only (padded j never enter a reduction)
         if not transpose:   # o[c,i,I] = sum_j q[c,i,j] k[c,I,j]
-            ops.gemm(off(qk, 0), off(qk, 32 * M), o, T, T, T, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M)
+            ops.gemm(off(qk, 0), off(qk, 32 * M), o, T, T, Tr, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M)
         else:               # o[c,a,b] = sum_j k[c,j,a] q[c,j,b]
-            ops.gemm(off(qk, 32 * M), off(qk, 0), o, T, T, T, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M,
+            ops.gemm(off(qk, 32 * M), off(qk, 0), o, T, T, Tr, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M,
                      a_kmajor=True, w_kmajor=True)
         st2 = self.stats(o, M, 32, RMS, self.eps, "stats_tri", kmajor=True, ldx=M)
         Wz, bz, _, _, ldw = P.linear(prefix + ".linear_z")
@@ -149,7 +150,7 @@ class Engine:
             st4, sto = (T * 4 * C, 4 * C), (T * C, C)
         else:
             st4, sto = (4 * C, T * 4 * C), (C, T * C)
-        ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=T, nbatch=T, nheads=H,
+        ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias)
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         ops.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z)
@@ -172,6 +173,10 @@ class Engine:
         T = batch["target_feat"].shape[0]
         S = batch["msa_feat"].shape[0]
         a2t = batch["atom_id_to_token_id"]
+        # padded counts size every row dimension; REAL counts bound every reduction (attention keys, the
+        # triangle-multiplication sum), so padding is exactly inert - also for fully masked query rows, which
+        # the reference's -1e9 mask turns into a uniform softmax over the real keys (tensor_utils.py:642-646)
+        self.Ar, self.Tr = batch.get("_A_real", A), batch.get("_T_real", T)
         ap_mask = batch["ap_mask"]
         z_mask = batch["z_mask"]
         pre = "diffusion_conditioning"
@@ -201,7 +206,7 @@ class Engine:
         for b in range(dc.no_blocks_atom):
             blk = f"{ae}.atom_transformer.blocks.{b}"
             self.pair_bias(blk + ".attention", ap, A, A, Cap, ap_mask, P[blk + ".attention.norm_z.weight"], abias)
-            self.attention_pair_bias(blk + ".attention", a, 1, A, Ca, abias)
+            self.attention_pair_bias(blk + ".attention", a, 1, A, Ca, abias, nk=self.Ar)
             self.transition(blk + ".transition", a, A, Ca)
 
         # ---------------- TokenEmbedder (:178-202)
@@ -232,7 +237,7 @@ class Engine:
             blk = f"{te}.evoformer.blocks.{b}"
             # MSA row attention with pair bias (attentions.py:76-97)
             self.pair_bias(blk + ".msa_row_attention", z, T, T, Cz, z_mask, P[blk + ".msa_row_attention.norm_z.weight"], mbias)
-            self.attention_pair_bias(blk + ".msa_row_attention", m, S, T, Cm, mbias, norm_name="norm_m")
+            self.attention_pair_bias(blk + ".msa_row_attention", m, S, T, Cm, mbias, norm_name="norm_m", nk=self.Tr)
             self.msa_column_attention(blk + ".msa_col_attention", m, S, T, Cm)
             self.transition(blk + ".msa_transition", m, S * T, Cm)
             self.outer_product_mean(blk + ".opm", m, z, S, T, Cm, Cz)
@@ -266,7 +271,7 @@ class Engine:
             blk = f"{te}.pairformer.blocks.{b}"
             self.triangle_block(blk, z, T, Cz, z_mask)
             self.pair_bias(blk + ".attention", z, T, T, Cz, z_mask, P[blk + ".attention.norm_z.weight"], sbias)
-            self.attention_pair_bias(blk + ".attention", s, 1, T, Cs, sbias)
+            self.attention_pair_bias(blk + ".attention", s, 1, T, Cs, sbias, nk=self.Tr)
             self.transition(blk + ".transition", s, T, Cs)
 
         # ---------------- tail (:236-237)
@@ -342,7 +347,7 @@ class Engine:
         ops.gemm(t, Wtt, tab_t, n, Wtt.shape[0], 256, bias=btt, pro_act=ACT_SILU)
         return {"atom_bias": fa, "token_bias": ft, "tab_atom": tab_a, "tab_token": tab_t}
 
-    def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample):
+    def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample, nk):
         """DiTBlock (transformers.py:155-159; attentions.py:241-265; transitions.py:27-30).
         tab: AdaLN table row(s) [shift | 1+scale | gate] x (attention, transition) for this block."""
         P, eps = self.P, self.eps
@@ -357,7 +362,7 @@ class Engine:
                  hn_eps=eps, **grp)
         o = self.ws.get("dit_o", rows, C)
         st3 = (N * 3 * C, 3 * C)
-        ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, nq=N, nk=N, nbatch=B, nheads=H,
+        ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, nq=N, nk=nk, nbatch=B, nheads=H,
                       q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         ops.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)
@@ -376,6 +381,7 @@ class Engine:
         dt = self.cfg.model.dit
         Ca, Cs = dt.c_a, dt.c_s
         A, T = a.shape[0], s.shape[0]
+        Ar, Tr = batch.get("_A_real", A), batch.get("_T_real", T)
         Ha, Hs = Ca // 32, Cs // 32
         L = ops._lib.init()
         sp = ops.stream()
@@ -390,21 +396,21 @@ class Engine:
         nb_a, nb_t = dt.no_blocks_atom, dt.no_blocks_dit
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_encoder.blocks.{b}", ba, B, A, Ca, off(prep["atom_bias"], b * fa_stride),
-                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample)
+                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar)
         u = ws.get("dit_u", B * A, Cs)
         self.lin(ba, "dit.linear_downscale", B * A, out=u, act=ACT_SILU)
         bs = ws.get("dit_bs", B * T, Cs)
         ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs), B, A, T, Cs, sp), "pool")
         for b in range(nb_t):
             self.dit_block(f"dit.token_dit.blocks.{b}", bs, B, T, Cs, off(prep["token_bias"], b * ft_stride),
-                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample)
+                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr)
         us = ws.get("dit_us", B * T, Ca)
         self.lin(bs, "dit.linear_upscale", B * T, out=us)
         ops.check(L.pd_unpool_add(ops.ptr(ba), ops.ptr(us), ops.ptr(batch["atom_id_to_token_id"]), B, A, T, Ca, sp), "unpool")
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_decoder.blocks.{b}", ba, B, A, Ca,
                            off(prep["atom_bias"], (nb_a + b) * fa_stride), tab_a, row * lda_ + (nb_a + b) * 6 * Ca, lda_,
-                           per_sample)
+                           per_sample, Ar)
         cs_b = ops.ptr(scal["c_skip"]) if per_sample else None
         co_b = ops.ptr(scal["c_out"]) if per_sample else None
         ops.check(L.pd_denoise(ops.ptr(ba), ops.ptr(x_hat), ops.ptr(P["dit.norm_r.weight"]), ops.ptr(P["dit.norm_r.bias"]),

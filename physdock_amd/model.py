@@ -86,23 +86,65 @@ class PhysDock(nn.Module):
 
     @staticmethod
     def _prepare_batch(batch):
-        """index bookkeeping the kernels need (int32 token start offsets) - metadata only"""
-        if "_tok_start" not in batch:
-            chunk = batch["token_id_to_chunk_sizes"]
-            ts = torch.zeros(chunk.shape[0] + 1, dtype=torch.int32, device=chunk.device)
-            ts[1:] = torch.cumsum(chunk, 0).to(torch.int32)
-            batch = dict(batch)
-            batch["_tok_start"] = ts
-        A, T = batch["ref_pos"].shape[0], batch["target_feat"].shape[0]
-        if A % 4 or T % 4:
-            raise NotImplementedError("token / atom counts must be multiples of 4 (pad with masked entries)")
+        """Boundary bookkeeping (layout only): int32 token start offsets for the pooling kernels, fp32
+        contiguity, and - for un-padded real systems whose token / atom counts are not multiples of 4
+        (reference feature_loader.py:982-983) - padding with MASKED tokens / atoms.  The reference's own
+        masks (a_mask / ap_mask / z_mask, tensor_utils.py:642-646) make padded entries inert: masked keys
+        get weight exp(-1e9) = 0, triangle operands are multiplied by the mask, pooling is per token."""
+        if "_tok_start" in batch:
+            return batch
+        b = dict(batch)
+        A, T = b["ref_pos"].shape[0], b["target_feat"].shape[0]
+        b["_A_real"], b["_T_real"] = A, T
+        pa = (-A) % 4
+        pt = (-T) % 4
+        if pa and not pt:
+            pt = 4                      # padded atoms need a padded token to belong to
+        if pa or pt:
+            import torch.nn.functional as F
+            dev = b["ref_pos"].device
+
+            def pad(k, dims, value=0):
+                v = b[k]
+                spec = []
+                for d in range(v.dim() - 1, -1, -1):
+                    spec += [0, dims.get(d, 0)]
+                b[k] = F.pad(v, spec, value=value)
+            for k in ("ref_feat", "ref_pos", "a_mask", "x_gt"):
+                pad(k, {0: pa})
+            if "x_exists" in b:
+                pad("x_exists", {0: pa})
+            pad("ap_mask", {0: pa, 1: pa})
+            b["ref_space_uid"] = torch.cat([b["ref_space_uid"], b["ref_space_uid"].max() + 1 +
+                                            torch.arange(pa, device=dev, dtype=b["ref_space_uid"].dtype)])
+            b["atom_id_to_token_id"] = torch.cat([b["atom_id_to_token_id"],
+                                                  torch.full((pa,), T, device=dev, dtype=b["atom_id_to_token_id"].dtype)])
+            chunk_pad = torch.zeros(pt, device=dev, dtype=b["token_id_to_chunk_sizes"].dtype)
+            if pt:
+                chunk_pad[0] = pa
+            b["token_id_to_chunk_sizes"] = torch.cat([b["token_id_to_chunk_sizes"], chunk_pad])
+            for k in ("target_feat", "key_res_feat", "pocket_res_feat", "is_ligand"):
+                pad(k, {0: pt})
+            for k in ("token_bonds_feature", "rel_tok_feat", "templ_feat", "z_mask"):
+                pad(k, {0: pt, 1: pt})
+            pad("msa_feat", {1: pt})
+            for k in ("asym_id", "sym_id", "entity_id"):
+                b[k] = torch.cat([b[k], (b[k].max() + 1).expand(pt).to(b[k].dtype)])
+            b["residue_index"] = torch.cat([b["residue_index"], torch.zeros(pt, device=dev, dtype=b["residue_index"].dtype)])
+        chunk = b["token_id_to_chunk_sizes"]
+        ts = torch.zeros(chunk.shape[0] + 1, dtype=torch.int32, device=chunk.device)
+        ts[1:] = torch.cumsum(chunk, 0).to(torch.int32)
+        b["_tok_start"] = ts
         for k in ("ref_feat", "ref_pos", "a_mask", "ap_mask", "target_feat", "key_res_feat", "pocket_res_feat",
-                  "token_bonds_feature", "rel_tok_feat", "msa_feat", "templ_feat", "z_mask", "x_gt", "is_ligand"):
-            v = batch[k]
+                  "token_bonds_feature", "rel_tok_feat", "msa_feat", "templ_feat", "z_mask", "x_gt", "is_ligand", "t_mask"):
+            v = b[k]
             if v.dtype != torch.float32 or not v.is_contiguous():
-                batch = dict(batch)
-                batch[k] = v.float().contiguous()
-        return batch
+                b[k] = v.float().contiguous()
+        for k, dt in (("ref_space_uid", torch.int64), ("atom_id_to_token_id", torch.int64), ("residue_index", torch.int64),
+                      ("asym_id", torch.int32), ("sym_id", torch.int32), ("entity_id", torch.int32)):
+            if b[k].dtype != dt or not b[k].is_contiguous():
+                b[k] = b[k].to(dt).contiguous()
+        return b
 
     # ------------------------------------------------------------------ reference API
     def karras_noise_schedule(self, num_steps=200, sigma_data=16, s_max=160, s_min=4 * 10e-4, p=7):
@@ -163,7 +205,8 @@ class PhysDock(nn.Module):
         L = ops._lib.init()
         ws = eng.ws
         B = num_sample
-        A = batch["ref_pos"].shape[0]
+        A = batch["ref_pos"].shape[0]            # padded atom count
+        A_real = batch["_A_real"]
         sp = ops.stream()
 
         if ref_mol is not None:
@@ -206,12 +249,12 @@ class PhysDock(nn.Module):
         x_proj = ws.get("x_proj", B, A, 3)
         n_noisy = sum(p["noisy"] for p in plan)
         if noise is not None:
-            n_init = ws.get("n_init", B, A, 3); n_init.copy_(noise["init"])
+            n_init = ws.get("n_init", B, A, 3, zero=True); n_init[:, :A_real].copy_(noise["init"])
             n_rot = ws.get("n_rot", steps, 4, B); n_rot.copy_(noise["rot_u"])
             n_tr = ws.get("n_trans", steps, B, 3); n_tr.copy_(noise["trans"])
-            n_dif = ws.get("n_diffuse", max(n_noisy, 1), B, A, 3)
+            n_dif = ws.get("n_diffuse", max(n_noisy, 1), B, A, 3, zero=True)
             if n_noisy:
-                n_dif[:n_noisy].copy_(noise["diffuse"])
+                n_dif[:n_noisy, :, :A_real].copy_(noise["diffuse"])
             seed_buf = None
         else:
             seed_buf = ws.get("seed", 1, dtype=torch.int64)
@@ -269,7 +312,7 @@ class PhysDock(nn.Module):
             ops.check(L.pd_graph_launch(g["exec"], sp), "graph_launch")
         else:
             run_loop()
-        out = x_a.clone()
+        out = x_a[:, :A_real].clone()
         if return_conditioning:
             return out, (a, ap, s, z)
         return out
@@ -285,6 +328,7 @@ class PhysDock(nn.Module):
         ws = eng.ws
         B = self.num_augmentation_sample
         A, T = batch["ref_pos"].shape[0], batch["target_feat"].shape[0]
+        A_real, T_real = batch["_A_real"], batch["_T_real"]
         sd = float(self.sigma_data)
         a, ap, s, z = eng.conditioning(batch)
         # augmentation_diffuse (model.py:87-97): per-sample noise levels; RNG on the host generator
@@ -303,8 +347,8 @@ class PhysDock(nn.Module):
         prep = eng.prepare_dit(a, ap, s, z, batch, tau)
         x_den = ws.get("fw_xden", B, A, 3)
         eng.af3_dit(batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=True)
-        pd = eng.lin(z, "linear_distogram", T * T).reshape(T, T, -1)
-        return {"x_denoised": x_den.clone(), "x_hat": x_hat.clone(), "t_hat": t_hat,
+        pd = eng.lin(z, "linear_distogram", T * T).reshape(T, T, -1)[:T_real, :T_real]
+        return {"x_denoised": x_den[:, :A_real].clone(), "x_hat": x_hat[:, :A_real].clone(), "t_hat": t_hat,
                 "p_distogram": pd + pd.transpose(0, 1)}
 
 

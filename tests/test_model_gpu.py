@@ -130,3 +130,44 @@ def test_philox_mode_is_seeded_and_shard_invariant(small):
     hi = model.sample_diffusion(dbatch, num_sample=2, seed=7, sample_offset=2, **kw)
     assert rmsd(torch.cat([lo, hi]).cpu(), full.cpu()) < 1e-4
     assert torch.isfinite(full).all()
+
+
+def test_ragged_sizes_are_padded_with_masked_entries():
+    """un-padded real systems (T, A not multiples of 4): masked padding at the boundary, same poses as the oracle"""
+    import physdock_oracle as orc
+    from physdock_amd import PhysDock, param_shapes, seeded_state_dict, small_config
+    from physdock_amd.synthetic import make_batch
+    cfg = small_config()
+    P = seeded_state_dict(param_shapes(cfg), seed=0)
+    batch = make_batch(17, 5, 6, 8, seed=2)                 # T = 23, A = 91
+    assert batch["target_feat"].shape[0] == 23 and batch["ref_pos"].shape[0] == 91
+    model = PhysDock(cfg); model.load_state_dict(P); model = model.cuda().eval()
+    B, steps, A = 2, 8, 91
+    g = torch.Generator().manual_seed(4)
+    n_noisy = int((orc.karras_noise_schedule(steps, p=1000)[:-1] > 1.0).sum())
+    noise = {"init": torch.randn(B, A, 3, generator=g), "rot_u": torch.rand(steps, 4, B, generator=g),
+             "trans": torch.randn(steps, B, 3, generator=g), "diffuse": torch.randn(n_noisy, B, A, 3, generator=g)}
+    kw = dict(num_sample=B, steps=steps, karras_noise_schedule_power=1000, align_ref_pos=True)
+    ref = orc.sample_diffusion(P, batch, noise, **kw)
+    x = model.sample_diffusion(to_dev(batch), noise=noise, **kw)
+    assert x.shape == (B, A, 3)
+    assert rmsd(x.cpu(), ref) < 1e-3
+
+
+def test_forward_api(small):
+    """training-time forward (reference model.py:99-115): keys, shapes, distogram logits vs the oracle"""
+    import physdock_oracle as orc
+    model, cfg, P, batch, dbatch = small
+    out = model(dbatch)
+    T, A, Bn = batch["target_feat"].shape[0], batch["ref_pos"].shape[0], cfg.model.num_augmentation_sample
+    assert set(out) == {"x_denoised", "x_hat", "t_hat", "p_distogram"}
+    assert out["x_denoised"].shape == (Bn, A, 3) and out["x_hat"].shape == (Bn, A, 3) and out["t_hat"].shape == (Bn,)
+    assert torch.isfinite(out["x_denoised"]).all()
+    dc = cfg.model.diffusion_conditioning
+    a, ap, s, z = orc.diffusion_conditioning(P, batch, dc.inf, dc.eps)
+    pdg = orc.linear(P, "linear_distogram", z)
+    pdg = pdg + pdg.transpose(-2, -3)
+    assert float((out["p_distogram"].cpu() - pdg).abs().max()) < 2e-4 * float(pdg.abs().max())
+    # the denoiser on the returned (x_hat, t_hat) reproduces x_denoised (per-sample noise levels)
+    xd = orc.af3_dit(P, batch, out["x_hat"].cpu(), out["t_hat"].cpu(), a, ap, s, z)
+    assert float((out["x_denoised"].cpu() - xd).abs().max()) < 5e-4 * float(xd.abs().max())
