@@ -161,7 +161,7 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = world > 1
+    dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # launched by torch.distributed.run
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -22,6 +22,7 @@
 //   epilogue  : accumulators are parked in LDS (re-using the stage buffers) and re-read
 //               row-major, so bias / gate / residual / output traffic is 16-byte coalesced and
 //               the epilogue is one compact rolled loop whatever the fusion flags.
+#include <stdlib.h>
 #include "common.h"
 #include "physdock_hip.h"
 
@@ -484,6 +485,10 @@ static int select_variant(pd_gemm_args& p, int& cfg, bool& akm, bool& wkm, bool&
     else if (p.N <= 64) cfg = 1;
     else cfg = 0;
     if (pro == 2 && cfg != 0 && cfg != 3) cfg = 0;
+    if (const char* f = getenv("PD_GEMM_CFG")) {      // tuning override: force a tile configuration where legal
+        const int c = atoi(f);
+        if (c >= 0 && c <= 3 && !akm && !wkm && !p.glu && vec && pro != 2) cfg = c;
+    }
     return cfg * 100 + (akm ? (wkm ? 2 : 1) : 0) * 10 + pro + (vec ? 0 : 1000);
 }
 

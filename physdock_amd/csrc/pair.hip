@@ -95,19 +95,33 @@ __global__ __launch_bounds__(256) void pair_init_z_kernel(const float* __restric
 }
 
 // out[b,t,:] = sum_{atoms of t} u[b,atom,:] / (n_t + 1e-3) [+ add[t,:]]     (transformers.py:205-212)
+// one thread per (b, t, 16-byte channel chunk); loads are issued 8 atoms at a time (clamped row, zero
+// weight beyond the token) so every lane keeps 8 independent 16-byte loads in flight.
 __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restrict__ u, const int* __restrict__ tok_start,
                                                           const float* __restrict__ add, float* __restrict__ out,
-                                                          int A, int T, int C) {
-    const int t = blockIdx.x, b = blockIdx.y;
+                                                          int A, int T, int C, long long n4) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    const int c4 = idx % (C / 4);
+    const long long bt = idx / (C / 4);
+    const int t = bt % T;
+    const long long b = bt / T;
     const int s = tok_start[t], e = tok_start[t + 1];
-    const float inv = 1.f / ((float)(e - s) + 1e-3f);
-    for (int c4 = threadIdx.x; c4 < C / 4; c4 += blockDim.x) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int a = s; a < e; ++a) acc += *reinterpret_cast<const f32x4*>(u + ((long long)b * A + a) * C + c4 * 4);
-        acc *= inv;
-        if (add) acc += *reinterpret_cast<const f32x4*>(add + (long long)t * C + c4 * 4);
-        *reinterpret_cast<f32x4*>(out + ((long long)b * T + t) * C + c4 * 4) = acc;
+    const float* base = u + (b * A) * C + c4 * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int a0 = s; a0 < e; a0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int a = a0 + k < e ? a0 + k : e - 1;
+            v[k] = *reinterpret_cast<const f32x4*>(base + (long long)a * C);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (a0 + k < e) acc += v[k];
     }
+    acc *= 1.f / ((float)(e - s) + 1e-3f);
+    if (add) acc += *reinterpret_cast<const f32x4*>(add + (long long)t * C + c4 * 4);
+    *reinterpret_cast<f32x4*>(out + bt * C + c4 * 4) = acc;
 }
 
 // ba[b,l,:] += us[b, a2t[l], :]                                            (transformers.py:214-216)
@@ -194,8 +208,9 @@ PD_EXPORT int pd_pair_init_z(const float* si, const float* sj, const float* WT, 
 PD_EXPORT int pd_segment_pool(const float* u, const int* tok_start, const float* add, float* out, int B, int A, int T,
                               int C, void* stream) {
     if (!u || !tok_start || !out || C % 4) return PD_ERR_ARG;
-    const int threads = C / 4 < 256 ? ((C / 4 + 63) / 64) * 64 : 256;
-    hipLaunchKernelGGL(segment_pool_kernel, dim3(T, B), dim3(threads), 0, (hipStream_t)stream, u, tok_start, add, out, A, T, C);
+    const long long n4 = (long long)B * T * (C / 4);
+    hipLaunchKernelGGL(segment_pool_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, tok_start,
+                       add, out, A, T, C, n4);
     return pd_check_launch();
 }
 
