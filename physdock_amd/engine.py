@@ -53,12 +53,17 @@ class Engine:
         self.cfg = config
         self.device = device
         self.ws = Workspace(device)
+        self.lane = 0              # sample lane (concurrent stream) whose private DiT scratch is in use
         dc = config.model.diffusion_conditioning
         self.inf, self.eps = float(dc.inf), float(dc.eps)
 
     # ------------------------------------------------------------------ small helpers
+    def lws(self, name, *shape):
+        """lane-private scratch: concurrent sample lanes never share a DiT intermediate"""
+        return self.ws.get(f"{name}@{self.lane}", *shape)
+
     def stats(self, x, M, C, mode, eps, name="stats", kmajor=False, ldx=None):
-        st = self.ws.get(name, M, 2)
+        st = self.ws.get(f"{name}@{self.lane}", M, 2)
         ops.rowstats(x, st, M, C, mode=mode, eps=eps, kmajor=kmajor, ldx=ldx)
         return st
 
@@ -356,11 +361,11 @@ class Engine:
         grp = dict(pro_rows_per_group=N, pro_gstride=tab_ld) if per_sample else {}
         mgrp = dict(mul_rows_per_group=N if per_sample else rows, mul_gstride=tab_ld if per_sample else 0)
         st = self.stats(x, rows, C, LN, eps)
-        qkv = self.ws.get("dit_qkv", rows, 3 * C)
+        qkv = self.lws("dit_qkv", rows, 3 * C)
         ops.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
                  pro_w=off(tab, tab_off + C), hn_w=P.headnorm(prefix + ".attention"), hn_cols=2 * C, hn_split=C,
                  hn_eps=eps, **grp)
-        o = self.ws.get("dit_o", rows, C)
+        o = self.lws("dit_o", rows, C)
         st3 = (N * 3 * C, 3 * C)
         ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, nq=N, nk=nk, nbatch=B, nheads=H,
                       q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias)
@@ -368,7 +373,7 @@ class Engine:
         ops.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)
         st = self.stats(x, rows, C, LN, eps)
         W13, hidden = P.glu(prefix + ".transition.feed_forward")
-        h = self.ws.get("dit_h", rows, hidden)
+        h = self.lws("dit_h", rows, hidden)
         o2 = tab_off + 3 * C
         ops.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, o2), pro_w=off(tab, o2 + C), glu=1, **grp)
         W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
@@ -385,7 +390,7 @@ class Engine:
         Ha, Hs = Ca // 32, Cs // 32
         L = ops._lib.init()
         sp = ops.stream()
-        ba = ws.get("dit_ba", B * A, Ca)
+        ba = self.lws("dit_ba", B * A, Ca)
         cin_b = ops.ptr(scal["c_in"]) if per_sample else None
         ops.check(L.pd_precond(ops.ptr(x_hat), 0.0 if per_sample else scal["c_in"], cin_b, ops.ptr(P["dit.linear_x.weight"]),
                                ops.ptr(P["dit.linear_x.bias"]), ops.ptr(a), ops.ptr(ba), B, A, Ca, sp), "precond")
@@ -397,14 +402,14 @@ class Engine:
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_encoder.blocks.{b}", ba, B, A, Ca, off(prep["atom_bias"], b * fa_stride),
                            tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar)
-        u = ws.get("dit_u", B * A, Cs)
+        u = self.lws("dit_u", B * A, Cs)
         self.lin(ba, "dit.linear_downscale", B * A, out=u, act=ACT_SILU)
-        bs = ws.get("dit_bs", B * T, Cs)
+        bs = self.lws("dit_bs", B * T, Cs)
         ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs), B, A, T, Cs, sp), "pool")
         for b in range(nb_t):
             self.dit_block(f"dit.token_dit.blocks.{b}", bs, B, T, Cs, off(prep["token_bias"], b * ft_stride),
                            tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr)
-        us = ws.get("dit_us", B * T, Ca)
+        us = self.lws("dit_us", B * T, Ca)
         self.lin(bs, "dit.linear_upscale", B * T, out=us)
         ops.check(L.pd_unpool_add(ops.ptr(ba), ops.ptr(us), ops.ptr(batch["atom_id_to_token_id"]), B, A, T, Ca, sp), "unpool")
         for b in range(nb_a):

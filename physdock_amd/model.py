@@ -11,7 +11,8 @@ without the built library or without a GPU the calls raise.
 Extensions (keyword-only, not in the reference): ``noise=`` injects pre-drawn random
 numbers (parity mode; same draw order as the reference, see oracle), ``seed=`` /
 ``sample_offset=`` select the on-device Philox streams (perf / multi-GPU mode),
-``use_graph=`` replays the step loop from a hipGraph.
+``use_graph=`` replays the step loop from a hipGraph, ``lanes=`` sets the number of concurrent sample lanes
+(independent sample groups on forked HIP streams; experimental, default 1).
 """
 from __future__ import annotations
 
@@ -57,6 +58,7 @@ class PhysDock(nn.Module):
         self._packed: Optional[PackedWeights] = None
         self._engine: Optional[Engine] = None
         self._graphs = {}
+        self._side_streams = []
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
     # ------------------------------------------------------------------ plumbing
@@ -195,6 +197,7 @@ class PhysDock(nn.Module):
             seed: int = 0,
             sample_offset: int = 0,
             use_graph: bool = True,
+            lanes: int = 0,
             conditioning=None,
             return_conditioning: bool = False,
     ) -> torch.Tensor:
@@ -242,58 +245,93 @@ class PhysDock(nn.Module):
                     ref_dist = ws.get("ref_dist", n_conf, n_lig, n_lig)
                     ops.check(L.pd_pose_dist(ops.ptr(poses), ops.ptr(ref_dist), n_conf, n_lig, sp), "pose_dist")
 
-        # ---- random numbers: parity mode copies the caller's draws into fixed buffers
+        # ---- sample lanes: the B samples are split into independent groups that run the whole loop on their own
+        #      HIP streams (forked branches of one hipGraph).  Samples never interact (model.py:211-281), and two
+        #      de-phased kernel streams fill each other's launch / epilogue ramps.
+        n_lanes = max(1, min(int(lanes) if lanes else 1, B))   # measured on MI355X: forked lanes do not overlap better than one stream
+        bounds = [(h * B) // n_lanes for h in range(n_lanes + 1)]
+        lane_rng = [(bounds[h], bounds[h + 1] - bounds[h]) for h in range(n_lanes)]
+        while len(self._side_streams) < n_lanes - 1:
+            self._side_streams.append(torch.cuda.Stream(device=device))
+
+        # ---- random numbers: parity mode copies the caller's draws into fixed (per-lane contiguous) buffers
         x_a = ws.get("x_a", B, A, 3)
         x_hat = ws.get("x_hat", B, A, 3)
         x_den = ws.get("x_den", B, A, 3)
         x_proj = ws.get("x_proj", B, A, 3)
         n_noisy = sum(p["noisy"] for p in plan)
+        lane_noise = []
         if noise is not None:
-            n_init = ws.get("n_init", B, A, 3, zero=True); n_init[:, :A_real].copy_(noise["init"])
-            n_rot = ws.get("n_rot", steps, 4, B); n_rot.copy_(noise["rot_u"])
-            n_tr = ws.get("n_trans", steps, B, 3); n_tr.copy_(noise["trans"])
-            n_dif = ws.get("n_diffuse", max(n_noisy, 1), B, A, 3, zero=True)
-            if n_noisy:
-                n_dif[:n_noisy, :, :A_real].copy_(noise["diffuse"])
+            for h, (b0, Bh) in enumerate(lane_rng):
+                n_init = ws.get(f"n_init@{h}", Bh, A, 3, zero=True); n_init[:, :A_real].copy_(noise["init"][b0:b0 + Bh])
+                n_rot = ws.get(f"n_rot@{h}", steps, 4, Bh); n_rot.copy_(noise["rot_u"][:, :, b0:b0 + Bh])
+                n_tr = ws.get(f"n_trans@{h}", steps, Bh, 3); n_tr.copy_(noise["trans"][:, b0:b0 + Bh])
+                n_dif = ws.get(f"n_diffuse@{h}", max(n_noisy, 1), Bh, A, 3, zero=True)
+                if n_noisy:
+                    n_dif[:n_noisy, :, :A_real].copy_(noise["diffuse"][:, b0:b0 + Bh])
+                lane_noise.append((n_init, n_rot, n_tr, n_dif))
             seed_buf = None
         else:
             seed_buf = ws.get("seed", 1, dtype=torch.int64)
             seed_buf.fill_(int(seed))
 
-        def run_loop():
-            """the hot loop (reference model.py:211-281): no host sync, no allocation -> graph-capturable"""
+        def lane_step(h, i, p, k_noisy):
+            """one reverse-diffusion step of lane h (reference model.py:212-281) on the current stream"""
+            b0, Bh = lane_rng[h]
             sp_ = ops.stream()
-            if noise is None:
-                ops.check(L.pd_init_noise(ops.ptr(x_a), ops.ptr(seed_buf), sample_offset, float(sig[0]), B, A, sp_), "init_noise")
-            src, x_scale = (n_init, float(sig[0])) if noise is not None else (x_a, 1.0)
+            xa, xh, xd, xp = x_a[b0:b0 + Bh], x_hat[b0:b0 + Bh], x_den[b0:b0 + Bh], x_proj[b0:b0 + Bh]
+            if noise is not None:
+                n_init, n_rot, n_tr, n_dif = lane_noise[h]
+                ru, tr = off(n_rot, i * 4 * Bh), off(n_tr, i * Bh * 3)
+                nz = off(n_dif, k_noisy * Bh * A * 3) if p["noisy"] else None
+                sd_ptr = None
+                src, x_scale = (n_init, float(sig[0])) if i == 0 else (xa, 1.0)
+            else:
+                ru = tr = nz = None
+                sd_ptr = ops.ptr(seed_buf)
+                src, x_scale = xa, 1.0
+                if i == 0:
+                    ops.check(L.pd_init_noise(ops.ptr(xa), sd_ptr, sample_offset + b0, float(sig[0]), Bh, A, sp_), "init_noise")
+            ops.check(L.pd_augment(ops.ptr(src), x_scale, ops.ptr(batch["a_mask"]), ru, tr, nz, float(noise_scale_lambda),
+                                   p["sdev"], sd_ptr, i, sample_offset + b0, ops.ptr(xh), Bh, A, sp_), "augment")
+            eng.lane = h
+            eng.af3_dit(batch, xh, xd, a, s, prep, Bh, p, row=i)
+            if p["align"]:
+                br = bref[b0:b0 + Bh]
+                if poses is not None:
+                    ops.check(L.pd_template_match(ops.ptr(xd), ops.ptr(lig_idx), ops.ptr(ref_dist), ops.ptr(poses),
+                                                  ops.ptr(br), None, None, Bh, A, n_lig, n_conf, sp_), "template_match")
+                ops.check(L.pd_kabsch_align(ops.ptr(xd), ops.ptr(batch["a_mask"]), ops.ptr(br), A * 3, ops.ptr(lig_w),
+                                            ops.ptr(xp), Bh, A, sp_), "kabsch")
+                ops.check(L.pd_euler(ops.ptr(xh), ops.ptr(xd), ops.ptr(xp), ops.ptr(lig_w), p["t_hat"], p["eta"],
+                                     p["dt"], ops.ptr(xa), Bh, A, sp_), "euler")
+            else:
+                ops.check(L.pd_euler(ops.ptr(xh), ops.ptr(xd), None, None, p["t_hat"], p["eta"], p["dt"],
+                                     ops.ptr(xa), Bh, A, sp_), "euler")
+
+        def run_loop():
+            """the hot loop: no host sync, no allocation -> capturable; lanes fork from / join to the current stream"""
+            main = torch.cuda.current_stream()
+            streams = [main] + self._side_streams[:n_lanes - 1]
+            if n_lanes > 1:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                for st_ in streams[1:]:
+                    st_.wait_event(ev)
             k_noisy = 0
             for i, p in enumerate(plan):
-                if noise is not None:
-                    ru, tr = off(n_rot, i * 4 * B), off(n_tr, i * B * 3)
-                    nz = off(n_dif, k_noisy * B * A * 3) if p["noisy"] else None
-                    sd_ptr = None
-                else:
-                    ru = tr = nz = None
-                    sd_ptr = ops.ptr(seed_buf)
-                ops.check(L.pd_augment(ops.ptr(src), x_scale, ops.ptr(batch["a_mask"]), ru, tr, nz, float(noise_scale_lambda),
-                                       p["sdev"], sd_ptr, i, sample_offset, ops.ptr(x_hat), B, A, sp_), "augment")
+                for h in range(n_lanes):
+                    with torch.cuda.stream(streams[h]):
+                        lane_step(h, i, p, k_noisy)
                 k_noisy += int(p["noisy"])
-                eng.af3_dit(batch, x_hat, x_den, a, s, prep, B, p, row=i)
-                if p["align"]:
-                    if poses is not None:
-                        ops.check(L.pd_template_match(ops.ptr(x_den), ops.ptr(lig_idx), ops.ptr(ref_dist), ops.ptr(poses),
-                                                      ops.ptr(bref), None, None, B, A, n_lig, n_conf, sp_), "template_match")
-                    ops.check(L.pd_kabsch_align(ops.ptr(x_den), ops.ptr(batch["a_mask"]), ops.ptr(bref), A * 3, ops.ptr(lig_w),
-                                                ops.ptr(x_proj), B, A, sp_), "kabsch")
-                    ops.check(L.pd_euler(ops.ptr(x_hat), ops.ptr(x_den), ops.ptr(x_proj), ops.ptr(lig_w), p["t_hat"], p["eta"],
-                                         p["dt"], ops.ptr(x_a), B, A, sp_), "euler")
-                else:
-                    ops.check(L.pd_euler(ops.ptr(x_hat), ops.ptr(x_den), None, None, p["t_hat"], p["eta"], p["dt"],
-                                         ops.ptr(x_a), B, A, sp_), "euler")
-                src, x_scale = x_a, 1.0
+            for st_ in streams[1:]:
+                ev = torch.cuda.Event()
+                ev.record(st_)
+                main.wait_event(ev)
+            eng.lane = 0
 
         if use_graph:
-            key = (B, A, batch["target_feat"].shape[0], steps, noise is not None, poses is not None and n_conf,
+            key = (B, A, batch["target_feat"].shape[0], steps, noise is not None, poses is not None and n_conf, n_lanes,
                    tuple((p["t_hat"], p["align"], p["eta"]) for p in plan), float(noise_scale_lambda), sample_offset)
             g = self._graphs.get(key)
             if g is None:

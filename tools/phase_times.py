@@ -31,7 +31,10 @@ t_prep, prep = timed(lambda: eng.prepare_dit(*cond, pb, tau))
 print(f"prepare_dit (hoisted biases + AdaLN tables) {t_prep*1e3:.2f} ms")
 for B in [b for b in Bs if b > 0]:
     kw = dict(num_sample=B, steps=40, karras_noise_schedule_power=1000, align_ref_pos=False, conditioning=cond)
-    t_g, _ = timed(lambda: model.sample_diffusion(dbatch, use_graph=True, **kw))
-    t_e, _ = timed(lambda: model.sample_diffusion(dbatch, use_graph=False, **kw))
-    print(f"B={B}: 40-step loop (+prep) graph {t_g*1e3:.1f} ms  eager {t_e*1e3:.1f} ms  -> {(t_g - t_prep)/40*1e3:.2f} ms/step; "
-          f"full call {1e3*(t_g + t_trunk):.0f} ms = {B/(t_g + t_trunk):.1f} poses/s  (workspace {eng.ws.nbytes()/2**30:.2f} GiB)")
+    for lanes in (1, 2, 4):
+        if lanes > B:
+            continue
+        t_g, _ = timed(lambda: model.sample_diffusion(dbatch, use_graph=True, lanes=lanes, **kw))
+        t_e, _ = timed(lambda: model.sample_diffusion(dbatch, use_graph=False, lanes=lanes, **kw))
+        print(f"B={B} lanes={lanes}: 40-step loop (+prep) graph {t_g*1e3:.1f} ms  eager {t_e*1e3:.1f} ms  -> {(t_g - t_prep)/40*1e3:.2f} ms/step; "
+              f"full call {1e3*(t_g + t_trunk):.0f} ms = {B/(t_g + t_trunk):.1f} poses/s  (workspace {eng.ws.nbytes()/2**30:.2f} GiB)")
