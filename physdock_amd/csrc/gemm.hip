@@ -77,8 +77,9 @@ struct TileLoader {
             }
         }
     }
-    // zero the out-of-range elements (rows >= rows_total, k >= K)
+    // zero the out-of-range elements (rows >= rows_total, k >= K); interior tiles skip it (block-uniform test)
     __device__ __forceinline__ void mask(int r0, int rows, int k0, int K, int tid) {
+        if (r0 + R <= rows && k0 + BK <= K) return;
         if constexpr (!KM) {
             const int kc = k0 + (tid & 7) * 4;
 #pragma unroll
@@ -279,67 +280,97 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     const float* resp = p.res ? p.res + (long long)bz * p.sRes : nullptr;
 
     if (p.out_mode == PD_OUT_ROWMAJOR) {
+        // U row-chunks per trip: all gate / residual loads of a trip are issued before the first store, so the
+        // epilogue keeps U independent 16-byte loads in flight per lane instead of one dependent round trip per row.
+        constexpr int U = 4;
         const int cpr = BN_out / 4;
+        const int total = BM * cpr;            // multiple of NT*U for every tile configuration
 #pragma unroll 1
-        for (int idx = tid; idx < BM * cpr; idx += NT) {
-            const int row = idx / cpr, c = idx - row * cpr;
-            const int m = bm0 + row, n = bn_out0 + c * 4;
-            const bool ok = m < p.M && n < N_out;
-            const int pc = glu ? ((c * 4) >> 5) * 64 + ((c * 4) & 31) : c * 4;    // packed column in Cs / bias
-            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + pc);
-            if (p.rowscale_acc) v *= (m < p.M ? p.rowscale_acc[(long long)bz * p.M + m] : 0.f);
-            if (biasp) {
+        for (int base = tid; base < total; base += NT * U) {
+            f32x4 v[U], mulv[U], resv[U];
+            int mrow[U], ncol[U];
+            bool ok[U], full[U];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (bn0 + pc + e < p.N) v[e] += biasp[bn0 + pc + e];
-            }
-            if (p.hn_w && bn0 + pc < p.hn_cols) {   // per-head RMSNorm: 8 consecutive lanes own one 32-wide head
-                float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-                ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
-                const float rs = rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps);
-                const float* hw = p.hn_w + ((bn0 + pc) / p.hn_split) * 32 + ((bn0 + pc) & 31);
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * NT;
+                const int row = idx / cpr, c = idx - row * cpr;
+                const int m = bm0 + row, n = bn_out0 + c * 4;
+                mrow[u] = m; ncol[u] = n;
+                ok[u] = idx < total && m < p.M && n < N_out;
+                full[u] = p.vecY && n + 3 < N_out;
+                mulv[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+                resv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok[u]) {
+                    if (p.mul) {
+                        const float* mp = p.mul + (p.mul_rows_per_group > 0
+                                                       ? (long long)(m / p.mul_rows_per_group) * p.mul_gstride
+                                                       : (long long)m * p.ldmul) + n;
+                        if (full[u]) mulv[u] = *reinterpret_cast<const f32x4*>(mp);
+                        else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * rs * hw[e];
+                            for (int e = 0; e < 4; ++e) if (n + e < N_out) mulv[u][e] = mp[e];
+                        }
+                    }
+                    if (resp) {
+                        const int mr = p.res_row_mod > 0 ? m % p.res_row_mod : m;
+                        const float* rp = resp + (long long)mr * p.ldres + n;
+                        if (full[u]) resv[u] = *reinterpret_cast<const f32x4*>(rp);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) if (n + e < N_out) resv[u][e] = rp[e];
+                        }
+                    }
+                }
             }
-            if (glu) {
-                f32x4 b2 = *reinterpret_cast<const f32x4*>(Cs + row * LDC + pc + 32);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * NT;
+                const int row = idx / cpr, c = idx - row * cpr;
+                const int m = mrow[u];
+                const int pc = glu ? ((c * 4) >> 5) * 64 + ((c * 4) & 31) : c * 4;    // packed column in Cs / bias
+                f32x4 x = *reinterpret_cast<const f32x4*>(Cs + row * LDC + pc);
+                if (p.rowscale_acc) x *= (m < p.M ? p.rowscale_acc[(long long)bz * p.M + m] : 0.f);
                 if (biasp) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (bn0 + pc + 32 + e < p.N) b2[e] += biasp[bn0 + pc + 32 + e];
+                    for (int e = 0; e < 4; ++e) if (bn0 + pc + e < p.N) x[e] += biasp[bn0 + pc + e];
                 }
+                if (p.hn_w && bn0 + pc < p.hn_cols) {   // per-head RMSNorm: 8 consecutive lanes own one 32-wide head
+                    float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+                    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+                    const float rs = rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps);
+                    const float* hw = p.hn_w + ((bn0 + pc) / p.hn_split) * 32 + ((bn0 + pc) & 31);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (glu == 1) ? pd_silu(v[e]) * b2[e] : v[e] * pd_sigmoid(b2[e]);
-            } else {
-                pd_act4(v, p.act);
+                    for (int e = 0; e < 4; ++e) x[e] = x[e] * rs * hw[e];
+                }
+                if (glu) {
+                    f32x4 b2 = *reinterpret_cast<const f32x4*>(Cs + row * LDC + pc + 32);
+                    if (biasp) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (bn0 + pc + 32 + e < p.N) b2[e] += biasp[bn0 + pc + 32 + e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = (glu == 1) ? pd_silu(x[e]) * b2[e] : x[e] * pd_sigmoid(b2[e]);
+                } else {
+                    pd_act4(x, p.act);
+                }
+                v[u] = x;
             }
-            if (!ok) continue;
-            if (p.rowscale) v *= p.rowscale[m];
-            if (p.maskadd && p.maskadd[m] == 0.f) v += p.maskval;
-            const bool full = p.vecY && n + 3 < N_out;
-            if (p.mul) {
-                const float* mp = p.mul + (p.mul_rows_per_group > 0
-                                               ? (long long)(m / p.mul_rows_per_group) * p.mul_gstride
-                                               : (long long)m * p.ldmul) + n;
-                if (full) v *= *reinterpret_cast<const f32x4*>(mp);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const int m = mrow[u], n = ncol[u];
+                f32x4 x = v[u];
+                if (p.rowscale) x *= p.rowscale[m];
+                if (p.maskadd && p.maskadd[m] == 0.f) x += p.maskval;
+                x *= mulv[u];
+                x *= p.out_scale;
+                x += resv[u];
+                float* yp = Y + (long long)m * p.ldy + n;
+                if (full[u]) *reinterpret_cast<f32x4*>(yp) = x;
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < N_out) v[e] *= mp[e];
+                    for (int e = 0; e < 4; ++e) if (n + e < N_out) yp[e] = x[e];
                 }
-            }
-            v *= p.out_scale;
-            if (resp) {
-                const int mr = p.res_row_mod > 0 ? m % p.res_row_mod : m;
-                const float* rp = resp + (long long)mr * p.ldres + n;
-                if (full) v += *reinterpret_cast<const f32x4*>(rp);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < N_out) v[e] += rp[e];
-                }
-            }
-            float* yp = Y + (long long)m * p.ldy + n;
-            if (full) *reinterpret_cast<f32x4*>(yp) = v;
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (n + e < N_out) yp[e] = v[e];
             }
         }
     } else if (p.out_mode == PD_OUT_TRANSPOSED) {
