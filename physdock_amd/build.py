@@ -22,6 +22,11 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+#: per-source extra flags.  attention.hip: the SLP vectoriser packs the softmax's f32 adds/muls into v_pk_*_f32,
+#: which issue slower beside MFMAs on gfx950 (cdna guide: packed f32 VALU is an anti-lever next to MFMA).
+EXTRA_FLAGS = {}     # (-fno-slp-vectorize on attention.hip measured neutral)
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
@@ -34,6 +39,8 @@ def build(force=False, verbose=True):
         objs.append(obj)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
+        if os.environ.get("PD_NO_EXTRA_FLAGS") != "1":
+            cmd[1:1] = EXTRA_FLAGS.get(os.path.basename(src), [])
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, pr in procs:
         out, _ = pr.communicate()

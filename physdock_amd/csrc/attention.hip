@@ -19,6 +19,7 @@
 //     batch index; batch is the fastest grid dimension so the blocks that share a bias tile
 //     run together and the tile is served from L2 / Infinity Cache (the step- and
 //     sample-invariant biases of the DiT are hoisted out of the loop entirely).
+#include <type_traits>
 #include "common.h"
 #include "physdock_hip.h"
 
@@ -94,6 +95,61 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
     sstore(0);
     __syncthreads();
 
+    // one 32-key sub-tile: S^T = K.Q^T (+bias), online softmax, O^T += V^T.P^T.  RAGGED is only instantiated for the
+    // single partial tile at the end of the key range, so the steady-state loop carries no masking code at all.
+    auto subtile = [&](auto ragged_tag, int cur, int sub, int kt32) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        f32x4 bf[4];
+        if (bias_wave) {   // bias tile first: its latency hides under the 16 QK^T MFMAs
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bf[g] = *reinterpret_cast<const f32x4*>(bias_wave + (long long)kt32 * 1024 + g * 256);
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* kbase = &sK[cur][(sub * 32 + l31) * LDKS + 4 * hh];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(kbase + 8 * t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[t][e], s, 0, 0, 0);
+        }
+        if (bias_wave) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] += bf[r >> 2][r & 3];
+        }
+        if constexpr (RAGGED) {   // padded keys drop out
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kt32 * 32 + pd_frag_row(r, hh) >= p.nk) s[r] = -INFINITY;
+        }
+        float mloc = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+            psum += s[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        const float* vbase = &sV[cur][(sub * 32 + 4 * hh) * LDVS + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float vf = vbase[((r & 3) + 8 * (r >> 2)) * LDVS];
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o, 0, 0, 0);
+        }
+    };
+    const int nfull32 = p.nk >> 5;                 // sub-tiles with all 32 keys in range
+
     for (int it = 0; it < nit; ++it) {
         const int cur = it & 1;
         if (it + 1 < nit) gload((it + 1) * KT);
@@ -101,56 +157,8 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 const int kt32 = it * 2 + sub;
-                if (kt32 * 32 >= p.nk) break;
-                // bias tile first: its latency hides under the 16 QK^T MFMAs
-                f32x4 bf[4];
-                if (bias_wave) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        bf[g] = *reinterpret_cast<const f32x4*>(bias_wave + (long long)kt32 * 1024 + g * 256);
-                }
-                f32x16 s;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = 0.f;
-                const float* kbase = &sK[cur][(sub * 32 + l31) * LDKS + 4 * hh];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f32x4 kf = *reinterpret_cast<const f32x4*>(kbase + 8 * t);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[t][e], s, 0, 0, 0);
-                }
-                if (bias_wave) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[r] += bf[r >> 2][r & 3];
-                }
-                if (kt32 * 32 + 32 > p.nk) {   // ragged last tile: padded keys drop out
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kt32 * 32 + pd_frag_row(r, hh) >= p.nk) s[r] = -INFINITY;
-                }
-                float mloc = s[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-                const float m_new = fmaxf(m_run, mloc);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                float psum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
-                    psum += s[r];
-                }
-                l_run = l_run * alpha + psum;
-                m_run = m_new;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] *= alpha;
-                const float* vbase = &sV[cur][(sub * 32 + 4 * hh) * LDVS + l31];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float vf = vbase[((r & 3) + 8 * (r >> 2)) * LDVS];
-                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o, 0, 0, 0);
-                }
+                if (kt32 < nfull32) subtile(std::false_type{}, cur, sub, kt32);
+                else if (kt32 * 32 < p.nk) subtile(std::true_type{}, cur, sub, kt32);
             }
         }
         if (it + 1 < nit) sstore(cur ^ 1);
