@@ -113,10 +113,11 @@ class LaunchTimer:
         self.ops = ops
         self.rec = {}      # kernel symbol -> [events, flops]
 
-    def _add(self, name, e0, e1, flops):
-        r = self.rec.setdefault(name, [[], 0.0])
+    def _add(self, name, e0, e1, flops, nbytes=0.0):
+        r = self.rec.setdefault(name, [[], 0.0, 0.0])
         r[0].append((e0, e1))
         r[1] += flops
+        r[2] += nbytes
 
     def __enter__(self):
         ops = self.ops
@@ -130,7 +131,10 @@ class LaunchTimer:
                                                          "true" if lay == 2 else "false", "false" if scalar else "true", pro)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); launch(); e1.record()
-            self._add(name, e0, e1, 2.0 * a.M * a.N * a.K * max(a.batch, 1))
+            nb = max(a.batch, 1)
+            n_out = a.N // 2 if a.glu else a.N
+            byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))
+            self._add(name, e0, e1, 2.0 * a.M * a.N * a.K * nb, byt)
         self._orig_attn = ops.attention
 
         def attn(*a, **k):
@@ -149,10 +153,10 @@ class LaunchTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = []
-        for name, (ev, fl) in self.rec.items():
+        for name, (ev, fl, by) in self.rec.items():
             t = sum(a.elapsed_time(b) for a, b in ev) * 1e-3
             out.append(dict(kernel=name, launches=len(ev), total_s=t, avg_launch_ms=1e3 * t / len(ev),
-                            flop_per_launch=fl / len(ev), tflops=fl / t / 1e12))
+                            flop_per_launch=fl / len(ev), tflops=fl / t / 1e12, algorithmic_bytes_per_launch=by / len(ev)))
         return sorted(out, key=lambda d: -d["total_s"])
 
 
@@ -236,10 +240,20 @@ def main():
             model.sample_diffusion(dbatch, seed=99, sample_offset=0, **kw2)
             summ = lt.summary()
         dom = summ[0]
+        traffic, traffic_src = None, None
+        pmc = os.path.join(REPO, "profiles", "r01_pmc_summary.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(pmc) and args.cfg == "cfg1" and B == 64:
+            for row in json.load(open(pmc)):
+                if row["kernel"].replace("void ", "") == dom["kernel"]:
+                    traffic = row["fetch_bytes_x2"] + row["write_bytes"]
+                    traffic_src = ("profiles/r01_pmc_summary.json: per-launch (FETCH_SIZE x2 [gfx950 wide-read correction] + "
+                                   "WRITE_SIZE) x 1024 B, separate --pmc passes of this same call; FETCH_SIZE counts L2 misses "
+                                   "incl. Infinity-Cache hits")
         out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
                            "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
-                           "flop_per_launch": dom["flop_per_launch"], "traffic": None,
+                           "flop_per_launch": dom["flop_per_launch"], "traffic": traffic,
+                           "algorithmic_bytes_per_launch": dom.get("algorithmic_bytes_per_launch"), "traffic_source": traffic_src,
                            "note": "algorithmic flops = 2*M*N*K per GEMM launch (4*B*H*Nq*Nk*32 per attention launch)"}
         out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in summ[:4]]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
