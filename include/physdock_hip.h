@@ -69,6 +69,7 @@ typedef struct pd_gemm_args {
     int T1, T2;                  /* OPM: T2 = tokens; BIASFRAG: rows m = (i,j), i<T1, j<T2   */
     int frag_transpose;          /* BIASFRAG: query = j, key = i                             */
     int vecA, vecW, vecY;        /* set by the launcher                                      */
+    void* dbg;                   /* optional phase-trace buffer (tools/gemm_trace.py); NULL in production      */
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
 /* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling) */

@@ -212,13 +212,20 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     lw.store(sW, tid);
     __syncthreads();
 
+    // optional in-kernel phase trace (debug): lane 0 of every wave of blocks < 64 stamps the shader clock
+    unsigned long long* dbg = nullptr;
+    if (p.dbg && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 64)
+        dbg = reinterpret_cast<unsigned long long*>(p.dbg) + ((long long)blockIdx.x * 4 + wave) * (5 * 64);
+#define PD_STAMP(slot) if (dbg && kt < 64) dbg[kt * 5 + slot] = __builtin_amdgcn_s_memtime()
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
+        PD_STAMP(0);
         if (more) {
             la.load(A, p.lda, bm0, p.M, (kt + 1) * BK, p.K, tid);
             lw.load(W, p.ldw, bn0, p.N, (kt + 1) * BK, p.K, tid);
         }
+        PD_STAMP(1);
         const float* a = sA + cur * A_TILE;
         const float* w = sW + cur * W_TILE;
 #pragma unroll
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fw[j][e], acc[i][j], 0, 0, 0);
         }
+        PD_STAMP(2);
         if (more) {
             transform_A((kt + 1) * BK);
             la.mask(bm0, p.M, (kt + 1) * BK, p.K, tid);
@@ -257,8 +265,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
             la.store(sA + (cur ^ 1) * A_TILE, tid);
             lw.store(sW + (cur ^ 1) * W_TILE, tid);
         }
+        PD_STAMP(3);
         __syncthreads();
+        PD_STAMP(4);
     }
+#undef PD_STAMP
 
     // ---- park the accumulators in LDS (stage buffers are free after the last barrier) ---
     float* Cs = smem;

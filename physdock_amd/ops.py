@@ -63,10 +63,15 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
     a.out_scale = out_scale
     a.res, a.ldres, a.res_row_mod, a.sRes = P(res), (ldres or n_out), res_row_mod, sRes
     a.out_mode, a.T1, a.T2, a.frag_transpose = out_mode, T1, T2, int(frag_transpose)
+    if GEMM_DBG is not None:
+        a.dbg = GEMM_DBG.data_ptr()
     if GEMM_HOOK is not None:
         return GEMM_HOOK(a, lambda: check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm"))
     check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm")
 
+
+#: optional in-kernel phase-trace buffer (int64 tensor of 64*4*5*64 entries), see tools/gemm_trace.py
+GEMM_DBG = None
 
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None
