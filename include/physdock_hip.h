@@ -146,6 +146,10 @@ int pd_kabsch_align(const float* x_pred, const float* pred_mask, const float* x_
 int pd_template_match(const float* x, const int* lig_idx, const float* ref_dist, const float* poses, float* batch_ref_pos,
                       float* eps_out, int* sel_out, int B, int A, int L, int Cn, void* stream);
 int pd_pose_dist(const float* poses, float* D, int Cn, int L, void* stream);
+/* pairwise RMSD matrix of n poses over the atoms idx[0..L) (NULL: first L atoms) and, if ref != NULL, the RMSD of
+ * every pose to ref: the device half of the ranking step (redocking.py:357-423)                  */
+int pd_pairwise_rmsd(const float* x, const int* idx, const float* ref, float* D, float* rmsd_ref, int n, int A, int L,
+                     void* stream);
 int pd_euler(const float* x_hat, const float* x_den, const float* x_proj, const float* w, float t_hat, float eta, float dt,
              float* x_next, int B, int A, void* stream);
 int pd_timestep_embed(const float* tau, float* emb, int n, void* stream);

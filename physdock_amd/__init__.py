@@ -9,5 +9,6 @@ Importing the package does not load the HIP library; the first kernel launch doe
 raises if `physdock_amd/libphysdock_hip.so` has not been built (python -m physdock_amd.build).
 """
 from .configs import PhysDockConfig, small_config  # noqa: F401
+from .import_weights import import_state_dict, import_unicore_ckpt  # noqa: F401
 from .model import PhysDock, weighted_rigid_align  # noqa: F401
 from .params import param_shapes, seeded_state_dict  # noqa: F401

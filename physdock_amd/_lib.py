@@ -115,6 +115,7 @@ def _declare(L):
     sig("pd_template_match", p, p, p, p, p, p, p, i, i, i, i, p)
     sig("pd_pose_dist", p, p, i, i, p)
     sig("pd_euler", p, p, p, p, f, f, f, p, i, i, p)
+    sig("pd_pairwise_rmsd", p, p, p, p, p, i, i, i, p)
     sig("pd_timestep_embed", p, p, i, p)
 
 

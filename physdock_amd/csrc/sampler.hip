@@ -330,6 +330,30 @@ __global__ __launch_bounds__(256) void pose_dist_kernel(const float* __restrict_
     D[idx] = sqrtf(dx * dx + dy * dy + dz * dz);
 }
 
+// pairwise pose RMSD over a subset of atoms: D[i,j] = sqrt(mean_a |x_i[a] - x_j[a]|^2)   (redocking.py:389-390)
+// and RMSD of every pose to a reference structure (redocking.py:382).  One block per (i, j-tile of 4 waves).
+__global__ __launch_bounds__(256) void pairwise_rmsd_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                           const float* __restrict__ ref, float* __restrict__ D,
+                                                           float* __restrict__ rmsd_ref, int n, int A, int L) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per (i, j); j == n -> reference column
+    const int lane = threadIdx.x & 63;
+    if (j > n || (j == n && !ref)) return;
+    const float* xi = x + (long long)i * A * 3;
+    const float* xj = j < n ? x + (long long)j * A * 3 : ref;
+    float acc = 0.f;
+    for (int a = lane; a < L; a += 64) {
+        const int k = idx ? idx[a] : a;
+        const float dx = xi[3 * k] - xj[3 * k], dy = xi[3 * k + 1] - xj[3 * k + 1], dz = xi[3 * k + 2] - xj[3 * k + 2];
+        acc += dx * dx + dy * dy + dz * dz;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const float r = sqrtf(acc / (float)L);
+        if (j < n) D[(long long)i * n + j] = r; else rmsd_ref[i] = r;
+    }
+}
+
 // ------------------------------------------------------------------ Euler update (model.py:245-281)
 // d = (x_hat - x_den)/t_hat [mixed with the projected ligand by w];  x_next = x_hat + (eta*dt)*d
 __global__ __launch_bounds__(256) void euler_kernel(const float* __restrict__ x_hat, const float* __restrict__ x_den,
@@ -418,6 +442,14 @@ PD_EXPORT int pd_pose_dist(const float* poses, float* D, int Cn, int L, void* st
     if (!poses || !D) return PD_ERR_ARG;
     const long long n = (long long)Cn * L * L;
     hipLaunchKernelGGL(pose_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, poses, D, L, n);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_pairwise_rmsd(const float* x, const int* idx, const float* ref, float* D, float* rmsd_ref, int n, int A,
+                               int L, void* stream) {
+    if (!x || !D || n <= 0 || L <= 0 || (ref && !rmsd_ref)) return PD_ERR_ARG;
+    hipLaunchKernelGGL(pairwise_rmsd_kernel, dim3((n + 1 + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, x, idx, ref, D,
+                       rmsd_ref, n, A, L);
     return pd_check_launch();
 }
 

@@ -118,3 +118,14 @@ def test_synthetic_crops_have_the_benchmark_shapes():
     assert int(b["token_id_to_chunk_sizes"].sum()) == 2048
     assert torch.equal(torch.repeat_interleave(torch.arange(256), b["token_id_to_chunk_sizes"]), b["atom_id_to_token_id"])
     assert b["atom_id_to_token_id"].dtype == torch.int64 and b["asym_id"].dtype == torch.int32
+
+
+def test_import_state_dict_strips_reference_prefix(tmp_path, small_model_inputs):
+    """reference utils/import_weights.py:140-150: keys carry a 6-char prefix"""
+    from physdock_amd import PhysDock, import_state_dict
+    cfg, P, batch = small_model_inputs
+    path = tmp_path / "params.pt"
+    torch.save({"model." + k: v for k, v in P.items()}, path)
+    m = import_state_dict(PhysDock(cfg), str(path))
+    sd = m.state_dict()
+    assert all(torch.equal(sd[k], v) for k, v in P.items())

@@ -171,3 +171,38 @@ def test_forward_api(small):
     # the denoiser on the returned (x_hat, t_hat) reproduces x_denoised (per-sample noise levels)
     xd = orc.af3_dit(P, batch, out["x_hat"].cpu(), out["t_hat"].cpu(), a, ap, s, z)
     assert float((out["x_denoised"].cpu() - xd).abs().max()) < 5e-4 * float(xd.abs().max())
+
+
+def test_ranking_matches_reference_procedure():
+    """redocking.py:341-423 restated with numpy/sklearn on the CPU vs the device ranking path"""
+    import numpy as np
+    import physdock_oracle as orc
+    from physdock_amd.ranking import get_representatives, rank_poses
+    g = torch.Generator().manual_seed(0)
+    n, A, L0 = 23, 60, 12
+    x_gt = 6 * torch.randn(A, 3, generator=g)
+    lig = torch.zeros(A); lig[-L0:] = 1
+    w = torch.zeros(A); w[::5] = 1; w[-L0:] = 0          # pocket-CA style weights
+    modes = [0.0, 1.5, 4.0]                                # three pose families -> clusters
+    poses = []
+    for i in range(n):
+        x = x_gt.clone()
+        x[-L0:] += modes[i % 3] * torch.tensor([1.0, -0.5, 0.2]) + 0.3 * torch.randn(L0, 3, generator=g)
+        q = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        if torch.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        poses.append(x @ q.T + 5 * torch.randn(3, generator=g))
+    x_pred = torch.stack(poses)
+    res = rank_poses(x_pred.cuda(), x_gt.cuda(), w.cuda(), lig.cuda())
+    # CPU restatement
+    al = torch.stack([orc.weighted_rigid_align(x_gt[None], x_pred[i:i + 1], w)[0] for i in range(n)])
+    pl = al[:, lig.bool()].numpy().astype(np.float64)
+    gl = x_gt[lig.bool()].numpy().astype(np.float64)
+    rm = np.sqrt(np.mean(np.linalg.norm(pl - gl, axis=-1) ** 2, axis=-1))
+    dist = np.sqrt(np.mean(np.linalg.norm(pl[:, None] - pl[None], axis=-1) ** 2, axis=-1))
+    assert np.allclose(res["dist"].cpu().numpy(), dist, atol=2e-4)
+    assert np.allclose(res["rmsd_all"].cpu().numpy(), rm, atol=2e-4)
+    ids = get_representatives(dist, 5)
+    first = get_representatives(dist, 1)[0]
+    ids = [first] + [i for i in ids if i != first][:4] if first in ids else [first] + ids[:4]
+    assert res["order"] == ids
