@@ -262,6 +262,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist:
+        td.barrier()                  # rank 0 finishes its instrumented pass before anyone tears the group down
         td.destroy_process_group()
 
 

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     float* sA = smem;                 // 2 stages
     float* sW = smem + 2 * A_TILE;    // 2 stages
 
+    const unsigned long long t_entry = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -202,6 +203,30 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Row-major epilogue: a thread always handles the same 4 output columns (NT is a multiple of the chunks per
+    // row), so bias / head-norm weights are fetched ONCE, here, and their latency disappears under the main loop.
+    const int e_glu = p.glu;
+    const int e_cpr = (e_glu ? BN / 2 : BN) / 4;
+    const int e_c = tid % e_cpr;
+    const int e_pc = e_glu ? ((e_c * 4) >> 5) * 64 + ((e_c * 4) & 31) : e_c * 4;      // packed column in Cs / bias
+    f32x4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_bias2 = {0.f, 0.f, 0.f, 0.f}, e_hw = {1.f, 1.f, 1.f, 1.f};
+    const bool e_hn = p.hn_w != nullptr && bn0 + e_pc < p.hn_cols;
+    if (p.out_mode == PD_OUT_ROWMAJOR) {
+        if (p.bias) {
+            const float* bp = p.bias + (long long)bz * p.sBias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (bn0 + e_pc + e < p.N) e_bias[e] = bp[bn0 + e_pc + e];
+                if (e_glu && bn0 + e_pc + 32 + e < p.N) e_bias2[e] = bp[bn0 + e_pc + 32 + e];
+            }
+        }
+        if (e_hn) {
+            const float* hw = p.hn_w + ((bn0 + e_pc) / p.hn_split) * 32 + ((bn0 + e_pc) & 31);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) e_hw[e] = hw[e];
+        }
+    }
+
     const int nk = (p.K + BK - 1) / BK;
     la.load(A, p.lda, bm0, p.M, 0, p.K, tid);
     lw.load(W, p.ldw, bn0, p.N, 0, p.K, tid);
@@ -216,7 +241,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     unsigned long long* dbg = nullptr;
     if (p.dbg && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 64)
         dbg = reinterpret_cast<unsigned long long*>(p.dbg) + ((long long)blockIdx.x * 4 + wave) * (5 * 64);
-#define PD_STAMP(slot) if (dbg && kt < 64) dbg[kt * 5 + slot] = __builtin_amdgcn_s_memtime()
+#define PD_STAMP(slot) if (dbg && kt < 60) dbg[kt * 5 + slot] = __builtin_amdgcn_s_memtime()
+    if (dbg) { dbg[60 * 5 + 0] = t_entry; dbg[60 * 5 + 1] = __builtin_amdgcn_s_memtime(); }
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
@@ -270,6 +296,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
         PD_STAMP(4);
     }
 #undef PD_STAMP
+    if (dbg) dbg[60 * 5 + 2] = __builtin_amdgcn_s_memtime();
 
     // ---- park the accumulators in LDS (stage buffers are free after the last barrier) ---
     float* Cs = smem;
@@ -280,7 +307,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Cs[(wm * (TM * 32) + i * 32 + pd_frag_row(r, hh)) * LDC + wn * (TN * 32) + j * 32 + l31] = acc[i][j][r];
+    if (dbg) dbg[61 * 5 + 0] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (dbg) dbg[61 * 5 + 1] = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue ------------------------------------------------------------------------
     const int glu = p.glu;
@@ -298,6 +327,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
         const int total = BM * cpr;            // multiple of NT*U for every tile configuration
 #pragma unroll 1
         for (int base = tid; base < total; base += NT * U) {
+            if (dbg && base == tid + NT * U) dbg[61 * 5 + 2] = __builtin_amdgcn_s_memtime();
             f32x4 v[U], mulv[U], resv[U];
             int mrow[U], ncol[U];
             bool ok[U], full[U];
@@ -336,29 +366,21 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idx = base + u * NT;
-                const int row = idx / cpr, c = idx - row * cpr;
+                const int row = idx / cpr;
                 const int m = mrow[u];
-                const int pc = glu ? ((c * 4) >> 5) * 64 + ((c * 4) & 31) : c * 4;    // packed column in Cs / bias
-                f32x4 x = *reinterpret_cast<const f32x4*>(Cs + row * LDC + pc);
+                f32x4 x = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_pc);
                 if (p.rowscale_acc) x *= (m < p.M ? p.rowscale_acc[(long long)bz * p.M + m] : 0.f);
-                if (biasp) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (bn0 + pc + e < p.N) x[e] += biasp[bn0 + pc + e];
-                }
-                if (p.hn_w && bn0 + pc < p.hn_cols) {   // per-head RMSNorm: 8 consecutive lanes own one 32-wide head
+                x += e_bias;
+                if (e_hn) {   // per-head RMSNorm: 8 consecutive lanes own one 32-wide head
                     float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
                     ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
                     const float rs = rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps);
-                    const float* hw = p.hn_w + ((bn0 + pc) / p.hn_split) * 32 + ((bn0 + pc) & 31);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = x[e] * rs * hw[e];
+                    for (int e = 0; e < 4; ++e) x[e] = x[e] * rs * e_hw[e];
                 }
                 if (glu) {
-                    f32x4 b2 = *reinterpret_cast<const f32x4*>(Cs + row * LDC + pc + 32);
-                    if (biasp) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (bn0 + pc + 32 + e < p.N) b2[e] += biasp[bn0 + pc + 32 + e];
-                    }
+                    f32x4 b2 = *reinterpret_cast<const f32x4*>(Cs + row * LDC + e_pc + 32);
+                    b2 += e_bias2;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = (glu == 1) ? pd_silu(x[e]) * b2[e] : x[e] * pd_sigmoid(b2[e]);
                 } else {
@@ -439,6 +461,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
             }
         }
     }
+    if (dbg) dbg[60 * 5 + 3] = __builtin_amdgcn_s_memtime();
 }
 
 // op 0: launch, op 1: raise the dynamic-LDS limit of the instantiation (pd_init)

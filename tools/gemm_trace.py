@@ -14,7 +14,7 @@ ops.GEMM_DBG = dbg
 ops.gemm(A, W, Y, M, N, K)
 torch.cuda.synchronize()
 ops.GEMM_DBG = None
-nk = min((K + 31) // 32, 64)
+nk = min((K + 31) // 32, 60)
 d = dbg.cpu().reshape(64, 4, 64, 5)[:, :, :nk].double()          # block, wave, kt, slot
 ph = d[..., 1:] - d[..., :-1]                                      # per-slice phase durations
 names = ["issue loads", "MFMA block", "wait+stage", "barrier"]
@@ -26,6 +26,13 @@ tot = d[:, :, -1, 4] - d[:, :, 0, 0]
 print(f"  main loop total per wave: mean {tot.mean():.0f} ticks; per slice {tot.mean() / nk:.1f}")
 gap = d[:, :, 1:, 0] - d[:, :, :-1, 4]
 print(f"  gap between slices (loop overhead) mean {gap.mean():.1f}")
+ex = dbg.cpu().reshape(64, 4, 64, 5)[:, :, 60, :4].double()
+print(f"  kernel entry -> first slice (prologue: first loads, stats, LDS fill): mean {(ex[..., 1] - ex[..., 0]).mean():.0f}")
+print(f"  main loop: mean {(ex[..., 2] - ex[..., 1]).mean():.0f}")
+print(f"  epilogue (park in LDS, gate/residual, stores issued): mean {(ex[..., 3] - ex[..., 2]).mean():.0f}")
+e2 = dbg.cpu().reshape(64, 4, 64, 5)[:, :, 61, :3].double()
+print(f"  epilogue detail: park acc->LDS {(e2[..., 0] - ex[..., 2]).mean():.0f}, barrier {(e2[..., 1] - e2[..., 0]).mean():.0f}, first trip (4 row-chunks) {(e2[..., 2] - e2[..., 1]).mean():.0f}, remaining trips {(ex[..., 3] - e2[..., 2]).mean():.0f}")
+print(f"  block lifetime: mean {(ex[..., 3] - ex[..., 0]).mean():.0f}; spread of block entry times {ex[..., 0].max() - ex[..., 0].min():.0f}")
 # phase alignment of co-resident blocks is unknown; show start skew across blocks
 st = d[:, 0, 0, 0]
 print(f"  block start skew: min {st.min() - st.min():.0f} max {st.max() - st.min():.0f} ticks")
