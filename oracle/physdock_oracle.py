@@ -71,8 +71,8 @@ def dit_transition(P, name, x, t, eps):
 def timestep_embeddings(P, name, tau):
     """primitives/timestep_embeddings.py:35-86,156-166: cos|sin(256), shift 0, then MLP."""
     half = 128
-    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
-    arg = tau[:, None].float() * freq[None]
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half).to(tau.dtype)
+    arg = tau[:, None] * freq[None]
     emb = torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
     h = F.silu(linear(P, name + ".timestep_embedder.linear_1", emb))
     return linear(P, name + ".timestep_embedder.linear_2", h)
@@ -230,7 +230,7 @@ def segment_mean_pool(u, chunk_sizes):
 def one_hot_nearest(x, bins):
     """utils/tensor_utils.py:78-82."""
     am = torch.argmin(torch.abs(x[..., None] - bins), dim=-1)
-    return F.one_hot(am, num_classes=len(bins)).float()
+    return F.one_hot(am, num_classes=len(bins)).float()            # cast to the weight dtype by the caller
 
 
 def rel_pos_features(batch):
@@ -246,14 +246,15 @@ def rel_pos_features(batch):
     d_ch = torch.clamp(sym[:, None] - sym[None, :] + s_max, 0, 2 * s_max)
     d_ch = torch.where(chain_same | ~ent_same, 2 * s_max + 1, d_ch)
     f_ch = one_hot_nearest(d_ch, torch.arange(0, 2 * s_max + 2))
-    return torch.cat([f_pos, batch["rel_tok_feat"], ent_same[..., None].float(), f_ch], dim=-1)
+    dt = batch["rel_tok_feat"].dtype
+    return torch.cat([f_pos.to(dt), batch["rel_tok_feat"], ent_same[..., None].to(dt), f_ch.to(dt)], dim=-1)
 
 
 def atom_embedder(P, name, batch, inf, eps):
     """layers/diffusion_conditioning.py:110-128."""
     ref_pos, uid = batch["ref_pos"], batch["ref_space_uid"]
-    d = (ref_pos[:, None, :] - ref_pos[None, :, :]).float()
-    v = (uid[:, None] == uid[None, :]).float()[..., None]
+    d = ref_pos[:, None, :] - ref_pos[None, :, :]                 # (reference casts to fp32 here; inputs are fp32)
+    v = (uid[:, None] == uid[None, :]).to(ref_pos.dtype)[..., None]
     a = linear(P, name + ".linear_c", batch["ref_feat"])
     p = linear(P, name + ".linear_p", d) * v
     p = p + linear(P, name + ".linear_d", 1 / (1 + torch.norm(d, dim=-1)[..., None])) * v
@@ -370,7 +371,7 @@ def centre_random_augmentation(x, x_exists, u, trans):
 
 def weighted_rigid_align(x_pred, x_gt, weights):
     """utils/tensor_utils.py:744-778: returns x_gt moved onto x_pred (second argument moves)."""
-    x_pred, x_gt, weights = x_pred.float(), x_gt.float(), weights.float()
+    x_pred, x_gt, weights = x_pred.float(), x_gt.float(), weights.float()      # reference: fp32 under autocast-off
     if x_gt.dim() == 2:
         x_gt = x_gt[None]
     wsum = weights.sum()
