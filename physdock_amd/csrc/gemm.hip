@@ -28,8 +28,13 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;   // padded row (floats): 144 B, keeps ds_read_b128 conflict-free
+#ifndef PD_BK
+#define PD_BK 32
+#endif
+constexpr int BK = PD_BK;     // k-slice depth (32 or 16)
+constexpr int LDK = BK + 4;   // padded row (floats): 144 B / 80 B, keeps ds_read_b128 conflict-free
+constexpr int CH = BK / 4;    // 16-byte chunks per staged row
+constexpr int RPP = 256 / CH; // rows staged per pass of the 256 threads
 constexpr int NT = 256;
 constexpr int PADM = 4;
 
@@ -39,25 +44,26 @@ struct Cfg {
     static constexpr int W_TILE = WKM ? BK * (BN + PADM) : BN * LDK;
     static constexpr int LDC = BN + 4;
     static constexpr int STAGE_FLOATS = 2 * (A_TILE + W_TILE);
-    static constexpr int C_FLOATS = BM * LDC;
+    static constexpr int CPASS = (BM * LDC > STAGE_FLOATS && BM >= 128) ? 2 : 1;   // park the accumulators in row slabs
+    static constexpr int C_FLOATS = (BM / CPASS) * LDC;
     static constexpr int LDS_BYTES = 4 * (STAGE_FLOATS > C_FLOATS ? STAGE_FLOATS : C_FLOATS);
 };
 
 // One operand tile loader: R rows (m or n) x BK, either [R][K] (k contiguous) or k-major [K][R].
 template <int R, bool KM, bool VEC>
 struct TileLoader {
-    static constexpr int SLOTS = R / 32;               // float4 per thread per k-tile
     static constexpr int CPR = R / 4;                  // k-major: 16-byte chunks per k-row
     static constexpr int KSTEP = NT / CPR;
+    static constexpr int SLOTS = KM ? BK / KSTEP : R / RPP;   // float4 per thread per k-slice
     f32x4 reg[SLOTS];
 
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int r0, int rows, int k0, int K, int tid) {
         if constexpr (!KM) {
-            const int kc = k0 + (tid & 7) * 4;
+            const int kc = k0 + (tid % CH) * 4;
             const int kcl = kc < K ? kc : 0;
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i) {
-                int r = r0 + (tid >> 3) + 32 * i;
+                int r = r0 + tid / CH + RPP * i;
                 r = r < rows ? r : rows - 1;
                 const float* src = base + (long long)r * ld + kcl;
                 if constexpr (VEC) reg[i] = *reinterpret_cast<const f32x4*>(src);
@@ -81,10 +87,10 @@ struct TileLoader {
     __device__ __forceinline__ void mask(int r0, int rows, int k0, int K, int tid) {
         if (r0 + R <= rows && k0 + BK <= K) return;
         if constexpr (!KM) {
-            const int kc = k0 + (tid & 7) * 4;
+            const int kc = k0 + (tid % CH) * 4;
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i) {
-                const bool rok = r0 + (tid >> 3) + 32 * i < rows;
+                const bool rok = r0 + tid / CH + RPP * i < rows;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) reg[i][e] = (rok && kc + e < K) ? reg[i][e] : 0.f;
             }
@@ -102,7 +108,7 @@ struct TileLoader {
         if constexpr (!KM) {
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i)
-                *reinterpret_cast<f32x4*>(s + ((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4) = reg[i];
+                *reinterpret_cast<f32x4*>(s + (tid / CH + RPP * i) * LDK + (tid % CH) * 4) = reg[i];
         } else {
 #pragma unroll
             for (int i = 0; i < SLOTS; ++i)
@@ -135,7 +141,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
 
     // ---- prologue state: this thread always stages the same rows of A ------------------
     // PRO 0: none   1: pro_w/pro_b shared by all rows   2: per row group (AdaLN with per-sample t)
-    constexpr int NST = AKM ? 4 : BM / 32;
+    constexpr int ASLOTS = TileLoader<BM, AKM, VEC>::SLOTS;
+    constexpr int NST = AKM ? 4 : ASLOTS;
     float st_mean[NST], st_rstd[NST];
     int grp_off[NST];
 #pragma unroll
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     if constexpr (PRO != 0) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
-            int m = AKM ? bm0 + (tid % (BM / 4)) * 4 + i : bm0 + (tid >> 3) + 32 * i;
+            int m = AKM ? bm0 + (tid % (BM / 4)) * 4 + i : bm0 + tid / CH + RPP * i;
             m = m < p.M ? m : p.M - 1;
             st_mean[i] = p.stats[2 * ((long long)bz * p.M + m)];
             st_rstd[i] = p.stats[2 * ((long long)bz * p.M + m) + 1];
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     auto transform_A = [&](int k0) {
         if constexpr (PRO != 0) {
             if constexpr (!AKM) {
-                int kc = k0 + (tid & 7) * 4;
+                int kc = k0 + (tid % CH) * 4;
                 kc = kc < p.K ? kc : 0;
                 f32x4 pw, pb;
                 if constexpr (PRO == 1) {
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
                     pb = *reinterpret_cast<const f32x4*>(p.pro_b + kc);
                 }
 #pragma unroll
-                for (int i = 0; i < BM / 32; ++i) {
+                for (int i = 0; i < ASLOTS; ++i) {
                     if constexpr (PRO == 2) {
                         pw = *reinterpret_cast<const f32x4*>(p.pro_w + grp_off[i] + kc);
                         pb = *reinterpret_cast<const f32x4*>(p.pro_b + grp_off[i] + kc);
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
             } else {
                 constexpr int CPR = BM / 4, KSTEP = NT / CPR;
 #pragma unroll
-                for (int i = 0; i < BM / 32; ++i) {
+                for (int i = 0; i < ASLOTS; ++i) {
                     int k = k0 + tid / CPR + KSTEP * i;
                     k = k < p.K ? k : 0;
                     const float pw = p.pro_w[k], pb = p.pro_b[k];
@@ -184,12 +191,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
         }
         if (p.pro_act == PD_ACT_RELU) {
 #pragma unroll
-            for (int i = 0; i < BM / 32; ++i)
+            for (int i = 0; i < ASLOTS; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) la.reg[i][e] = fmaxf(la.reg[i][e], 0.f);
         } else if (p.pro_act == PD_ACT_SILU) {
 #pragma unroll
-            for (int i = 0; i < BM / 32; ++i)
+            for (int i = 0; i < ASLOTS; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) la.reg[i][e] = pd_silu(la.reg[i][e]);
         }
@@ -298,18 +305,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
 #undef PD_STAMP
     if (dbg) dbg[60 * 5 + 2] = __builtin_amdgcn_s_memtime();
 
-    // ---- park the accumulators in LDS (stage buffers are free after the last barrier) ---
+    // ---- park the accumulators in LDS one row slab at a time (stage buffers are free after the last barrier)
     float* Cs = smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Cs[(wm * (TM * 32) + i * 32 + pd_frag_row(r, hh)) * LDC + wn * (TN * 32) + j * 32 + l31] = acc[i][j][r];
-    if (dbg) dbg[61 * 5 + 0] = __builtin_amdgcn_s_memtime();
-    __syncthreads();
-    if (dbg) dbg[61 * 5 + 1] = __builtin_amdgcn_s_memtime();
+    constexpr int CPASS = C_::CPASS, SLAB = BM / CPASS;
 
     // ---- epilogue ------------------------------------------------------------------------
     const int glu = p.glu;
@@ -319,12 +317,29 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     const float* biasp = p.bias ? p.bias + (long long)bz * p.sBias : nullptr;
     const float* resp = p.res ? p.res + (long long)bz * p.sRes : nullptr;
 
+  for (int pass = 0; pass < CPASS; ++pass) {
+    const int slab0 = pass * SLAB;
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rbase = wm * (TM * 32) + i * 32;
+        if (rbase >= slab0 && rbase < slab0 + SLAB) {      // wave-uniform
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(rbase - slab0 + pd_frag_row(r, hh)) * LDC + wn * (TN * 32) + j * 32 + l31] = acc[i][j][r];
+        }
+    }
+    if (dbg && pass == 0) dbg[61 * 5 + 0] = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if (dbg && pass == 0) dbg[61 * 5 + 1] = __builtin_amdgcn_s_memtime();
     if (p.out_mode == PD_OUT_ROWMAJOR) {
         // U row-chunks per trip: all gate / residual loads of a trip are issued before the first store, so the
         // epilogue keeps U independent 16-byte loads in flight per lane instead of one dependent round trip per row.
         constexpr int U = 4;
         const int cpr = BN_out / 4;
-        const int total = BM * cpr;            // multiple of NT*U for every tile configuration
+        const int total = SLAB * cpr;          // rows of this slab x chunks
 #pragma unroll 1
         for (int base = tid; base < total; base += NT * U) {
             if (dbg && base == tid + NT * U) dbg[61 * 5 + 2] = __builtin_amdgcn_s_memtime();
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
             for (int u = 0; u < U; ++u) {
                 const int idx = base + u * NT;
                 const int row = idx / cpr, c = idx - row * cpr;
-                const int m = bm0 + row, n = bn_out0 + c * 4;
+                const int m = bm0 + slab0 + row, n = bn_out0 + c * 4;
                 mrow[u] = m; ncol[u] = n;
                 ok[u] = idx < total && m < p.M && n < N_out;
                 full[u] = p.vecY && n + 3 < N_out;
@@ -408,11 +423,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
         }
     } else if (p.out_mode == PD_OUT_TRANSPOSED) {
         // Y[n][m]: 4 consecutive m per thread.  Supports bias, glu/act, rowscale, out_scale.
-        const int mch = BM / 4;
+        const int mch = SLAB / 4;
 #pragma unroll 1
         for (int idx = tid; idx < BN_out * mch; idx += NT) {
             const int nl = idx / mch, mc = idx - nl * mch;
-            const int n = bn_out0 + nl, m0 = bm0 + mc * 4;
+            const int n = bn_out0 + nl, m0 = bm0 + slab0 + mc * 4;
             if (n >= N_out || m0 >= p.M) continue;
             const int pc = glu ? (nl >> 5) * 64 + (nl & 31) : nl;
             f32x4 v;
@@ -438,9 +453,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     } else {
         // PD_OUT_OPM / PD_OUT_BIASFRAG: scalar scatter (bias, maskadd, out_scale)
 #pragma unroll 1
-        for (int idx = tid; idx < BM * BN; idx += NT) {
+        for (int idx = tid; idx < SLAB * BN; idx += NT) {
             const int row = idx / BN, col = idx - row * BN;
-            const int m = bm0 + row, n = bn0 + col;
+            const int m = bm0 + slab0 + row, n = bn0 + col;
             if (m >= p.M || n >= p.N) continue;
             float v = Cs[row * LDC + col];
             if (biasp) v += biasp[n];
@@ -461,6 +476,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
             }
         }
     }
+  }   // slab pass
     if (dbg) dbg[60 * 5 + 3] = __builtin_amdgcn_s_memtime();
 }
 
