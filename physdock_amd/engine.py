@@ -160,12 +160,13 @@ class Engine:
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         ops.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z)
 
-    def triangle_block(self, prefix, z, T, C, mask):
-        """layers/transformers.py:48-54"""
+    def triangle_block(self, prefix, z, T, C, mask, maskT):
+        """layers/transformers.py:48-54.  The reference transposes z for the column variants but NOT the mask
+        (attentions.py:158-162,195,208), i.e. pair (i,j) of the original layout sees mask[j,i]: `maskT`."""
         self.triangle_update(prefix + ".triangle_row_update", z, T, C, mask, False)
-        self.triangle_update(prefix + ".triangle_col_update", z, T, C, mask, True)
+        self.triangle_update(prefix + ".triangle_col_update", z, T, C, maskT, True)
         self.triangle_attention(prefix + ".triangle_row_attention", z, T, C, mask, False)
-        self.triangle_attention(prefix + ".triangle_col_attention", z, T, C, mask, True)
+        self.triangle_attention(prefix + ".triangle_col_attention", z, T, C, maskT, True)
         self.transition(prefix + ".pair_transition", z, T * T, C)
 
     # ------------------------------------------------------------------ conditioning trunk
@@ -184,6 +185,7 @@ class Engine:
         self.Ar, self.Tr = batch.get("_A_real", A), batch.get("_T_real", T)
         ap_mask = batch["ap_mask"]
         z_mask = batch["z_mask"]
+        z_maskT = z_mask.t().contiguous()          # layout copy of an input mask (see triangle_block)
         pre = "diffusion_conditioning"
 
         # ---------------- AtomEmbedder (:110-128)
@@ -246,7 +248,7 @@ class Engine:
             self.msa_column_attention(blk + ".msa_col_attention", m, S, T, Cm)
             self.transition(blk + ".msa_transition", m, S * T, Cm)
             self.outer_product_mean(blk + ".opm", m, z, S, T, Cm, Cz)
-            self.triangle_block(blk, z, T, Cz, z_mask)
+            self.triangle_block(blk, z, T, Cz, z_mask, z_maskT)
 
         # ---------------- TemplatePairEmbedder (:38-50)
         tp = te + ".template_pair_embedder"
@@ -258,8 +260,9 @@ class Engine:
         st = self.stats(z, T * T, Cz, RMS, 1e-6)
         self.lin(z, tp + ".linear_in", T * T, out=uu, stats=st, pro_w=P[tp + ".norm_in.weight"])
         self.lin(batch["templ_feat"], tp + ".linear_templ_feat", T * T, out=uu, res=uu)
+        tmaskT = tmask.reshape(T, T).t().contiguous().reshape(-1)
         for b in range(2):
-            self.triangle_block(f"{tp}.triangleformer.blocks.{b}", uu, T, Cz, tmask)
+            self.triangle_block(f"{tp}.triangleformer.blocks.{b}", uu, T, Cz, tmask, tmaskT)
         st = self.stats(uu, T * T, Cz, RMS, eps)
         tpo = self.lin(uu, tp + ".linear_out", T * T, stats=st, pro_w=P[tp + ".norm_out.weight"], pro_act=ACT_RELU)
         ops.check(L.pd_axpby(ops.ptr(z), ops.ptr(z), 1.0, ops.ptr(tpo), ops.ptr(batch["t_mask"]), 1.0, T * T * Cz,
@@ -274,7 +277,7 @@ class Engine:
         sbias = ws.get("single_bias", ops.bias_frag_numel(Hs, T, T), zero=True)
         for b in range(dc.no_blocks_pairformer):
             blk = f"{te}.pairformer.blocks.{b}"
-            self.triangle_block(blk, z, T, Cz, z_mask)
+            self.triangle_block(blk, z, T, Cz, z_mask, z_maskT)
             self.pair_bias(blk + ".attention", z, T, T, Cz, z_mask, P[blk + ".attention.norm_z.weight"], sbias)
             self.attention_pair_bias(blk + ".attention", s, 1, T, Cs, sbias, nk=self.Tr)
             self.transition(blk + ".transition", s, T, Cs)

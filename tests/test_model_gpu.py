@@ -206,3 +206,36 @@ def test_ranking_matches_reference_procedure():
     first = get_representatives(dist, 1)[0]
     ids = [first] + [i for i in ids if i != first][:4] if first in ids else [first] + ids[:4]
     assert res["order"] == ids
+
+
+def test_non_trivial_masks_match_oracle(small_model_inputs):
+    """masks are all-ones at inference (feature_loader.py:789-791) but the kernels honour them like the reference
+    (gen_attn_mask -> -1e9 bias, mask-multiplied triangle operands, masked centroid): random zeros in every mask"""
+    import physdock_oracle as orc
+    from physdock_amd import PhysDock
+    cfg, P, batch0 = small_model_inputs
+    batch = dict(batch0)
+    g = torch.Generator().manual_seed(21)
+    T, A = batch["target_feat"].shape[0], batch["ref_pos"].shape[0]
+    am = (torch.rand(A, generator=g) > 0.1).float(); am[-6:] = 1.0          # keep the ligand
+    zm = (torch.rand(T, T, generator=g) > 0.15).float(); zm.fill_diagonal_(1.0)
+    batch["a_mask"] = am
+    batch["x_exists"] = am.clone()
+    batch["ap_mask"] = am[None] * am[:, None]
+    batch["z_mask"] = zm
+    batch["t_mask"] = torch.tensor(1.0)
+    model = PhysDock(cfg); model.load_state_dict(P); model = model.cuda().eval()
+    dc = cfg.model.diffusion_conditioning
+    ref_c = orc.diffusion_conditioning(P, batch, dc.inf, dc.eps)
+    eng = model.engine(torch.device("cuda", torch.cuda.current_device()))
+    a, ap, s, z = eng.conditioning(model._prepare_batch(to_dev(batch)))
+    for name, h, r in zip("a ap s z".split(), (a, ap, s, z), ref_c):
+        assert rel(h.reshape(r.shape), r) < 3e-4, name
+    B, steps = 2, 10
+    n_noisy = int((orc.karras_noise_schedule(steps, p=1000)[:-1] > 1.0).sum())
+    noise = {"init": torch.randn(B, A, 3, generator=g), "rot_u": torch.rand(steps, 4, B, generator=g),
+             "trans": torch.randn(steps, B, 3, generator=g), "diffuse": torch.randn(n_noisy, B, A, 3, generator=g)}
+    kw = dict(num_sample=B, steps=steps, karras_noise_schedule_power=1000, align_ref_pos=True)
+    ref = orc.sample_diffusion(P, batch, noise, **kw)
+    x = model.sample_diffusion(to_dev(batch), noise=noise, **kw)
+    assert rmsd(x.cpu(), ref) < 1e-3
