@@ -239,3 +239,38 @@ def test_non_trivial_masks_match_oracle(small_model_inputs):
     ref = orc.sample_diffusion(P, batch, noise, **kw)
     x = model.sample_diffusion(to_dev(batch), noise=noise, **kw)
     assert rmsd(x.cpu(), ref) < 1e-3
+
+
+def test_token_without_atoms(small_model_inputs):
+    """UNK residues give tokens with zero atoms (feature_loader.py:568-574): pooling yields 0/(0+1e-3) = 0 for them
+    (the reference's cumsum-diff does the same)"""
+    import physdock_oracle as orc
+    from physdock_amd import PhysDock
+    cfg, P, batch0 = small_model_inputs
+    batch = dict(batch0)
+    chunk = batch["token_id_to_chunk_sizes"].clone()
+    chunk[2] += chunk[3]; chunk[3] = 0                         # token 3 loses its atoms to token 2
+    batch["token_id_to_chunk_sizes"] = chunk
+    batch["atom_id_to_token_id"] = torch.repeat_interleave(torch.arange(len(chunk)), chunk)
+    model = PhysDock(cfg); model.load_state_dict(P); model = model.cuda().eval()
+    dc = cfg.model.diffusion_conditioning
+    ref_c = orc.diffusion_conditioning(P, batch, dc.inf, dc.eps)
+    eng = model.engine(torch.device("cuda", torch.cuda.current_device()))
+    pb = model._prepare_batch(to_dev(batch))
+    cond = eng.conditioning(pb)
+    for name, h, r in zip("a ap s z".split(), cond, ref_c):
+        assert rel(h.reshape(r.shape), r) < 3e-4, name
+    A = batch["ref_pos"].shape[0]
+    g = torch.Generator().manual_seed(2)
+    x_hat = 5 * torch.randn(2, A, 3, generator=g)
+    t_hat = torch.tensor([3.0, 3.0])
+    ref = orc.af3_dit(P, batch, x_hat, t_hat, *ref_c)
+    sd = 16.0
+    th = t_hat[0]
+    tau = (th * (torch.log(th / sd) / 4.0)).reshape(1).cuda()
+    prep = eng.prepare_dit(*cond, pb, tau)
+    scal = dict(c_in=float(1 / torch.sqrt(th ** 2 + sd ** 2)), c_skip=float(sd ** 2 / (sd ** 2 + th ** 2)),
+                c_out=float(sd * th / torch.sqrt(sd ** 2 + th ** 2)))
+    xd = torch.empty(2, A, 3, device="cuda")
+    eng.af3_dit(pb, x_hat.cuda().contiguous(), xd, cond[0], cond[2], prep, 2, scal, row=0)
+    assert float((xd.cpu() - ref).abs().max()) < 3e-4 * float(ref.abs().max())
