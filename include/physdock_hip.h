@@ -95,6 +95,7 @@ typedef struct pd_attn_args {
     long long q_bs, q_ss, k_bs, k_ss, v_bs, v_ss, o_bs, o_ss;
     const float* bias;
     float scale;             /* 1/sqrt(32) */
+    void* dbg;               /* optional phase-trace buffer (tools/attn_trace.py); NULL in production */
 } pd_attn_args;
 int pd_attention(const pd_attn_args* args, void* stream);
 

@@ -49,7 +49,7 @@ class AttnArgs(C.Structure):
         ("nq", C.c_int), ("nk", C.c_int), ("nbatch", C.c_int), ("nheads", C.c_int),
         ("q_bs", C.c_longlong), ("q_ss", C.c_longlong), ("k_bs", C.c_longlong), ("k_ss", C.c_longlong),
         ("v_bs", C.c_longlong), ("v_ss", C.c_longlong), ("o_bs", C.c_longlong), ("o_ss", C.c_longlong),
-        ("bias", _fp), ("scale", C.c_float),
+        ("bias", _fp), ("scale", C.c_float), ("dbg", _fp),
     ]
 
 

@@ -149,10 +149,16 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
         }
     };
     const int nfull32 = p.nk >> 5;                 // sub-tiles with all 32 keys in range
+    unsigned long long* dbg = nullptr;             // optional phase trace (tools/attn_trace.py)
+    if (p.dbg && lane == 0 && blockIdx.x < 8 && blockIdx.y < 2 && blockIdx.z == 0)
+        dbg = reinterpret_cast<unsigned long long*>(p.dbg) + (((long long)blockIdx.y * 8 + blockIdx.x) * 4 + wave) * (4 * 64);
+#define PD_STAMP(slot) if (dbg && it < 64) dbg[it * 4 + slot] = __builtin_amdgcn_s_memtime()
 
     for (int it = 0; it < nit; ++it) {
         const int cur = it & 1;
+        PD_STAMP(0);
         if (it + 1 < nit) gload((it + 1) * KT);
+        PD_STAMP(1);
         if (wave_active) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -161,9 +167,12 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
                 else if (kt32 * 32 < p.nk) subtile(std::true_type{}, cur, sub, kt32);
             }
         }
+        PD_STAMP(2);
         if (it + 1 < nit) sstore(cur ^ 1);
         __syncthreads();
+        PD_STAMP(3);
     }
+#undef PD_STAMP
 
     if (query < p.nq) {
         const float l = l_run + __shfl_xor(l_run, 32);

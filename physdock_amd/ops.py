@@ -70,6 +70,9 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
     check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm")
 
 
+#: optional in-kernel phase-trace buffer for the attention kernel (int64, 16*4*4*64 entries), see tools/attn_trace.py
+ATTN_DBG = None
+
 #: optional in-kernel phase-trace buffer (int64 tensor of 64*4*5*64 entries), see tools/gemm_trace.py
 GEMM_DBG = None
 
@@ -102,6 +105,8 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
     a.o_bs, a.o_ss = o_strides
     a.bias = P(bias)
     a.scale = scale
+    if ATTN_DBG is not None:
+        a.dbg = ATTN_DBG.data_ptr()
     check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention")
 
 
