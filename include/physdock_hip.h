@@ -72,7 +72,8 @@ typedef struct pd_gemm_args {
     void* dbg;                   /* optional phase-trace buffer (tools/gemm_trace.py); NULL in production      */
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
-/* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling) */
+/* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling);
+ * id % 10000 >= 5000: gemm_stream_kernel<id % 10, id / 10000> (csrc/gemm_stream.hip) takes it */
 int pd_gemm_variant(const pd_gemm_args* args);
 
 /* ---- pd_rowstats: per-row (mean, rstd) for the GEMM prologue --------------------------

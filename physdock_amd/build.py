@@ -41,6 +41,12 @@ def build(force=False, verbose=True):
                "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
         if os.environ.get("PD_BK") and os.path.basename(src) == "gemm.hip":
             cmd[1:1] = ["-DPD_BK=" + os.environ["PD_BK"]]
+        if os.environ.get("PD_STREAM_NOEMIT") and os.path.basename(src) == "gemm_stream.hip":
+            cmd[1:1] = ["-DPD_STREAM_NOEMIT=1"]
+        if os.environ.get("PD_STREAM_SAMETILE") and os.path.basename(src) == "gemm_stream.hip":
+            cmd[1:1] = ["-DPD_STREAM_SAMETILE=1"]
+        if os.environ.get("PD_GEMM_NOSTORE") and os.path.basename(src) == "gemm.hip":
+            cmd[1:1] = ["-DPD_GEMM_NOSTORE=1"]
         if os.environ.get("PD_NO_EXTRA_FLAGS") != "1":
             cmd[1:1] = EXTRA_FLAGS.get(os.path.basename(src), [])
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -519,8 +519,11 @@ inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 }  // namespace
 
+// gemm_stream.hip: persistent variant with a direct-from-fragment epilogue for large full-tile row-major problems
+extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, void* stream, int init_only);
+
 PD_EXPORT int pd_init(void) {
-    int rc = PD_OK;
+    int rc = pd_gemm_stream_try(nullptr, 0, nullptr, 1);
     for (int cfg = 0; cfg < 4; ++cfg)
         for (int lay = 0; lay < 3; ++lay)
             for (int vec = 0; vec < 2; ++vec)
@@ -573,11 +576,22 @@ static int select_variant(pd_gemm_args& p, int& cfg, bool& akm, bool& wkm, bool&
     return cfg * 100 + (akm ? (wkm ? 2 : 1) : 0) * 10 + pro + (vec ? 0 : 1000);
 }
 
+static bool use_stream() {
+    static const int on = [] { const char* e = getenv("PD_GEMM_STREAM"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
+// variant id as documented above; + 5000 + 10000 * EPI when the launch goes to gemm_stream_kernel<pro, EPI>
 PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     if (!args) return PD_ERR_ARG;
     pd_gemm_args p = *args;
     int cfg, pro; bool akm, wkm, vec;
-    return select_variant(p, cfg, akm, wkm, vec, pro);
+    const int v = select_variant(p, cfg, akm, wkm, vec, pro);
+    if (v >= 0 && use_stream() && cfg == 0 && !p.dbg) {
+        const int epi = pd_gemm_stream_try(&p, pro, nullptr, 2);
+        if (epi >= 0) return v + 5000 + 10000 * epi;
+    }
+    return v;
 }
 
 PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
@@ -586,5 +600,9 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
+    if (use_stream() && cfg == 0 && !p.dbg) {
+        const int r = pd_gemm_stream_try(&p, pro, stream, 0);
+        if (r != PD_ERR_UNSUPPORTED) return r;
+    }
     return dispatch(0, cfg, akm, wkm, vec, pro, &p, (hipStream_t)stream);
 }

@@ -1,0 +1,334 @@
+// Persistent fp32 MFMA GEMM with a direct-from-fragment, compile-time specialised epilogue (the variant of gemm.hip
+// for the hot full-tile row-major shapes).
+//
+// Why: measurements on gemm.hip (NOTES.md "epilogue finding, revisited") show that its flag-driven LDS-staged epilogue
+// costs ~20 % of a K=128 tile and ~7 % of a K=512 tile, and that this cost is NOT the stores (suppressing only the
+// stores changes the time by 6 %): it is the instruction / latency chain park -> barrier -> re-read -> flag tests ->
+// 64-bit address arithmetic, repeated per 16-byte chunk.  Here
+//   * the epilogue kind is a template parameter and tiles are always full, so an element costs 2-6 instructions,
+//   * values go straight from the MFMA accumulator fragment to memory (lane = column: every store instruction writes
+//     two full 128-byte row segments), no LDS round trip, no barrier,
+//   * SGPR base pointers + 32-bit lane offsets,
+//   * a block walks several output tiles; the first k-slice of the next tile and the per-column constants are
+//     requested before the epilogue of the current one, so their latency hides under it.
+// A register-parked DEFERRED epilogue (issued inside the next tile's main loop) was built first: it needs 64 more
+// registers than the 256 available at two waves per SIMD and the compiler spills (NOTES.md).
+//
+// Scope: A [M,K] and W [N,K] row-major with 16-byte aligned rows, row-major Y, one batch, M % 128 == N % 128 == 0,
+// epilogue kinds below.  Everything else stays on gemm.hip (pd_gemm dispatches).
+#include <stdlib.h>
+#include "common.h"
+#include "physdock_hip.h"
+
+#ifdef PD_STREAM_SAMETILE
+#define PD_LT(x) ((x) & 0)          // experiment: every tile re-reads tile 0 (all loads hit L2 / TLB)
+#else
+#define PD_LT(x) (x)
+#endif
+
+#ifdef PD_STREAM_NOEMIT
+#define PD_ST(dst, val) do { const float v_ = (val); if (v_ == 123.456f) (dst) = v_; } while (0)   // experiment: no stores
+#else
+#define PD_ST(dst, val) (dst) = (val)
+#endif
+
+namespace {
+
+constexpr int BK = 32, LDK = BK + 4, NT = 256, BM = 128, BN = 128, TM = 2, TN = 2;
+constexpr int A_TILE = BM * LDK, W_TILE = BN * LDK;
+constexpr int LDS_BYTES = 4 * 2 * (A_TILE + W_TILE);
+
+struct Loader {     // 128 rows x 32 k, [row][k] layout; thread -> rows (tid>>3)+32i, 16-byte chunk tid&7
+    f32x4 reg[4];
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int r0, int rows, int k0, int K, int tid) {
+        const int kc = k0 + (tid & 7) * 4;
+        const int kcl = kc < K ? kc : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = r0 + (tid >> 3) + 32 * i;
+            r = r < rows ? r : rows - 1;
+            reg[i] = *reinterpret_cast<const f32x4*>(base + (long long)r * ld + kcl);
+        }
+    }
+    __device__ __forceinline__ void mask(int r0, int rows, int k0, int K, int tid) {
+        if (r0 + 128 <= rows && k0 + BK <= K) return;
+        const int kc = k0 + (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool rok = r0 + (tid >> 3) + 32 * i < rows;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) reg[i][e] = (rok && kc + e < K) ? reg[i][e] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ s, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(s + ((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4) = reg[i];
+    }
+};
+
+// Epilogue kinds (compile-time, so that the deferred epilogue is a few straight-line instructions per element; the
+// first, flag-driven version cost ~75 instructions per element = 12 us per 128x128 tile, all of it exposed).
+//   PLAIN   : Y = act(acc + bias)
+//   HN      : Y = headnorm(acc + bias) on columns < hn_cols (q | k), plain beyond (v)        [no act]
+//   GLU     : Y = silu(a + ba) * (b + bb)  |  (a + ba) * sigmoid(b + bb)   on packed column pairs
+//   GATERES : Y = (acc + bias) * gate[row group] + res          (gate optional; res may alias Y)
+enum { EPI_PLAIN = 0, EPI_HN = 1, EPI_GLU = 2, EPI_GATERES = 3 };
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sW = smem + 2 * A_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int nMb = p.M / BM, nNb = p.N / BN;             // full tiles only (launcher)
+    const int ntiles = nMb * nNb;
+    const int nk = (p.K + BK - 1) / BK;
+    const int ldy = p.ldy, ldres = p.ldres;
+
+    Loader la, lw;
+    f32x16 acc[TM][TN];
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    {
+        const int bm0 = (tile % nMb) * BM, bn0 = (tile / nMb) * BN;
+        la.load(p.A, p.lda, PD_LT(bm0), p.M, 0, p.K, tid);
+        lw.load(p.W, p.ldw, PD_LT(bn0), p.N, 0, p.K, tid);
+    }
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int bm0 = (tile % nMb) * BM, bn0 = (tile / nMb) * BN;
+        // per-lane column constants of this tile (column group j = packed columns n0 + 32 j); consumed in the epilogue
+        const int n0 = bn0 + wn * 64 + l31;
+        float c0[2], c1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            c0[j] = p.bias ? p.bias[n0 + 32 * j] : 0.f;
+            c1[j] = 1.f;
+            if constexpr (EPI == EPI_HN) c1[j] = p.hn_w[((n0 + 32 * j) / p.hn_split) * 32 + l31];
+            if constexpr (EPI == EPI_GATERES)
+                c1[j] = p.mul ? p.mul[(long long)(bm0 / p.mul_rows_per_group) * p.mul_gstride + n0 + 32 * j] : 1.f;
+        }
+        // per-tile prologue state (rows this thread stages)
+        float st_mean[4], st_rstd[4];
+        int grp_off[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { st_mean[i] = 0.f; st_rstd[i] = 1.f; grp_off[i] = 0; }
+        if constexpr (PRO != 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = bm0 + (tid >> 3) + 32 * i;
+                st_mean[i] = p.stats[2 * (long long)m];
+                st_rstd[i] = p.stats[2 * (long long)m + 1];
+                if constexpr (PRO == 2) grp_off[i] = (m / p.pro_rows_per_group) * p.pro_gstride;
+            }
+        }
+        auto transform_A = [&](int k0) {
+            if constexpr (PRO != 0) {
+                int kc = k0 + (tid & 7) * 4;
+                kc = kc < p.K ? kc : 0;
+                f32x4 pw, pb;
+                if constexpr (PRO == 1) {
+                    pw = *reinterpret_cast<const f32x4*>(p.pro_w + kc);
+                    pb = *reinterpret_cast<const f32x4*>(p.pro_b + kc);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (PRO == 2) {
+                        pw = *reinterpret_cast<const f32x4*>(p.pro_w + grp_off[i] + kc);
+                        pb = *reinterpret_cast<const f32x4*>(p.pro_b + grp_off[i] + kc);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) la.reg[i][e] = (la.reg[i][e] - st_mean[i]) * st_rstd[i] * pw[e] + pb[e];
+                }
+            }
+            if (p.pro_act == PD_ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) la.reg[i][e] = fmaxf(la.reg[i][e], 0.f);
+            } else if (p.pro_act == PD_ACT_SILU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) la.reg[i][e] = pd_silu(la.reg[i][e]);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // slice 0 of this tile is already in la/lw (requested before the previous tile's epilogue)
+        transform_A(0);
+        la.mask(bm0, p.M, 0, p.K, tid);
+        lw.mask(bn0, p.N, 0, p.K, tid);
+        __syncthreads();                     // previous tile's last slice has been read by every wave
+        la.store(sA, tid);
+        lw.store(sW, tid);
+        __syncthreads();
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nk;
+            if (more) {
+                la.load(p.A, p.lda, PD_LT(bm0), p.M, (kt + 1) * BK, p.K, tid);
+                lw.load(p.W, p.ldw, PD_LT(bn0), p.N, (kt + 1) * BK, p.K, tid);
+            }
+            const float* a = sA + cur * A_TILE;
+            const float* w = sW + cur * W_TILE;
+#pragma unroll
+            for (int g = 0; g < BK / 8; ++g) {
+                f32x4 fa[TM], fw[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + (wm * 64 + i * 32 + l31) * LDK + g * 8 + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const f32x4*>(w + (wn * 64 + j * 32 + l31) * LDK + g * 8 + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fw[j][e], acc[i][j], 0, 0, 0);
+            }
+            if (more) {
+                transform_A((kt + 1) * BK);
+                la.mask(bm0, p.M, (kt + 1) * BK, p.K, tid);
+                lw.mask(bn0, p.N, (kt + 1) * BK, p.K, tid);
+                la.store(sA + (cur ^ 1) * A_TILE, tid);
+                lw.store(sW + (cur ^ 1) * W_TILE, tid);
+                __syncthreads();
+            }
+        }
+        // request the next tile's first slice: its latency hides under this tile's epilogue
+        const int nt = tile + gridDim.x;
+        if (nt < ntiles) {
+            la.load(p.A, p.lda, PD_LT((nt % nMb) * BM), p.M, 0, p.K, tid);
+            lw.load(p.W, p.ldw, PD_LT((nt / nMb) * BN), p.N, 0, p.K, tid);
+        }
+
+        // ---- epilogue straight from the accumulator fragments: lane = column, register r = row (r&3)+8(r>>2)+4*half
+        const int yoff = hh * 4 * ldy + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = bm0 + wm * 64 + i * 32;
+            if constexpr (EPI == EPI_GLU) {
+                float* __restrict__ Yo = p.Y + (long long)mb * ldy + ((bn0 + wn * 64) >> 1);
+                if (p.glu == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], pd_silu(acc[i][0][r] + c0[0]) * (acc[i][1][r] + c0[1]));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], (acc[i][0][r] + c0[0]) * pd_sigmoid(acc[i][1][r] + c0[1]));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int ncol0 = bn0 + wn * 64 + j * 32;
+                    float* __restrict__ Yo = p.Y + (long long)mb * ldy + ncol0;
+                    if constexpr (EPI == EPI_GATERES) {
+                        const float* __restrict__ Ro = p.res + (long long)mb * ldres + ncol0;
+                        const int roff = hh * 4 * ldres + l31;
+                        float rv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rv[r] = Ro[roff + pd_frag_row(r, 0) * ldres];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], (acc[i][j][r] + c0[j]) * c1[j] + rv[r]);
+                    } else if constexpr (EPI == EPI_HN) {
+                        if (ncol0 < p.hn_cols) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[i][j][r] + c0[j];
+                                float ss = v * v;
+#pragma unroll
+                                for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+                                PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], v * rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps) * c1[j]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], acc[i][j][r] + c0[j]);
+                        }
+                    } else {
+                        if (p.act == PD_ACT_SILU) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], pd_silu(acc[i][j][r] + c0[j]));
+                        } else if (p.act == PD_ACT_NONE) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], acc[i][j][r] + c0[j]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], pd_act(acc[i][j][r] + c0[j], p.act));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// (PRO, EPI) instantiations: op 0 launch, 1 raise the dynamic-LDS limit
+template <int PRO, int EPI>
+static int run_stream(int op, const pd_gemm_args* p, hipStream_t s) {
+    auto k = gemm_stream_kernel<PRO, EPI>;
+    if (op == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    const long long ntiles = (long long)(p->M / BM) * (p->N / BN);
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(NT), LDS_BYTES, s, *p);
+    return pd_check_launch();
+}
+
+static int dispatch_stream(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s) {
+#define PD_SCASE(P, E) if (pro == P && epi == E) return run_stream<P, E>(op, p, s);
+    PD_SCASE(0, EPI_PLAIN) PD_SCASE(1, EPI_PLAIN)
+    PD_SCASE(1, EPI_HN) PD_SCASE(2, EPI_HN)
+    PD_SCASE(1, EPI_GLU) PD_SCASE(2, EPI_GLU)
+    PD_SCASE(0, EPI_GATERES)
+#undef PD_SCASE
+    return PD_ERR_UNSUPPORTED;
+}
+
+// init_only: 0 launch, 1 raise the LDS limits (pd_init), 2 query only (returns the EPI_* kind)
+// returns PD_ERR_UNSUPPORTED when the arguments are outside this kernel's scope (pd_gemm then uses gemm.hip)
+extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, void* stream, int init_only) {
+    if (init_only == 1) {
+        int rc = PD_OK;
+        for (int P = 0; P < 3; ++P)
+            for (int E = 0; E < 4; ++E) {
+                const int r = dispatch_stream(1, P, E, nullptr, nullptr);
+                if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
+            }
+        return rc;
+    }
+    const pd_gemm_args& p = *args;
+    if (p.a_kmajor || p.w_kmajor || !p.vecA || !p.vecW || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
+    if (p.M % BM != 0 || p.N % BN != 0) return PD_ERR_UNSUPPORTED;          // full tiles only
+    if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
+    int epi;
+    if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
+    else if (p.hn_w) epi = (p.mul || p.res || p.act) ? -1 : EPI_HN;
+    else if (p.res) {
+        epi = EPI_GATERES;
+        if (p.act || p.res_row_mod > 0) epi = -1;
+        if (p.mul && (p.mul_rows_per_group <= 0 || p.mul_rows_per_group % BM != 0)) epi = -1;
+    } else epi = p.mul ? -1 : EPI_PLAIN;
+    if (epi < 0) return PD_ERR_UNSUPPORTED;
+    const long long ntiles = (long long)(p.M / BM) * (p.N / BN);
+    static const long long min_tiles = [] { const char* e = getenv("PD_STREAM_MIN_TILES"); return e ? atoll(e) : 1ll; }();
+    if (ntiles < min_tiles) return PD_ERR_UNSUPPORTED;
+    if (init_only == 2) {                                     // query: epilogue kind (>= 0) of the instantiation
+        const int r = dispatch_stream(1, pro, epi, nullptr, nullptr);
+        return r == PD_OK ? epi : r;
+    }
+    return dispatch_stream(0, pro, epi, &p, (hipStream_t)stream);
+}

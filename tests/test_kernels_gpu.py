@@ -28,6 +28,101 @@ def ops():
 
 
 # ------------------------------------------------------------------ GEMM
+def _variant(ops, **kw):
+    """kernel ids pd_gemm picks (id % 10000 >= 5000: gemm_stream.hip)"""
+    import ctypes as C
+    seen = []
+    ops.GEMM_HOOK = lambda a, launch: (seen.append(ops._lib.init().pd_gemm_variant(C.byref(a))), launch())
+    return seen
+
+
+def _streamed(ops, fn):
+    seen = _variant(ops)
+    try:
+        fn()
+    finally:
+        ops.GEMM_HOOK = None
+    assert seen and min(v % 10000 for v in seen) >= 5000, seen
+
+
+@pytest.mark.parametrize("M,N,K", [(128 * 40, 128 * 26, 100), (128 * 64, 128 * 16, 40), (128 * 33, 128 * 32, 300)])
+def test_gemm_stream_bias_act_res(ops, M, N, K):
+    """large full-tile row-major problems run on the persistent kernel (gemm_stream.hip): ragged K, in-place residual,
+    activation"""
+    A = torch.randn(M, K, generator=g(1)); W = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(3)); R = torch.randn(M, N, generator=g(4))
+    Yd, Y2 = dev(R), torch.empty(M, N, device="cuda")
+    Ad, Wd, bd = dev(A), dev(W), dev(b)
+    _streamed(ops, lambda: (ops.gemm(Ad, Wd, Yd, M, N, K, bias=bd, res=Yd),
+                            ops.gemm(Ad, Wd, Y2, M, N, K, bias=bd, act=ops.ACT_SILU)))
+    ref = A @ W.T + b
+    close(Yd, ref + R, atol=1e-4)
+    close(Y2, F.silu(ref), atol=1e-4)
+
+
+@pytest.mark.parametrize("glu", [1, 2])
+def test_gemm_stream_glu_norm_prologue(ops, glu):
+    from physdock_amd.packing import pack_glu
+    M, K, Hd = 128 * 48, 96, 128 * 12 + 64
+    A = torch.randn(M, K, generator=g(1)) + 0.3
+    W1 = torch.randn(Hd, K, generator=g(2)) / 8; W3 = torch.randn(Hd, K, generator=g(3)) / 8
+    b1 = torch.randn(Hd, generator=g(4)); b3 = torch.randn(Hd, generator=g(5))
+    w = 1 + 0.1 * torch.randn(K, generator=g(6)); bb = 0.1 * torch.randn(K, generator=g(7))
+    Wp, bp = pack_glu(W1, W3, b1, b3)
+    Ad, Wd, bd, wd, bbd = dev(A), dev(Wp), dev(bp), dev(w), dev(bb)
+    stats = torch.empty(M, 2, device="cuda")
+    ops.rowstats(Ad, stats, M, K, mode=ops.LN, eps=1e-5)
+    Y = torch.empty(M, Hd, device="cuda")
+    _streamed(ops, lambda: ops.gemm(Ad, Wd, Y, M, 2 * Hd, K, stats=stats, pro_w=wd, pro_b=bbd, bias=bd, glu=glu))
+    xn = F.layer_norm(A, (K,), w, bb, 1e-5)
+    a, b = xn @ W1.T + b1, xn @ W3.T + b3
+    close(Y, F.silu(a) * b if glu == 1 else a * torch.sigmoid(b), atol=2e-4)
+
+
+def test_gemm_stream_adaln_shapes(ops):
+    """the DiT block's four GEMMs at streaming sizes: per-sample AdaLN prologue + per-head RMSNorm (q|k|v), row-group
+    gate + in-place residual (o-projection), per-sample AdaLN + SwiGLU"""
+    from physdock_amd.packing import pack_glu
+    G, rows, C = 6, 128 * 9, 128
+    M = G * rows
+    x = torch.randn(M, C, generator=g(1))
+    tab = torch.randn(G, 3 * C, generator=g(2)) * 0.3 + 1          # [shift | scale | gate] per sample
+    xd, tabd = dev(x), dev(tab)
+    stats = torch.empty(M, 2, device="cuda")
+    ops.rowstats(xd, stats, M, C, mode=ops.LN, eps=1e-5)
+    xn = F.layer_norm(x, (C,), None, None, 1e-5).reshape(G, rows, C) * tab[:, None, C:2 * C] + tab[:, None, :C]
+    grp = dict(stats=stats, pro_b=tabd, pro_w=tabd.data_ptr() + 4 * C, pro_rows_per_group=rows, pro_gstride=3 * C)
+    # q | k | v with head norm on q, k  (N = 8 * 3C so that the problem has >= 1024 tiles)
+    N = 24 * C
+    Wq = torch.randn(N, C, generator=g(3)) / 11
+    wq = 1 + 0.1 * torch.randn(32, generator=g(4)); wk = 1 + 0.1 * torch.randn(32, generator=g(5))
+    Wqd, hnd = dev(Wq), dev(torch.stack([wq, wk]))
+    Yq = torch.empty(M, N, device="cuda")
+    _streamed(ops, lambda: ops.gemm(xd, Wqd, Yq, M, N, C, hn_w=hnd, hn_cols=16 * C, hn_split=8 * C, hn_eps=1e-8, **grp))
+    y = (xn.reshape(M, C) @ Wq.T).reshape(M, 3, 8 * C // 32, 32)
+    def hn(t, w_):
+        return t * torch.rsqrt((t * t).mean(-1, keepdim=True) + 1e-8) * w_
+    close(Yq, torch.stack([hn(y[:, 0], wq), hn(y[:, 1], wk), y[:, 2]], 1).reshape(M, N), atol=2e-4)
+    # gate * (o @ Wo^T + b) + x, in place
+    No = 20 * C
+    o = torch.randn(M, C, generator=g(6)); Wo = torch.randn(No, C, generator=g(7)) / 11; bo = torch.randn(No, generator=g(8))
+    gate = torch.randn(G, 2 * No, generator=g(9)); R = torch.randn(M, No, generator=g(10))
+    od, Wod, bod, gd, Yo = dev(o), dev(Wo), dev(bo), dev(gate), dev(R)
+    _streamed(ops, lambda: ops.gemm(od, Wod, Yo, M, No, C, bias=bod, mul=gd.data_ptr() + 4 * No, mul_rows_per_group=rows,
+                                    mul_gstride=2 * No, res=Yo))
+    ref = (o @ Wo.T + bo).reshape(G, rows, No) * gate[:, None, No:] + R.reshape(G, rows, No)
+    close(Yo, ref.reshape(M, No), atol=2e-4)
+    # SwiGLU up-projection behind the per-sample AdaLN
+    Hd = 10 * C
+    W1 = torch.randn(Hd, C, generator=g(11)) / 11; W3 = torch.randn(Hd, C, generator=g(12)) / 11
+    Wp, _ = pack_glu(W1, W3, None, None)
+    Wpd = dev(Wp)
+    Yh = torch.empty(M, Hd, device="cuda")
+    _streamed(ops, lambda: ops.gemm(xd, Wpd, Yh, M, 2 * Hd, C, glu=1, **grp))
+    xf = xn.reshape(M, C)
+    close(Yh, F.silu(xf @ W1.T) * (xf @ W3.T), atol=2e-4)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 200, 72), (65, 33, 36), (1000, 16, 16), (257, 512, 512),
                                    (4096, 384, 128), (50, 24, 167), (37, 128, 7), (2048, 1408, 512), (96, 4, 8)])
 def test_gemm_plain(ops, M, N, K):
