@@ -165,6 +165,7 @@ int pd_graph_destroy(void* exec);
 /* ---- library management ------------------------------------------------------------- */
 int pd_abi_version(void);
 int pd_init(void);            /* sets per-kernel LDS limits; call once before graph capture */
+int pd_attention_occupancy(void);   /* diagnostic: resident attention blocks per CU (runtime's figure) */
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,7 @@ def _declare(L):
     i, f, p, ll = C.c_int, C.c_float, C.c_void_p, C.c_longlong
     sig("pd_abi_version")
     sig("pd_init")
+    sig("pd_attention_occupancy")
     sig("pd_gemm", C.POINTER(GemmArgs), p)
     sig("pd_gemm_variant", C.POINTER(GemmArgs))
     sig("pd_rowstats", p, p, i, i, i, i, i, f, p)

@@ -200,3 +200,10 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
     return pd_check_launch();
 }
+
+// resident blocks per CU the runtime computes for the kernel (diagnostic, tools/attn_trace.py)
+PD_EXPORT int pd_attention_occupancy(void) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_kernel, 256, 0) != hipSuccess) return PD_ERR_LAUNCH;
+    return n;
+}

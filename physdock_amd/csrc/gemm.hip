@@ -576,6 +576,25 @@ static int select_variant(pd_gemm_args& p, int& cfg, bool& akm, bool& wkm, bool&
     return cfg * 100 + (akm ? (wkm ? 2 : 1) : 0) * 10 + pro + (vec ? 0 : 1000);
 }
 
+// Ragged M for the streaming kernel: head = the whole 128-row blocks, tail = the remaining rows with every row-indexed
+// operand advanced.  Only when row groups (AdaLN prologue / gate tables) do not subdivide the rows.
+static bool split_rows(const pd_gemm_args& p, int pro, pd_gemm_args& head, pd_gemm_args& tail) {
+    const int M0 = p.M / 128 * 128;
+    if (M0 == p.M || M0 == 0 || p.batch != 1 || p.a_kmajor || p.out_mode != PD_OUT_ROWMAJOR) return false;
+    if (pro == 2 && p.pro_rows_per_group < p.M) return false;
+    if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group < p.M) return false;
+    if (p.res_row_mod > 0 || p.rowscale_acc || p.rowscale || p.maskadd) return false;
+    head = p; head.M = M0;
+    if (head.mul && head.mul_rows_per_group > 0) head.mul_rows_per_group = M0;     // one group: keep it a multiple of 64
+    tail = p; tail.M = p.M - M0;
+    tail.A += (long long)M0 * p.lda;
+    tail.Y += (long long)M0 * p.ldy;
+    if (tail.res) tail.res += (long long)M0 * p.ldres;
+    if (tail.mul && tail.mul_rows_per_group <= 0) tail.mul += (long long)M0 * p.ldmul;
+    if (tail.stats) tail.stats += 2ll * M0;
+    return true;
+}
+
 static bool use_stream() {
     static const int on = [] { const char* e = getenv("PD_GEMM_STREAM"); return e ? atoi(e) : 1; }();
     return on != 0;
@@ -588,7 +607,8 @@ PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v >= 0 && use_stream() && cfg == 0 && !p.dbg) {
-        const int epi = pd_gemm_stream_try(&p, pro, nullptr, 2);
+        pd_gemm_args head, tail;
+        const int epi = pd_gemm_stream_try(split_rows(p, pro, head, tail) ? &head : &p, pro, nullptr, 2);
         if (epi >= 0) return v + 5000 + 10000 * epi;
     }
     return v;
@@ -601,8 +621,19 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
     if (use_stream() && cfg == 0 && !p.dbg) {
-        const int r = pd_gemm_stream_try(&p, pro, stream, 0);
-        if (r != PD_ERR_UNSUPPORTED) return r;
+        pd_gemm_args head, tail;
+        if (!split_rows(p, pro, head, tail)) {
+            const int r = pd_gemm_stream_try(&p, pro, stream, 0);
+            if (r != PD_ERR_UNSUPPORTED) return r;
+        } else if (pd_gemm_stream_try(&head, pro, nullptr, 2) >= 0) {
+            // whole 128-row blocks on the streaming kernel, the ragged remainder (< 128 rows) on the general one
+            const int r = pd_gemm_stream_try(&head, pro, stream, 0);
+            if (r != PD_OK) return r;
+            int tcfg, tpro; bool takm, twkm, tvec;
+            const int tv = select_variant(tail, tcfg, takm, twkm, tvec, tpro);
+            if (tv < 0) return tv;
+            return dispatch(0, tcfg, takm, twkm, tvec, tpro, &tail, (hipStream_t)stream);
+        }
     }
     return dispatch(0, cfg, akm, wkm, vec, pro, &p, (hipStream_t)stream);
 }

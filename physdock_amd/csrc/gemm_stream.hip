@@ -14,8 +14,8 @@
 // A register-parked DEFERRED epilogue (issued inside the next tile's main loop) was built first: it needs 64 more
 // registers than the 256 available at two waves per SIMD and the compiler spills (NOTES.md).
 //
-// Scope: A [M,K] and W [N,K] row-major with 16-byte aligned rows, row-major Y, one batch, M % 128 == N % 128 == 0,
-// epilogue kinds below.  Everything else stays on gemm.hip (pd_gemm dispatches).
+// Scope: A [M,K] and W [N,K] row-major with 16-byte aligned rows, row-major Y, one batch, M % 128 == N % 128 == 0
+// (pd_gemm peels a ragged row remainder off to gemm.hip), epilogue kinds below.  Everything else stays on gemm.hip (pd_gemm dispatches).
 #include <stdlib.h>
 #include "common.h"
 #include "physdock_hip.h"
@@ -72,7 +72,92 @@ struct Loader {     // 128 rows x 32 k, [row][k] layout; thread -> rows (tid>>3)
 //   HN      : Y = headnorm(acc + bias) on columns < hn_cols (q | k), plain beyond (v)        [no act]
 //   GLU     : Y = silu(a + ba) * (b + bb)  |  (a + ba) * sigmoid(b + bb)   on packed column pairs
 //   GATERES : Y = (acc + bias) * gate[row group] + res          (gate optional; res may alias Y)
-enum { EPI_PLAIN = 0, EPI_HN = 1, EPI_GLU = 2, EPI_GATERES = 3 };
+//   TGATERES: Y = (acc + bias) * gate[row, col] + res           (gate tensor, e.g. the sigmoid gate of an attention)
+enum { EPI_PLAIN = 0, EPI_HN = 1, EPI_GLU = 2, EPI_GATERES = 3, EPI_TGATERES = 4 };
+
+// Epilogue of one 128x128 tile straight from the accumulator fragments: lane = column, register r = row
+// (r&3)+8(r>>2)+4*half.  Tiles are always full (the launcher peels ragged rows off to gemm.hip).  Addresses are
+// (uniform row pointer)[lane offset]: SGPR base + one shared 32-bit VGPR offset per array, nothing per row in VGPRs.
+template <int EPI>
+__device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&acc)[TM][TN], const float (&c0)[2],
+                                         const float (&c1)[2], int bm0, int bn0, int wm, int wn, int l31, int hh) {
+    const int ldy = p.ldy, ldres = p.ldres, ldmul = p.ldmul;
+    const int yoff = hh * 4 * ldy + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = bm0 + wm * 64 + i * 32;
+        if constexpr (EPI == EPI_GLU) {
+            float* __restrict__ Yo = p.Y + (long long)mb * ldy + ((bn0 + wn * 64) >> 1);
+            if (p.glu == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu(acc[i][0][r] + c0[0]) * (acc[i][1][r] + c0[1]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], (acc[i][0][r] + c0[0]) * pd_sigmoid(acc[i][1][r] + c0[1]));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ncol0 = bn0 + wn * 64 + j * 32;
+                float* __restrict__ Yo = p.Y + (long long)mb * ldy + ncol0;
+                if constexpr (EPI == EPI_GATERES || EPI == EPI_TGATERES) {
+                    const float* __restrict__ Ro = p.res + (long long)mb * ldres + ncol0;
+                    const int roff = hh * 4 * ldres + l31;
+                    float gv[16];
+                    if constexpr (EPI == EPI_TGATERES) {       // gate pass first: 16 loads in flight, not 32
+                        const float* __restrict__ Go = p.mul + (long long)mb * ldmul + ncol0;
+                        const int goff = hh * 4 * ldmul + l31;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gv[r] = (Go + pd_frag_row(r, 0) * ldmul)[goff];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gv[r] = (acc[i][j][r] + c0[j]) * gv[r];
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gv[r] = (acc[i][j][r] + c0[j]) * c1[j];
+                    }
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = (Ro + pd_frag_row(r, 0) * ldres)[roff];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], gv[r] + rv[r]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the 16/32 loads of one fragment from piling up with the next
+                } else if constexpr (EPI == EPI_HN) {
+                    if (ncol0 < p.hn_cols) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[i][j][r] + c0[j];
+                            float ss = v * v;
+#pragma unroll
+                            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], v * rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps) * c1[j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], acc[i][j][r] + c0[j]);
+                    }
+                } else {
+                    if (p.act == PD_ACT_SILU) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu(acc[i][j][r] + c0[j]));
+                    } else if (p.act == PD_ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], acc[i][j][r] + c0[j]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_act(acc[i][j][r] + c0[j], p.act));
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int PRO, int EPI>
 __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p) {
@@ -85,7 +170,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
     const int nMb = p.M / BM, nNb = p.N / BN;             // full tiles only (launcher)
     const int ntiles = nMb * nNb;
     const int nk = (p.K + BK - 1) / BK;
-    const int ldy = p.ldy, ldres = p.ldres;
 
     Loader la, lw;
     f32x16 acc[TM][TN];
@@ -103,13 +187,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
         // per-lane column constants of this tile (column group j = packed columns n0 + 32 j); consumed in the epilogue
         const int n0 = bn0 + wn * 64 + l31;
         float c0[2], c1[2];
+        const int gate_row = bm0 + wm * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             c0[j] = p.bias ? p.bias[n0 + 32 * j] : 0.f;
             c1[j] = 1.f;
             if constexpr (EPI == EPI_HN) c1[j] = p.hn_w[((n0 + 32 * j) / p.hn_split) * 32 + l31];
             if constexpr (EPI == EPI_GATERES)
-                c1[j] = p.mul ? p.mul[(long long)(bm0 / p.mul_rows_per_group) * p.mul_gstride + n0 + 32 * j] : 1.f;
+                c1[j] = p.mul ? p.mul[(long long)(gate_row / p.mul_rows_per_group) * p.mul_gstride + n0 + 32 * j] : 1.f;
         }
         // per-tile prologue state (rows this thread stages)
         float st_mean[4], st_rstd[4];
@@ -212,65 +297,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
             lw.load(p.W, p.ldw, PD_LT((nt / nMb) * BN), p.N, 0, p.K, tid);
         }
 
-        // ---- epilogue straight from the accumulator fragments: lane = column, register r = row (r&3)+8(r>>2)+4*half
-        const int yoff = hh * 4 * ldy + l31;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = bm0 + wm * 64 + i * 32;
-            if constexpr (EPI == EPI_GLU) {
-                float* __restrict__ Yo = p.Y + (long long)mb * ldy + ((bn0 + wn * 64) >> 1);
-                if (p.glu == 1) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], pd_silu(acc[i][0][r] + c0[0]) * (acc[i][1][r] + c0[1]));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], (acc[i][0][r] + c0[0]) * pd_sigmoid(acc[i][1][r] + c0[1]));
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int ncol0 = bn0 + wn * 64 + j * 32;
-                    float* __restrict__ Yo = p.Y + (long long)mb * ldy + ncol0;
-                    if constexpr (EPI == EPI_GATERES) {
-                        const float* __restrict__ Ro = p.res + (long long)mb * ldres + ncol0;
-                        const int roff = hh * 4 * ldres + l31;
-                        float rv[16];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) rv[r] = Ro[roff + pd_frag_row(r, 0) * ldres];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], (acc[i][j][r] + c0[j]) * c1[j] + rv[r]);
-                    } else if constexpr (EPI == EPI_HN) {
-                        if (ncol0 < p.hn_cols) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float v = acc[i][j][r] + c0[j];
-                                float ss = v * v;
-#pragma unroll
-                                for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-                                PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], v * rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps) * c1[j]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], acc[i][j][r] + c0[j]);
-                        }
-                    } else {
-                        if (p.act == PD_ACT_SILU) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], pd_silu(acc[i][j][r] + c0[j]));
-                        } else if (p.act == PD_ACT_NONE) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], acc[i][j][r] + c0[j]);
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) PD_ST(Yo[yoff + pd_frag_row(r, 0) * ldy], pd_act(acc[i][j][r] + c0[j], p.act));
-                        }
-                    }
-                }
-            }
-        }
+        epilogue<EPI>(p, acc, c0, c1, bm0, bn0, wm, wn, l31, hh);
     }
 }
 
@@ -293,7 +320,7 @@ static int dispatch_stream(int op, int pro, int epi, const pd_gemm_args* p, hipS
     PD_SCASE(0, EPI_PLAIN) PD_SCASE(1, EPI_PLAIN)
     PD_SCASE(1, EPI_HN) PD_SCASE(2, EPI_HN)
     PD_SCASE(1, EPI_GLU) PD_SCASE(2, EPI_GLU)
-    PD_SCASE(0, EPI_GATERES)
+    PD_SCASE(0, EPI_GATERES) PD_SCASE(0, EPI_TGATERES)
 #undef PD_SCASE
     return PD_ERR_UNSUPPORTED;
 }
@@ -304,7 +331,7 @@ extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, void* strea
     if (init_only == 1) {
         int rc = PD_OK;
         for (int P = 0; P < 3; ++P)
-            for (int E = 0; E < 4; ++E) {
+            for (int E = 0; E < 5; ++E) {
                 const int r = dispatch_stream(1, P, E, nullptr, nullptr);
                 if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
             }
@@ -318,9 +345,9 @@ extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, void* strea
     if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
     else if (p.hn_w) epi = (p.mul || p.res || p.act) ? -1 : EPI_HN;
     else if (p.res) {
-        epi = EPI_GATERES;
+        epi = (p.mul && p.mul_rows_per_group <= 0) ? EPI_TGATERES : EPI_GATERES;
         if (p.act || p.res_row_mod > 0) epi = -1;
-        if (p.mul && (p.mul_rows_per_group <= 0 || p.mul_rows_per_group % BM != 0)) epi = -1;
+        if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group % 64 != 0) epi = -1;   // one gate row per wave
     } else epi = p.mul ? -1 : EPI_PLAIN;
     if (epi < 0) return PD_ERR_UNSUPPORTED;
     const long long ntiles = (long long)(p.M / BM) * (p.N / BN);

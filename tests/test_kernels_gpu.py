@@ -45,7 +45,8 @@ def _streamed(ops, fn):
     assert seen and min(v % 10000 for v in seen) >= 5000, seen
 
 
-@pytest.mark.parametrize("M,N,K", [(128 * 40, 128 * 26, 100), (128 * 64, 128 * 16, 40), (128 * 33, 128 * 32, 300)])
+@pytest.mark.parametrize("M,N,K", [(128 * 40, 128 * 26, 100), (128 * 64, 128 * 16, 40), (128 * 33, 128 * 32, 300),
+                                   (128 * 70 + 37, 128 * 3, 72), (128 * 200 + 1, 128, 128)])
 def test_gemm_stream_bias_act_res(ops, M, N, K):
     """large full-tile row-major problems run on the persistent kernel (gemm_stream.hip): ragged K, in-place residual,
     activation"""
@@ -58,12 +59,17 @@ def test_gemm_stream_bias_act_res(ops, M, N, K):
     ref = A @ W.T + b
     close(Yd, ref + R, atol=1e-4)
     close(Y2, F.silu(ref), atol=1e-4)
+    # tensor gate (the sigmoid gate of an attention output) + in-place residual, gate read with a row stride
+    G = torch.randn(M, 2 * N, generator=g(5))
+    Gd, Y3 = dev(G), dev(R)
+    _streamed(ops, lambda: ops.gemm(Ad, Wd, Y3, M, N, K, bias=bd, mul=Gd.data_ptr() + 4 * N, ldmul=2 * N, res=Y3))
+    close(Y3, ref * G[:, N:] + R, atol=1e-4)
 
 
 @pytest.mark.parametrize("glu", [1, 2])
 def test_gemm_stream_glu_norm_prologue(ops, glu):
     from physdock_amd.packing import pack_glu
-    M, K, Hd = 128 * 48, 96, 128 * 12 + 64
+    M, K, Hd = 128 * 48 + 77, 96, 128 * 12 + 64          # ragged rows: whole blocks stream, the rest goes to gemm.hip
     A = torch.randn(M, K, generator=g(1)) + 0.3
     W1 = torch.randn(Hd, K, generator=g(2)) / 8; W3 = torch.randn(Hd, K, generator=g(3)) / 8
     b1 = torch.randn(Hd, generator=g(4)); b3 = torch.randn(Hd, generator=g(5))

@@ -13,9 +13,9 @@ f = glob.glob(d + "/**/p_counter_collection.csv", recursive=True)
 t = glob.glob(d + "/**/p_kernel_trace.csv", recursive=True)
 agg = {}
 for r in csv.DictReader(open(f[0])):
-    if "gemm_kernel" in r["Kernel_Name"] or "attn_kernel" in r["Kernel_Name"]:
+    if "gemm_kernel" in r["Kernel_Name"] or "gemm_stream_kernel" in r["Kernel_Name"] or "attn_kernel" in r["Kernel_Name"]:
         agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-dur = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(t[0])) if "gemm_kernel" in r["Kernel_Name"] or "attn_kernel" in r["Kernel_Name"]]
+dur = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(t[0])) if "gemm_kernel" in r["Kernel_Name"] or "gemm_stream_kernel" in r["Kernel_Name"] or "attn_kernel" in r["Kernel_Name"]]
 m = {k: sum(v) / len(v) for k, v in agg.items()}
 util = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)
 print(f"{shape:28s} MfmaUtil {util:6.3f}  wait_any/wave_cycles {m['SQ_WAIT_ANY']/m['SQ_WAVE_CYCLES']:6.3f}  lds_bank_conflict {m['SQ_LDS_BANK_CONFLICT']:10.0f}  avg_dur_us {sum(dur)/len(dur)/1e3:9.1f}")
