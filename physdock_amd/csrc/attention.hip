@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
         float mloc = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        mloc = pd_xhalf_max(mloc);
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
 #undef PD_STAMP
 
     if (query < p.nq) {
-        const float l = l_run + __shfl_xor(l_run, 32);
+        const float l = pd_xhalf_sum(l_run);
         const float inv = 1.0f / l;
         float* op = p.O + (long long)b * p.o_bs + (long long)query * p.o_ss + h * 32 + 4 * hh;
 #pragma unroll

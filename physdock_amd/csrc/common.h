@@ -49,6 +49,17 @@ __device__ __forceinline__ void pd_act4(f32x4& v, int act) {
 }
 
 // row index inside a 32x32 MFMA C fragment: lane half hh (=lane>>5), register r (0..15)
+// value held by lane ^ 32 combined with the own value, without the LDS round trip of ds_bpermute: gfx950's
+// v_permlane32_swap exchanges the upper half of one register with the lower half of another
+__device__ __forceinline__ float pd_xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pd_xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ int pd_frag_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 __device__ __forceinline__ float wave_sum(float v) {
