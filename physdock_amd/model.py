@@ -228,6 +228,17 @@ class PhysDock(nn.Module):
         tau.copy_(torch.tensor([p["tau"] for p in plan], dtype=torch.float32))
         prep = eng.prepare_dit(a, ap, s, z, batch, tau)
 
+        # Everything the step loop reads is staged in workspace buffers: a captured hipGraph replays raw addresses, so
+        # no caller-owned or per-call temporary tensor may be referenced from inside the loop.
+        def staged(name, t):
+            buf = ws.get("loop:" + name, *t.shape, dtype=t.dtype)
+            buf.copy_(t)
+            return buf
+        if conditioning is not None:
+            a, s = staged("a", a), staged("s", s)
+        batch = dict(batch)
+        for k in ("a_mask", "atom_id_to_token_id", "_tok_start"):
+            batch[k] = staged(k, batch[k])
         lig_w = ws.get("lig_w", A)
         lig_w.copy_(batch["a_mask"] * batch["is_ligand"][batch["atom_id_to_token_id"]])   # index gather: metadata
         any_align = any(p["align"] for p in plan)
@@ -239,8 +250,9 @@ class PhysDock(nn.Module):
             if ref_mol_poses is not None:
                 lig_idx = torch.nonzero(batch["is_ligand"][batch["atom_id_to_token_id"]] > 0).flatten().to(torch.int32)
                 n_lig = int(lig_idx.numel())
+                lig_idx = staged("lig_idx", lig_idx)
                 if ref_mol_poses.shape[1] == n_lig:      # mismatch: reference silently keeps ref_pos (model.py:229-243)
-                    poses = ref_mol_poses.to(device).float().contiguous()
+                    poses = staged("poses", ref_mol_poses.to(device).float())
                     n_conf = poses.shape[0]
                     ref_dist = ws.get("ref_dist", n_conf, n_lig, n_lig)
                     ops.check(L.pd_pose_dist(ops.ptr(poses), ops.ptr(ref_dist), n_conf, n_lig, sp), "pose_dist")
@@ -331,7 +343,7 @@ class PhysDock(nn.Module):
             eng.lane = 0
 
         if use_graph:
-            key = (B, A, batch["target_feat"].shape[0], steps, noise is not None, poses is not None and n_conf, n_lanes,
+            key = (B, A, batch["target_feat"].shape[0], steps, noise is not None, poses is not None and (n_conf, n_lig), n_lanes,
                    tuple((p["t_hat"], p["align"], p["eta"]) for p in plan), float(noise_scale_lambda), sample_offset)
             g = self._graphs.get(key)
             if g is None:

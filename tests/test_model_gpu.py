@@ -274,3 +274,68 @@ def test_token_without_atoms(small_model_inputs):
     xd = torch.empty(2, A, 3, device="cuda")
     eng.af3_dit(pb, x_hat.cuda().contiguous(), xd, cond[0], cond[2], prep, 2, scal, row=0)
     assert float((xd.cpu() - ref).abs().max()) < 3e-4 * float(ref.abs().max())
+
+
+def test_driver_template_scores_match_golden():
+    """driver.template_scores / select_reference_templates = redocking.py:326-335 (golden set G7)"""
+    from physdock_amd import driver
+    g = load_golden("g7_reselect")
+    lp, poses = g["ligand_poses"].cuda(), g["ref_mol_poses"].cuda()
+    idx = torch.arange(lp.shape[1], dtype=torch.int32, device="cuda")
+    eps = driver.template_scores(lp, idx, poses)
+    torch.testing.assert_close(eps.cpu(), g["eps_bc"], atol=2e-6, rtol=1e-5)
+    k = len(g["order"]) // 2
+    assert torch.equal(driver.select_reference_templates(lp, idx, poses, k).cpu(), g["order"][:k])
+
+
+def test_driver_redock_rounds_on_device(small):
+    """the whole round loop (redocking.py:156-342) on the small model: three physics rounds with a deterministic
+    accept rule, template pool fed back into the sampler, final poses in the ground-truth frame, ranking"""
+    from physdock_amd import driver
+    from physdock_amd.synthetic import reference_conformers
+    model, cfg, P, batch, dbatch = small
+    confs = reference_conformers(batch, n_conf=6).cuda()
+    db = dict(dbatch)
+    db["batch_msa_feat"] = torch.stack([dbatch["msa_feat"] * (1.0 if r % 2 == 0 else 0.5) for r in range(4)])
+    seen = []
+
+    def accept(x):                      # rejects the first pose of every round
+        seen.append(x)
+        return len(seen) % 3 != 1
+    out = driver.redock(model, db, ref_mol_poses=confs, accept_fn=accept, physics_correction=True, max_samples=5,
+                        max_rounds=4, num_samples_per_round=3, steps=6, seed=11)
+    assert [r["accepted"] for r in out["rounds"]] == [2, 2, 2] and out["accepted"] == 6
+    assert [r["templates"] for r in out["rounds"]] == [0, 5, 5]
+    assert out["poses"].shape == (5, batch["ref_pos"].shape[0], 3) and torch.isfinite(out["poses"]).all()
+    # poses are in the ground-truth frame: re-aligning them changes nothing
+    from physdock_amd import weighted_rigid_align
+    w = driver.pocket_align_weights(db)
+    again = weighted_rigid_align(db["x_gt"][None].expand(5, -1, -1).contiguous(), out["poses"], w)
+    assert rmsd(again.cpu(), out["poses"].cpu()) < 1e-3
+    assert len(out["ranking"]["order"]) == 5 and all(r >= 0 for r in out["ranking"]["rmsd"])
+    # same seeds, same verdicts -> same poses
+    seen.clear()
+    out2 = driver.redock(model, db, ref_mol_poses=confs, accept_fn=accept, physics_correction=True, max_samples=5,
+                         max_rounds=4, num_samples_per_round=3, steps=6, seed=11)
+    assert torch.equal(out["poses"], out2["poses"])
+
+
+def test_graph_replay_is_independent_of_caller_tensors(small):
+    """a captured step loop replays raw addresses: inputs of a later call (another system of the same shape, other
+    reference conformers) must reach it although the first call's tensors are gone"""
+    from physdock_amd.synthetic import reference_conformers
+    model, cfg, P, batch, dbatch = small
+    kw = dict(num_sample=3, steps=6, karras_noise_schedule_power=1000, align_ref_pos=True, use_ref_mol_poses=True,
+              mmff_gamma_0_factor=2.0, seed=5)
+    c1 = reference_conformers(batch, n_conf=4, seed=1).cuda()
+    x1 = model.sample_diffusion({k: v.clone() for k, v in dbatch.items()}, ref_mol_poses=c1.clone(), use_graph=True, **kw)
+    junk = [torch.randn(1 << 16, device="cuda") for _ in range(8)]                 # perturb the caching allocator
+    db2 = {k: v.clone() for k, v in dbatch.items()}
+    db2["ref_pos"] = db2["ref_pos"] * 1.05
+    db2["a_mask"] = db2["a_mask"].clone(); db2["a_mask"][3] = 0                     # same shapes, other content
+    c2 = reference_conformers(batch, n_conf=4, seed=2).cuda()
+    x2g = model.sample_diffusion(db2, ref_mol_poses=c2, use_graph=True, **kw)       # replays the graph of call 1
+    x2e = model.sample_diffusion(db2, ref_mol_poses=c2, use_graph=False, **kw)
+    assert rmsd(x2g.cpu(), x2e.cpu()) < 1e-4
+    assert rmsd(x2g.cpu(), x1.cpu()) > 1e-3
+    del junk
