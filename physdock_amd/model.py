@@ -59,6 +59,9 @@ class PhysDock(nn.Module):
         self._engine: Optional[Engine] = None
         self._graphs = {}
         self._side_streams = []
+        #: workspace buffers are cached per shape (288 GB of HBM make re-allocation pointless for a stream of
+        #: same-size crops); when systems of many different sizes pass through, the cache is dropped beyond this size
+        self.workspace_limit_bytes = 160 * 2 ** 30
         self.register_load_state_dict_post_hook(lambda m, k: m._invalidate())
 
     # ------------------------------------------------------------------ plumbing
@@ -68,6 +71,15 @@ class PhysDock(nn.Module):
         for g in self._graphs.values():
             ops._lib.lib().pd_graph_destroy(g["exec"])
         self._graphs = {}
+
+    def release_workspace(self):
+        """free every cached activation buffer and captured step-loop graph (they are rebuilt on the next call)"""
+        for g in self._graphs.values():
+            ops._lib.lib().pd_graph_destroy(g["exec"])
+        self._graphs = {}
+        if self._engine is not None:
+            torch.cuda.synchronize(self._engine.device)
+            self._engine.ws.bufs.clear()
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -204,6 +216,8 @@ class PhysDock(nn.Module):
         """reference models/model.py:157-282.  Returns x_next [num_sample, A, 3] on the batch device."""
         device = batch["x_gt"].device
         eng = self.engine(device)
+        if eng.ws.nbytes() > self.workspace_limit_bytes:
+            self.release_workspace()
         batch = self._prepare_batch(batch)
         L = ops._lib.init()
         ws = eng.ws
@@ -373,6 +387,8 @@ class PhysDock(nn.Module):
         conditioning -> 48 noised copies (per-sample noise level) -> denoiser -> distogram logits."""
         device = batch["x_gt"].device
         eng = self.engine(device)
+        if eng.ws.nbytes() > self.workspace_limit_bytes:
+            self.release_workspace()
         batch = self._prepare_batch(batch)
         L = ops._lib.init()
         ws = eng.ws

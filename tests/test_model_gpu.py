@@ -339,3 +339,20 @@ def test_graph_replay_is_independent_of_caller_tensors(small):
     assert rmsd(x2g.cpu(), x2e.cpu()) < 1e-4
     assert rmsd(x2g.cpu(), x1.cpu()) > 1e-3
     del junk
+
+
+def test_workspace_release_rebuilds_buffers_and_graphs(small):
+    model, cfg, P, batch, dbatch = small
+    kw = dict(num_sample=2, steps=5, karras_noise_schedule_power=1000, align_ref_pos=False, seed=9, use_graph=True)
+    x1 = model.sample_diffusion(dbatch, **kw)
+    assert model._graphs and model.engine(torch.device("cuda", 0)).ws.nbytes() > 0
+    model.release_workspace()
+    assert not model._graphs and model.engine(torch.device("cuda", 0)).ws.nbytes() == 0
+    old = model.workspace_limit_bytes
+    try:
+        model.workspace_limit_bytes = 1                     # every call starts from an empty cache
+        x2 = model.sample_diffusion(dbatch, **kw)
+        x3 = model.sample_diffusion(dbatch, **kw)
+    finally:
+        model.workspace_limit_bytes = old
+    assert torch.equal(x1, x2) and torch.equal(x1, x3)
