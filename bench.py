@@ -143,7 +143,9 @@ class LaunchTimer:
         def attn(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); r = self._orig_attn(*a, **k); e1.record()
-            self._add("attn_kernel", e0, e1, 4.0 * k["nbatch"] * k["nheads"] * k["nq"] * k["nk"] * 32)
+            c = k["nheads"] * 32                 # q, o: nq rows; k, v: nk rows; the bias tile set is read once per launch
+            byt = 4.0 * k["nbatch"] * c * (2 * k["nq"] + 2 * k["nk"]) + (4.0 * k["nheads"] * k["nq"] * k["nk"] if k.get("bias") is not None else 0.0)
+            self._add("attn_kernel", e0, e1, 4.0 * k["nbatch"] * k["nheads"] * k["nq"] * k["nk"] * 32, byt)
             return r
         ops.GEMM_HOOK = gemm_hook
         ops.attention = attn
