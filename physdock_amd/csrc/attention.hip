@@ -19,6 +19,7 @@
 //     batch index; batch is the fastest grid dimension so the blocks that share a bias tile
 //     run together and the tile is served from L2 / Infinity Cache (the step- and
 //     sample-invariant biases of the DiT are hoisted out of the loop entirely).
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 #include "physdock_hip.h"
@@ -29,14 +30,17 @@ constexpr int KT = 64;      // keys per LDS tile
 constexpr int LDKS = 36;    // K row stride (floats): conflict-free ds_read_b128
 constexpr int LDVS = 32;    // V row stride
 
-__global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
+// NW = waves (32-query tiles) per block: 4, or 8 for long query ranges - the K/V tiles staged through LDS are then shared
+// by twice as many MFMAs (half the global-load / LDS-write traffic per flop), at the same 4 waves per SIMD.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) {
     __shared__ __attribute__((aligned(16))) float sK[2][KT * LDKS];
     __shared__ __attribute__((aligned(16))) float sV[2][KT * LDVS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int b = blockIdx.x, qb = blockIdx.y, h = blockIdx.z;
-    const int q0 = qb * 128 + wave * 32;
+    const int q0 = qb * (32 * NW) + wave * 32;
     const int query = q0 + l31;
     const bool wave_active = q0 < p.nq;
 
@@ -67,13 +71,15 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging: thread -> key row (tid>>3)+32*i, 16-byte chunk tid&7
+    // staging: thread -> key row (tid>>3)+RPP*i, 16-byte chunk tid&7
+    constexpr int RPP = 8 * NW;            // key rows covered per pass of the block
+    constexpr int NST = KT / RPP;          // passes per 64-key tile (2 for 4 waves, 1 for 8)
     const int srow = tid >> 3, schunk = (tid & 7) * 4;
-    f32x4 rk[2], rv[2];
+    f32x4 rk[NST], rv[NST];
     auto gload = [&](int key0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = key0 + srow + 32 * i;
+        for (int i = 0; i < NST; ++i) {
+            const int key = key0 + srow + RPP * i;
             rk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (key < p.nk) {
@@ -84,9 +90,9 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
     };
     auto sstore = [&](int st) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f32x4*>(&sK[st][(srow + 32 * i) * LDKS + schunk]) = rk[i];
-            *reinterpret_cast<f32x4*>(&sV[st][(srow + 32 * i) * LDVS + schunk]) = rv[i];
+        for (int i = 0; i < NST; ++i) {
+            *reinterpret_cast<f32x4*>(&sK[st][(srow + RPP * i) * LDKS + schunk]) = rk[i];
+            *reinterpret_cast<f32x4*>(&sV[st][(srow + RPP * i) * LDVS + schunk]) = rv[i];
         }
     };
 
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const pd_attn_args p) {
     };
     const int nfull32 = p.nk >> 5;                 // sub-tiles with all 32 keys in range
     unsigned long long* dbg = nullptr;             // optional phase trace (tools/attn_trace.py)
-    if (p.dbg && lane == 0 && blockIdx.x < 8 && blockIdx.y < 2 && blockIdx.z == 0)
+    if (p.dbg && lane == 0 && blockIdx.x < 8 && blockIdx.y < 2 && blockIdx.z == 0 && wave < 4)
         dbg = reinterpret_cast<unsigned long long*>(p.dbg) + (((long long)blockIdx.y * 8 + blockIdx.x) * 4 + wave) * (4 * 64);
 #define PD_STAMP(slot) if (dbg && it < 64) dbg[it * 4 + slot] = __builtin_amdgcn_s_memtime()
 
@@ -196,14 +202,21 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     for (long long s : strides) if (s % 4) return PD_ERR_UNSUPPORTED;
     if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O | (uintptr_t)a->bias) & 15)
         return PD_ERR_UNSUPPORTED;
-    dim3 grid(a->nbatch, (a->nq + 127) / 128, a->nheads);
-    hipLaunchKernelGGL(attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
+    // 8-wave blocks pay off (+2 %) when they still fill the chip twice over; short query ranges / few batches keep 4 waves
+    if (wide && a->nq >= 512 && (long long)a->nbatch * a->nheads * ((a->nq + 255) / 256) >= 1024) {
+        dim3 grid(a->nbatch, (a->nq + 255) / 256, a->nheads);
+        hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, *a);
+    } else {
+        dim3 grid(a->nbatch, (a->nq + 127) / 128, a->nheads);
+        hipLaunchKernelGGL(attn_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    }
     return pd_check_launch();
 }
 
 // resident blocks per CU the runtime computes for the kernel (diagnostic, tools/attn_trace.py)
 PD_EXPORT int pd_attention_occupancy(void) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_kernel, 256, 0) != hipSuccess) return PD_ERR_LAUNCH;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_kernel<4>, 256, 0) != hipSuccess) return PD_ERR_LAUNCH;
     return n;
 }
