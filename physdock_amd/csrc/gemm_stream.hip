@@ -11,6 +11,8 @@
 //   * SGPR base pointers + 32-bit lane offsets,
 //   * a block walks several output tiles; the first k-slice of the next tile and the per-column constants are
 //     requested before the epilogue of the current one, so their latency hides under it.
+//   * the persistent grid walks the tiles in XCD-aware patches (struct TileOrder) so that A / W panels are shared
+//     through each XCD's L2 instead of being re-fetched per column block.
 // A register-parked DEFERRED epilogue (issued inside the next tile's main loop) was built first: it needs 64 more
 // registers than the 256 available at two waves per SIMD and the compiler spills (NOTES.md).
 //
@@ -66,8 +68,8 @@ struct Loader {     // 128 rows x 32 k, [row][k] layout; thread -> rows (tid>>3)
     }
 };
 
-// Epilogue kinds (compile-time, so that the deferred epilogue is a few straight-line instructions per element; the
-// first, flag-driven version cost ~75 instructions per element = 12 us per 128x128 tile, all of it exposed).
+// Epilogue kinds (compile-time, so that the epilogue is a few straight-line instructions per element; a flag-driven
+// fragment epilogue cost ~75 instructions per element = 12 us per 128x128 tile).
 //   PLAIN   : Y = act(acc + bias)
 //   HN      : Y = headnorm(acc + bias) on columns < hn_cols (q | k), plain beyond (v)        [no act]
 //   GLU     : Y = silu(a + ba) * (b + bb)  |  (a + ba) * sigmoid(b + bb)   on packed column pairs
