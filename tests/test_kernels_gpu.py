@@ -338,3 +338,62 @@ def test_attention_strided_column(ops):
         return t.reshape(T, S, H, 32).transpose(1, 2)
     ref = ref_attention(heads(x[..., :C]), heads(x[..., C:2 * C]), heads(x[..., 2 * C:]), None)
     close(o, ref.transpose(1, 2).reshape(T, S, C).transpose(0, 1), atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_gemm_dispatch_fuzz(ops, seed):
+    """random shapes / epilogue combinations through pd_gemm's dispatcher (tile choice, streaming kernel, ragged-row
+    split) against torch"""
+    import random
+    rnd = random.Random(seed)
+    from physdock_amd.packing import pack_glu
+    M = rnd.choice([1, 37, 128, 129, 640, 1000, 128 * 9, 128 * 9 + 5, 128 * 200 + 3, 128 * 260])
+    K = rnd.choice([4, 36, 64, 100, 128, 384])
+    kind = rnd.choice(["plain", "act", "res", "gate_res", "tgate_res", "glu", "norm_plain", "norm_glu"])
+    Nb = rnd.choice([32, 128, 256, 384, 512])
+    gen = g(100 + seed)
+    A = torch.randn(M, K, generator=gen) + 0.2
+    b = torch.randn(Nb, generator=gen)
+    Ad = dev(A)
+    kw, ref_in = {}, A
+    if kind.startswith("norm"):
+        w = 1 + 0.1 * torch.randn(K, generator=gen); bb = 0.1 * torch.randn(K, generator=gen)
+        stats = torch.empty(M, 2, device="cuda")
+        ops.rowstats(Ad, stats, M, K, mode=ops.LN, eps=1e-5)
+        wd, bbd = dev(w), dev(bb)
+        kw.update(stats=stats, pro_w=wd, pro_b=bbd)
+        ref_in = F.layer_norm(A, (K,), w, bb, 1e-5)
+    if kind.endswith("glu"):
+        W1 = torch.randn(Nb, K, generator=gen) / math.sqrt(K); W3 = torch.randn(Nb, K, generator=gen) / math.sqrt(K)
+        Wp, _ = pack_glu(W1, W3, None, None)
+        Wd = dev(Wp)
+        Y = torch.empty(M, Nb, device="cuda")
+        ops.gemm(Ad, Wd, Y, M, 2 * Nb, K, glu=1, **kw)
+        close(Y, F.silu(ref_in @ W1.T) * (ref_in @ W3.T), atol=3e-4, rtol=1e-4)
+        return
+    W = torch.randn(Nb, K, generator=gen) / math.sqrt(K)
+    Wd, bd = dev(W), dev(b)
+    ref = ref_in @ W.T + b
+    R = torch.randn(M, Nb, generator=gen)
+    if kind in ("plain", "norm_plain"):
+        Y = torch.empty(M, Nb, device="cuda")
+        ops.gemm(Ad, Wd, Y, M, Nb, K, bias=bd, **kw)
+    elif kind == "act":
+        Y = torch.empty(M, Nb, device="cuda")
+        ops.gemm(Ad, Wd, Y, M, Nb, K, bias=bd, act=ops.ACT_SILU)
+        ref = F.silu(ref)
+    elif kind == "res":
+        Y = dev(R)
+        ops.gemm(Ad, Wd, Y, M, Nb, K, bias=bd, res=Y)
+        ref = ref + R
+    elif kind == "gate_res":
+        gate = torch.randn(1, Nb, generator=gen); gd = dev(gate)
+        Y = dev(R)
+        ops.gemm(Ad, Wd, Y, M, Nb, K, bias=bd, mul=gd, mul_rows_per_group=M, mul_gstride=0, res=Y)
+        ref = ref * gate + R
+    else:
+        G = torch.randn(M, Nb, generator=gen); Gd = dev(G)
+        Y = dev(R)
+        ops.gemm(Ad, Wd, Y, M, Nb, K, bias=bd, mul=Gd, ldmul=Nb, res=Y)
+        ref = ref * G + R
+    close(Y, ref, atol=3e-4, rtol=1e-4)
