@@ -303,7 +303,8 @@ def ref_attention(q, k, v, bias):
 
 @pytest.mark.parametrize("B,H,nq,nk,use_bias", [(2, 4, 128, 128, True), (3, 2, 96, 96, True), (1, 4, 300, 300, True),
                                                 (5, 1, 24, 24, True), (2, 8, 40, 8, False), (1, 16, 256, 256, True),
-                                                (2, 4, 70, 333, True), (3, 2, 2048, 2048, True)])
+                                                (2, 4, 70, 333, True), (3, 2, 2048, 2048, True),
+                                                (64, 4, 1000, 1000, True), (32, 8, 1024, 520, False)])     # 8-wave blocks
 def test_attention(ops, B, H, nq, nk, use_bias):
     C = H * 32
     q = torch.randn(B, nq, C, generator=g(1)); k = torch.randn(B, nk, C, generator=g(2))
