@@ -4,7 +4,11 @@ RCCL over xGMI on MI355X, "gloo" in the CPU tests).
 Diffusion samples are independent given the conditioning (reference model.py:211-281 has no
 cross-sample op), so ranks own contiguous blocks of global sample ids, recompute the trunk
 redundantly (no data-path collective) and send their poses to rank 0 with ONE gather for
-ranking (the consumer of the poses is redocking.py:357-423)."""
+ranking (the consumer of the poses is redocking.py:357-423).
+
+Many independent systems (the full benchmark, or one receptor x many ligands in screening.py) shard the other way:
+whole systems are dealt to the ranks, each rank runs every sample of its systems, and only small per-system results
+travel (`map_systems`)."""
 from __future__ import annotations
 
 import torch
@@ -46,3 +50,40 @@ def sample_diffusion_parallel(model, batch, num_sample: int, **kw):
     lo, hi = shard_range(num_sample, dist.get_rank(), dist.get_world_size())
     x = model.sample_diffusion(batch, num_sample=hi - lo, sample_offset=kw.pop("sample_offset", 0) + lo, **kw)
     return gather_poses(x, num_sample)
+
+
+def system_shard(n_systems: int, rank: int, world: int, costs=None):
+    """Indices of the systems `rank` processes.  Without costs: round-robin (system i -> rank i % world, so a stream
+    sorted by size stays balanced).  With per-system costs (e.g. atoms^2): greedy longest-processing-time assignment,
+    identical on every rank (deterministic, no communication)."""
+    if costs is None:
+        return list(range(rank, n_systems, world))
+    order = sorted(range(n_systems), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    mine = []
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += float(costs[i])
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
+
+
+def map_systems(fn, systems, costs=None, dst: int = 0):
+    """Run `fn(system)` for this rank's share of `systems` (by-system / by-ligand sharding: BASELINE configs 3 and 5)
+    and collect the picklable results on `dst` in the original order (None on the other ranks).  One
+    `gather_object` at the end; the systems themselves never move."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [fn(s) for s in systems]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = system_shard(len(systems), rank, world, costs)
+    local = [(i, fn(systems[i])) for i in mine]
+    bufs = [None] * world if rank == dst else None
+    dist.gather_object(local, bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = [None] * len(systems)
+    for part in bufs:
+        for i, r in part:
+            out[i] = r
+    return out

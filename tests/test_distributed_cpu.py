@@ -22,11 +22,17 @@ def _worker(rank, world, port, num_sample, results):
     x = FakeModel().sample_diffusion(None, hi - lo, sample_offset=lo)
     full = gather_poses(x, num_sample)
     full2 = sample_diffusion_parallel(FakeModel(), None, num_sample)
+    from physdock_amd.parallel import map_systems
+    systems = list(range(11))
+    res = map_systems(lambda s: {"system": s, "rank": rank, "score": s * s}, systems)
+    res_c = map_systems(lambda s: (s, rank), systems, costs=[1, 9, 1, 1, 1, 1, 1, 1, 1, 1, 5])
     if rank == 0:
         ok = torch.equal(full[:, 0, 0], torch.arange(num_sample, dtype=torch.float32)) and torch.equal(full, full2)
+        ok = ok and [r["system"] for r in res] == systems and [r["rank"] for r in res] == [i % world for i in systems]
+        ok = ok and [r[0] for r in res_c] == systems and res_c[1][1] != res_c[10][1]       # the two heavy systems are split
         results.put(bool(ok))
     else:
-        assert full is None and full2 is None
+        assert full is None and full2 is None and res is None and res_c is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -39,6 +45,19 @@ def test_shard_ranges_partition():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_system_shard_is_a_partition_and_balances():
+    from physdock_amd.parallel import system_shard
+    for n in (0, 1, 5, 16):
+        for w in (1, 2, 3, 8):
+            parts = [system_shard(n, r, w) for r in range(w)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+    costs = [100, 1, 1, 1, 1, 1, 1, 1, 1, 90, 5, 5]
+    parts = [system_shard(len(costs), r, 2, costs) for r in range(2)]
+    assert sorted(i for p in parts for i in p) == list(range(len(costs)))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 10
 
 
 def test_gather_world2_gloo():
