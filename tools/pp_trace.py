@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Phase trace of the ping-pong GEMM (build with PP_TRACE=1, run with PD_GEMM_PP=1)."""
+"""Phase trace of the ping-pong GEMM experiment: apply tools/experiments/pingpong_gemm.patch first, build with
+PP_TRACE=1 (python -m physdock_amd.build --force), run with PD_GEMM_PP=1.  Results are recorded in NOTES.md."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
