@@ -138,22 +138,20 @@ class LaunchTimer:
             n_out = a.N // 2 if a.glu else a.N
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))
             self._add(name, e0, e1, 2.0 * a.M * a.N * a.K * nb, byt)
-        self._orig_attn = ops.attention
-
-        def attn(*a, **k):
+        def attn_hook(a, launch):
+            name = "attn_kernel<%d>" % L.pd_attention_variant(C.byref(a))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); r = self._orig_attn(*a, **k); e1.record()
-            c = k["nheads"] * 32                 # q, o: nq rows; k, v: nk rows; the bias tile set is read once per launch
-            byt = 4.0 * k["nbatch"] * c * (2 * k["nq"] + 2 * k["nk"]) + (4.0 * k["nheads"] * k["nq"] * k["nk"] if k.get("bias") is not None else 0.0)
-            self._add("attn_kernel", e0, e1, 4.0 * k["nbatch"] * k["nheads"] * k["nq"] * k["nk"] * 32, byt)
-            return r
+            e0.record(); launch(); e1.record()
+            c = a.nheads * 32                    # q, o: nq rows; k, v: nk rows; the bias tile set is read once per launch
+            byt = 4.0 * a.nbatch * c * (2 * a.nq + 2 * a.nk) + (4.0 * a.nheads * a.nq * a.nk if a.bias else 0.0)
+            self._add(name, e0, e1, 4.0 * a.nbatch * a.nheads * a.nq * a.nk * 32, byt)
         ops.GEMM_HOOK = gemm_hook
-        ops.attention = attn
+        ops.ATTN_HOOK = attn_hook
         return self
 
     def __exit__(self, *e):
         self.ops.GEMM_HOOK = None
-        self.ops.attention = self._orig_attn
+        self.ops.ATTN_HOOK = None
 
     def summary(self):
         torch.cuda.synchronize()

@@ -99,6 +99,8 @@ typedef struct pd_attn_args {
     void* dbg;               /* optional phase-trace buffer (tools/attn_trace.py); NULL in production */
 } pd_attn_args;
 int pd_attention(const pd_attn_args* args, void* stream);
+/* waves per block (4 or 8 = template argument of attn_kernel) pd_attention picks for these arguments (profiling) */
+int pd_attention_variant(const pd_attn_args* args);
 
 /* ---- pair-representation / pooling kernels (pair.hip) ----------------------------------
  * pd_atom_pair_init : ap = cl_l + cm_m + v*(Wp.d + Wd/(1+|d|) + Wv)   (diffusion_conditioning.py:116-124)

@@ -95,6 +95,7 @@ def _declare(L):
     sig("pd_rowstats", p, p, i, i, i, i, i, f, p)
     sig("pd_rownorm", p, p, p, p, p, i, i, i, f, i, p)
     sig("pd_attention", C.POINTER(AttnArgs), p)
+    sig("pd_attention_variant", C.POINTER(AttnArgs))
     sig("pd_graph_begin", p)
     sig("pd_graph_end", p, C.POINTER(C.c_void_p))
     sig("pd_graph_launch", p, p)

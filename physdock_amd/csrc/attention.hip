@@ -39,6 +39,10 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
+    // Batch is the fastest grid dimension, so the blocks that share a bias tile and the query blocks that share the K/V
+    // panels of one (batch, head) are resident together.  Two XCD-aware remappings of the block index (whole (query
+    // block, head) groups per XCD, interleaved or contiguous) were measured: both raise the fetch traffic of the DiT atom
+    // attention from 433 to 637 MB (FETCH_SIZE) at unchanged run time, so the plain order stays.
     const int b = blockIdx.x, qb = blockIdx.y, h = blockIdx.z;
     const int q0 = qb * (32 * NW) + wave * 32;
     const int query = q0 + l31;
@@ -194,6 +198,14 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) 
 
 }  // namespace
 
+// waves per block pd_attention uses for these arguments (= template argument of attn_kernel; for profiling)
+PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
+    if (!a) return PD_ERR_ARG;
+    static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
+    // 8-wave blocks pay off (+2 %) when they still fill the chip twice over; short query ranges / few batches keep 4 waves
+    return (wide && a->nq >= 512 && (long long)a->nbatch * a->nheads * ((a->nq + 255) / 256) >= 1024) ? 8 : 4;
+}
+
 PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     if (!a || !a->Q || !a->K || !a->V || !a->O) return PD_ERR_ARG;
     if (a->nq <= 0 || a->nk <= 0 || a->nbatch <= 0 || a->nheads <= 0) return PD_ERR_ARG;
@@ -202,9 +214,7 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     for (long long s : strides) if (s % 4) return PD_ERR_UNSUPPORTED;
     if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O | (uintptr_t)a->bias) & 15)
         return PD_ERR_UNSUPPORTED;
-    static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
-    // 8-wave blocks pay off (+2 %) when they still fill the chip twice over; short query ranges / few batches keep 4 waves
-    if (wide && a->nq >= 512 && (long long)a->nbatch * a->nheads * ((a->nq + 255) / 256) >= 1024) {
+    if (pd_attention_variant(a) == 8) {
         dim3 grid(a->nbatch, (a->nq + 255) / 256, a->nheads);
         hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, *a);
     } else {

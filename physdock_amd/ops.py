@@ -78,6 +78,7 @@ GEMM_DBG = None
 
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None
+ATTN_HOOK = None
 
 
 def rowstats(x, stats, M, Cdim, *, ldx=None, kmajor=False, mode=RMS, eps=1e-8):
@@ -107,6 +108,8 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
     a.scale = scale
     if ATTN_DBG is not None:
         a.dbg = ATTN_DBG.data_ptr()
+    if ATTN_HOOK is not None:
+        return ATTN_HOOK(a, lambda: check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention"))
     check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention")
 
 
