@@ -258,7 +258,7 @@ def main():
                            "flop_per_launch": dom["flop_per_launch"], "traffic": traffic,
                            "algorithmic_bytes_per_launch": dom.get("algorithmic_bytes_per_launch"), "traffic_source": traffic_src,
                            "note": "algorithmic flops = 2*M*N*K per GEMM launch (4*B*H*Nq*Nk*32 per attention launch)"}
-        out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in summ[:4]]
+        out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()} for d in summ[:8]]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, P, batch, confs, args)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
