@@ -520,10 +520,10 @@ inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 }  // namespace
 
 // gemm_stream.hip: persistent variant with a direct-from-fragment epilogue for large full-tile row-major problems
-extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, void* stream, int init_only);
+extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only);
 
 PD_EXPORT int pd_init(void) {
-    int rc = pd_gemm_stream_try(nullptr, 0, nullptr, 1);
+    int rc = pd_gemm_stream_try(nullptr, 0, 0, nullptr, 1);
     for (int cfg = 0; cfg < 4; ++cfg)
         for (int lay = 0; lay < 3; ++lay)
             for (int vec = 0; vec < 2; ++vec)
@@ -576,10 +576,10 @@ static int select_variant(pd_gemm_args& p, int& cfg, bool& akm, bool& wkm, bool&
     return cfg * 100 + (akm ? (wkm ? 2 : 1) : 0) * 10 + pro + (vec ? 0 : 1000);
 }
 
-// Ragged M for the streaming kernel: head = the whole 128-row blocks, tail = the remaining rows with every row-indexed
+// Ragged M for the streaming kernel: head = the whole row blocks of the tile size, tail = the remaining rows with every row-indexed
 // operand advanced.  Only when row groups (AdaLN prologue / gate tables) do not subdivide the rows.
-static bool split_rows(const pd_gemm_args& p, int pro, pd_gemm_args& head, pd_gemm_args& tail) {
-    const int M0 = p.M / 128 * 128;
+static bool split_rows(const pd_gemm_args& p, int pro, int tile, pd_gemm_args& head, pd_gemm_args& tail) {
+    const int M0 = p.M / tile * tile;
     if (M0 == p.M || M0 == 0 || p.batch != 1 || p.a_kmajor || p.out_mode != PD_OUT_ROWMAJOR) return false;
     if (pro == 2 && p.pro_rows_per_group < p.M) return false;
     if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group < p.M) return false;
@@ -595,6 +595,9 @@ static bool split_rows(const pd_gemm_args& p, int pro, pd_gemm_args& head, pd_ge
     return true;
 }
 
+// block tile of gemm_stream.hip that corresponds to a tile configuration of this file (0 = none)
+static int stream_tile(int cfg) { return cfg == 0 ? 128 : cfg == 3 ? 64 : 0; }
+
 static bool use_stream() {
     static const int on = [] { const char* e = getenv("PD_GEMM_STREAM"); return e ? atoi(e) : 1; }();
     return on != 0;
@@ -606,9 +609,10 @@ PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     pd_gemm_args p = *args;
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
-    if (v >= 0 && use_stream() && cfg == 0 && !p.dbg) {
+    if (v >= 0 && use_stream() && stream_tile(cfg) && !p.dbg) {
         pd_gemm_args head, tail;
-        const int epi = pd_gemm_stream_try(split_rows(p, pro, head, tail) ? &head : &p, pro, nullptr, 2);
+        const int tile = stream_tile(cfg);
+        const int epi = pd_gemm_stream_try(split_rows(p, pro, tile, head, tail) ? &head : &p, pro, tile, nullptr, 2);
         if (epi >= 0) return v + 5000 + 10000 * epi;
     }
     return v;
@@ -620,14 +624,15 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
-    if (use_stream() && cfg == 0 && !p.dbg) {
+    if (use_stream() && stream_tile(cfg) && !p.dbg) {
         pd_gemm_args head, tail;
-        if (!split_rows(p, pro, head, tail)) {
-            const int r = pd_gemm_stream_try(&p, pro, stream, 0);
+        const int tile = stream_tile(cfg);
+        if (!split_rows(p, pro, tile, head, tail)) {
+            const int r = pd_gemm_stream_try(&p, pro, tile, stream, 0);
             if (r != PD_ERR_UNSUPPORTED) return r;
-        } else if (pd_gemm_stream_try(&head, pro, nullptr, 2) >= 0) {
-            // whole 128-row blocks on the streaming kernel, the ragged remainder (< 128 rows) on the general one
-            const int r = pd_gemm_stream_try(&head, pro, stream, 0);
+        } else if (pd_gemm_stream_try(&head, pro, tile, nullptr, 2) >= 0) {
+            // whole row blocks on the streaming kernel, the ragged remainder (< one tile of rows) on the general one
+            const int r = pd_gemm_stream_try(&head, pro, tile, stream, 0);
             if (r != PD_OK) return r;
             int tcfg, tpro; bool takm, twkm, tvec;
             const int tv = select_variant(tail, tcfg, takm, twkm, tvec, tpro);

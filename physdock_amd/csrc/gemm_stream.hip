@@ -36,27 +36,37 @@
 
 namespace {
 
-constexpr int BK = 32, LDK = BK + 4, NT = 256, BM = 128, BN = 128, TM = 2, TN = 2;
-constexpr int A_TILE = BM * LDK, W_TILE = BN * LDK;
-constexpr int LDS_BYTES = 4 * 2 * (A_TILE + W_TILE);
+constexpr int BK = 32, LDK = BK + 4, NT = 256;
 
-struct Loader {     // 128 rows x 32 k, [row][k] layout; thread -> rows (tid>>3)+32i, 16-byte chunk tid&7
-    f32x4 reg[4];
+// Block tile T x T (T = 128 or 64), 2 x 2 waves, each wave (T/2) x (T/2) = TF x TF MFMA fragments of 32 x 32.
+template <int T>
+struct Tile {
+    static constexpr int BM = T, BN = T, TF = T / 64;
+    static constexpr int A_TILE = T * LDK, W_TILE = T * LDK;
+    static constexpr int LDS_BYTES = 4 * 2 * (A_TILE + W_TILE);
+    static constexpr int BLOCKS_PER_CU = T == 128 ? 2 : 4;          // by LDS (73.7 / 36.9 KB) and registers
+    static constexpr int GRID = 256 * BLOCKS_PER_CU;                // persistent grid
+};
+
+template <int ROWS>
+struct Loader {     // ROWS rows x 32 k, [row][k] layout; thread -> rows (tid>>3)+32i, 16-byte chunk tid&7
+    static constexpr int NP = ROWS / 32;
+    f32x4 reg[NP];
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int r0, int rows, int k0, int K, int tid) {
         const int kc = k0 + (tid & 7) * 4;
         const int kcl = kc < K ? kc : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             int r = r0 + (tid >> 3) + 32 * i;
             r = r < rows ? r : rows - 1;
             reg[i] = *reinterpret_cast<const f32x4*>(base + (long long)r * ld + kcl);
         }
     }
     __device__ __forceinline__ void mask(int r0, int rows, int k0, int K, int tid) {
-        if (r0 + 128 <= rows && k0 + BK <= K) return;
+        if (r0 + ROWS <= rows && k0 + BK <= K) return;
         const int kc = k0 + (tid & 7) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const bool rok = r0 + (tid >> 3) + 32 * i < rows;
 #pragma unroll
             for (int e = 0; e < 4; ++e) reg[i][e] = (rok && kc + e < K) ? reg[i][e] : 0.f;
@@ -64,7 +74,7 @@ struct Loader {     // 128 rows x 32 k, [row][k] layout; thread -> rows (tid>>3)
     }
     __device__ __forceinline__ void store(float* __restrict__ s, int tid) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(s + ((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4) = reg[i];
+        for (int i = 0; i < NP; ++i) *reinterpret_cast<f32x4*>(s + ((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4) = reg[i];
     }
 };
 
@@ -77,32 +87,34 @@ struct Loader {     // 128 rows x 32 k, [row][k] layout; thread -> rows (tid>>3)
 //   TGATERES: Y = (acc + bias) * gate[row, col] + res           (gate tensor, e.g. the sigmoid gate of an attention)
 enum { EPI_PLAIN = 0, EPI_HN = 1, EPI_GLU = 2, EPI_GATERES = 3, EPI_TGATERES = 4 };
 
-// Epilogue of one 128x128 tile straight from the accumulator fragments: lane = column, register r = row
+// Epilogue of one block tile straight from the accumulator fragments: lane = column, register r = row
 // (r&3)+8(r>>2)+4*half.  Tiles are always full (the launcher peels ragged rows off to gemm.hip).  Addresses are
 // (uniform row pointer)[lane offset]: SGPR base + one shared 32-bit VGPR offset per array, nothing per row in VGPRs.
-template <int EPI>
-__device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&acc)[TM][TN], const float (&c0)[2],
-                                         const float (&c1)[2], int bm0, int bn0, int wm, int wn, int l31, int hh) {
+template <int EPI, int TF>
+__device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&acc)[TF][TF], const float (&c0)[TF],
+                                         const float (&c1)[TF], int bm0, int bn0, int wm, int wn, int l31, int hh) {
+    constexpr int TM = TF, TN = TF;
+    static_assert(EPI != EPI_GLU || TF == 2, "a GLU pair needs both column fragments in one wave");
     const int ldy = p.ldy, ldres = p.ldres, ldmul = p.ldmul;
     const int yoff = hh * 4 * ldy + l31;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int mb = bm0 + wm * 64 + i * 32;
+        const int mb = bm0 + wm * (32 * TM) + i * 32;
         if constexpr (EPI == EPI_GLU) {
-            float* __restrict__ Yo = p.Y + (long long)mb * ldy + ((bn0 + wn * 64) >> 1);
+            float* __restrict__ Yo = p.Y + (long long)mb * ldy + ((bn0 + wn * (32 * TN)) >> 1);
             if (p.glu == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu(acc[i][0][r] + c0[0]) * (acc[i][1][r] + c0[1]));
+                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu(acc[i][0][r] + c0[0]) * (acc[i][TN - 1][r] + c0[TN - 1]));
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], (acc[i][0][r] + c0[0]) * pd_sigmoid(acc[i][1][r] + c0[1]));
+                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], (acc[i][0][r] + c0[0]) * pd_sigmoid(acc[i][TN - 1][r] + c0[TN - 1]));
             }
         } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int ncol0 = bn0 + wn * 64 + j * 32;
+                const int ncol0 = bn0 + wn * (32 * TN) + j * 32;
                 float* __restrict__ Yo = p.Y + (long long)mb * ldy + ncol0;
                 if constexpr (EPI == EPI_GATERES || EPI == EPI_TGATERES) {
                     const float* __restrict__ Ro = p.res + (long long)mb * ldres + ncol0;
@@ -162,7 +174,7 @@ __device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&a
 }
 
 // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.
-// A persistent grid of 512 blocks gives every XCD 64 concurrently running tiles; they are chosen as a compact patch of
+// A persistent grid of 512 (1024 for 64x64 tiles) blocks gives every XCD 64 (128) concurrently running tiles; they are chosen as a compact patch of
 // GM row blocks x (64 / GM) column blocks inside a contiguous range of row blocks owned by that XCD, so that an A panel
 // fetched by one tile is an L2 hit for the tiles of the other column blocks (M-fastest order re-fetches A once per
 // column block: measured 8x the algorithmic read traffic for N = 2816), and W panels are shared by GM tiles.
@@ -190,8 +202,11 @@ struct TileOrder {
     }
 };
 
-template <int PRO, int EPI>
-__global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p) {
+template <int PRO, int EPI, int T>
+__global__ __launch_bounds__(NT, Tile<T>::BLOCKS_PER_CU) void gemm_stream_kernel(const pd_gemm_args p) {
+    constexpr int BM = Tile<T>::BM, BN = Tile<T>::BN, TM = Tile<T>::TF, TN = Tile<T>::TF;
+    constexpr int A_TILE = Tile<T>::A_TILE, W_TILE = Tile<T>::W_TILE;
+    constexpr int XSLOTS = Tile<T>::GRID / 8;          // resident blocks per XCD
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sW = smem + 2 * A_TILE;
@@ -202,14 +217,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
     const int ntiles = nMb * nNb;
     const int nk = (p.K + BK - 1) / BK;
 
-    Loader la, lw;
+    Loader<BM> la;
+    Loader<BN> lw;
     f32x16 acc[TM][TN];
 
     // tile sequence of this block: XCD-aware patches for the persistent grid, plain M-fastest order otherwise
-    const bool grouped = gridDim.x == 512 && nMb >= 8;
+    const bool grouped = gridDim.x == Tile<T>::GRID && nMb >= 8;
     TileOrder ord;
-    ord.init(nMb, nNb, grouped ? blockIdx.x & 7 : 0, grouped ? 8 : 1, 64);
-    const int t_step = grouped ? 64 : gridDim.x;
+    ord.init(nMb, nNb, grouped ? blockIdx.x & 7 : 0, grouped ? 8 : 1, XSLOTS);
+    const int t_step = grouped ? XSLOTS : gridDim.x;
     const int t_end = grouped ? ord.ntiles : ntiles;
     int tile = grouped ? blockIdx.x >> 3 : blockIdx.x;
     if (tile >= t_end) return;
@@ -226,11 +242,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
 
     for (; tile < t_end; tile += t_step) {
         // per-lane column constants of this tile (column group j = packed columns n0 + 32 j); consumed in the epilogue
-        const int n0 = bn0 + wn * 64 + l31;
-        float c0[2], c1[2];
-        const int gate_row = bm0 + wm * 64;
+        const int n0 = bn0 + wn * (32 * TN) + l31;
+        float c0[TN], c1[TN];
+        const int gate_row = bm0 + wm * (32 * TM);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
             c0[j] = p.bias ? p.bias[n0 + 32 * j] : 0.f;
             c1[j] = 1.f;
             if constexpr (EPI == EPI_HN) c1[j] = p.hn_w[((n0 + 32 * j) / p.hn_split) * 32 + l31];
@@ -238,13 +254,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
                 c1[j] = p.mul ? p.mul[(long long)(gate_row / p.mul_rows_per_group) * p.mul_gstride + n0 + 32 * j] : 1.f;
         }
         // per-tile prologue state (rows this thread stages)
-        float st_mean[4], st_rstd[4];
-        int grp_off[4];
+        constexpr int NPA = Loader<BM>::NP;
+        float st_mean[NPA], st_rstd[NPA];
+        int grp_off[NPA];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { st_mean[i] = 0.f; st_rstd[i] = 1.f; grp_off[i] = 0; }
+        for (int i = 0; i < NPA; ++i) { st_mean[i] = 0.f; st_rstd[i] = 1.f; grp_off[i] = 0; }
         if constexpr (PRO != 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NPA; ++i) {
                 const int m = bm0 + (tid >> 3) + 32 * i;
                 st_mean[i] = p.stats[2 * (long long)m];
                 st_rstd[i] = p.stats[2 * (long long)m + 1];
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
                     pb = *reinterpret_cast<const f32x4*>(p.pro_b + kc);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NPA; ++i) {
                     if constexpr (PRO == 2) {
                         pw = *reinterpret_cast<const f32x4*>(p.pro_w + grp_off[i] + kc);
                         pb = *reinterpret_cast<const f32x4*>(p.pro_b + grp_off[i] + kc);
@@ -272,12 +289,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
             }
             if (p.pro_act == PD_ACT_RELU) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NPA; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) la.reg[i][e] = fmaxf(la.reg[i][e], 0.f);
             } else if (p.pro_act == PD_ACT_SILU) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NPA; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) la.reg[i][e] = pd_silu(la.reg[i][e]);
             }
@@ -311,9 +328,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
             for (int g = 0; g < BK / 8; ++g) {
                 f32x4 fa[TM], fw[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + (wm * 64 + i * 32 + l31) * LDK + g * 8 + 4 * hh);
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + (wm * (32 * TM) + i * 32 + l31) * LDK + g * 8 + 4 * hh);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const f32x4*>(w + (wn * 64 + j * 32 + l31) * LDK + g * 8 + 4 * hh);
+                for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const f32x4*>(w + (wn * (32 * TN) + j * 32 + l31) * LDK + g * 8 + 4 * hh);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -339,49 +356,57 @@ __global__ __launch_bounds__(NT, 2) void gemm_stream_kernel(const pd_gemm_args p
             lw.load(p.W, p.ldw, PD_LT(bn0), p.N, 0, p.K, tid);
         }
 
-        epilogue<EPI>(p, acc, c0, c1, cur_bm0, cur_bn0, wm, wn, l31, hh);
+        epilogue<EPI, TM>(p, acc, c0, c1, cur_bm0, cur_bn0, wm, wn, l31, hh);
     }
 }
 
 }  // namespace
 
-// (PRO, EPI) instantiations: op 0 launch, 1 raise the dynamic-LDS limit
-template <int PRO, int EPI>
+// (PRO, EPI, T) instantiations: op 0 launch, 1 raise the dynamic-LDS limit
+template <int PRO, int EPI, int T>
 static int run_stream(int op, const pd_gemm_args* p, hipStream_t s) {
-    auto k = gemm_stream_kernel<PRO, EPI>;
+    auto k = gemm_stream_kernel<PRO, EPI, T>;
+    constexpr int lds = Tile<T>::LDS_BYTES;
     if (op == 1)
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
-    const long long ntiles = (long long)(p->M / BM) * (p->N / BN);
-    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(NT), LDS_BYTES, s, *p);
+    const long long ntiles = (long long)(p->M / T) * (p->N / T);
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < Tile<T>::GRID ? ntiles : Tile<T>::GRID)), dim3(NT), lds, s, *p);
     return pd_check_launch();
 }
 
-static int dispatch_stream(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s) {
-#define PD_SCASE(P, E) if (pro == P && epi == E) return run_stream<P, E>(op, p, s);
-    PD_SCASE(0, EPI_PLAIN) PD_SCASE(1, EPI_PLAIN)
-    PD_SCASE(1, EPI_HN) PD_SCASE(2, EPI_HN)
-    PD_SCASE(1, EPI_GLU) PD_SCASE(2, EPI_GLU)
-    PD_SCASE(0, EPI_GATERES) PD_SCASE(0, EPI_TGATERES)
+static int dispatch_stream(int op, int pro, int epi, int tile, const pd_gemm_args* p, hipStream_t s) {
+#define PD_SCASE(P, E, T) if (pro == P && epi == E && tile == T) return run_stream<P, E, T>(op, p, s);
+    PD_SCASE(0, EPI_PLAIN, 128) PD_SCASE(1, EPI_PLAIN, 128)
+    PD_SCASE(1, EPI_HN, 128) PD_SCASE(2, EPI_HN, 128)
+    PD_SCASE(1, EPI_GLU, 128) PD_SCASE(2, EPI_GLU, 128)
+    PD_SCASE(0, EPI_GATERES, 128) PD_SCASE(0, EPI_TGATERES, 128)
+    // 64 x 64 tiles for problems that do not fill the chip with 128 x 128 ones (small sample counts, trunk side tracks)
+    PD_SCASE(0, EPI_PLAIN, 64) PD_SCASE(1, EPI_PLAIN, 64)
+    PD_SCASE(1, EPI_HN, 64) PD_SCASE(2, EPI_HN, 64)
+    PD_SCASE(0, EPI_GATERES, 64) PD_SCASE(0, EPI_TGATERES, 64)
 #undef PD_SCASE
     return PD_ERR_UNSUPPORTED;
 }
 
-// init_only: 0 launch, 1 raise the LDS limits (pd_init), 2 query only (returns the EPI_* kind)
-// returns PD_ERR_UNSUPPORTED when the arguments are outside this kernel's scope (pd_gemm then uses gemm.hip)
-extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, void* stream, int init_only) {
+// tile: 128 or 64 (the block tile pd_gemm's heuristic picked).  init_only: 0 launch, 1 raise the LDS limits (pd_init),
+// 2 query only (returns the EPI_* kind).  Returns PD_ERR_UNSUPPORTED when the arguments are outside this file's scope
+// (pd_gemm then uses gemm.hip).
+extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only) {
     if (init_only == 1) {
         int rc = PD_OK;
-        for (int P = 0; P < 3; ++P)
-            for (int E = 0; E < 5; ++E) {
-                const int r = dispatch_stream(1, P, E, nullptr, nullptr);
-                if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
-            }
+        for (int T = 64; T <= 128; T += 64)
+            for (int P = 0; P < 3; ++P)
+                for (int E = 0; E < 5; ++E) {
+                    const int r = dispatch_stream(1, P, E, T, nullptr, nullptr);
+                    if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
+                }
         return rc;
     }
     const pd_gemm_args& p = *args;
+    if (tile != 128 && tile != 64) return PD_ERR_UNSUPPORTED;
     if (p.a_kmajor || p.w_kmajor || !p.vecA || !p.vecW || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
-    if (p.M % BM != 0 || p.N % BN != 0) return PD_ERR_UNSUPPORTED;          // full tiles only
+    if (p.M % tile != 0 || p.N % tile != 0) return PD_ERR_UNSUPPORTED;      // full tiles only
     if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
     if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
@@ -392,12 +417,9 @@ extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, void* strea
         if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group % 64 != 0) epi = -1;   // one gate row per wave
     } else epi = p.mul ? -1 : EPI_PLAIN;
     if (epi < 0) return PD_ERR_UNSUPPORTED;
-    const long long ntiles = (long long)(p.M / BM) * (p.N / BN);
-    static const long long min_tiles = [] { const char* e = getenv("PD_STREAM_MIN_TILES"); return e ? atoll(e) : 1ll; }();
-    if (ntiles < min_tiles) return PD_ERR_UNSUPPORTED;
     if (init_only == 2) {                                     // query: epilogue kind (>= 0) of the instantiation
-        const int r = dispatch_stream(1, pro, epi, nullptr, nullptr);
+        const int r = dispatch_stream(1, pro, epi, tile, nullptr, nullptr);
         return r == PD_OK ? epi : r;
     }
-    return dispatch_stream(0, pro, epi, &p, (hipStream_t)stream);
+    return dispatch_stream(0, pro, epi, tile, &p, (hipStream_t)stream);
 }
