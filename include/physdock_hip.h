@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 1
+#define PD_ABI_VERSION 2
 
 enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFRAG = 3 };
 
@@ -98,9 +98,15 @@ typedef struct pd_attn_args {
     const float* bias;
     float scale;             /* 1/sqrt(32) */
     void* dbg;               /* optional phase-trace buffer (tools/attn_trace.py); NULL in production */
+    float* ws;               /* optional scratch (16-byte aligned) for key-split launches, see below; may be NULL       */
+    long long ws_bytes;
+    int nsplit;              /* set by the launcher                                                                      */
 } pd_attn_args;
+/* Launches that cannot fill the chip (nbatch * nheads * ceil(nq/128) < 512 blocks) with a long key range are split into
+ * up to 8 key chunks when ws holds nsplit * nbatch * nq * nheads * 34 floats; a second kernel merges the chunks. */
 int pd_attention(const pd_attn_args* args, void* stream);
-/* waves per block (4 or 8 = template argument of attn_kernel) pd_attention picks for these arguments (profiling) */
+/* waves per block (4 or 8 = template argument of attn_kernel) pd_attention picks for these arguments; 4 + 100 * nsplit for
+ * a key-split launch (profiling) */
 int pd_attention_variant(const pd_attn_args* args);
 
 /* ---- pair-representation / pooling kernels (pair.hip) ----------------------------------

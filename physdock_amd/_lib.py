@@ -50,6 +50,7 @@ class AttnArgs(C.Structure):
         ("q_bs", C.c_longlong), ("q_ss", C.c_longlong), ("k_bs", C.c_longlong), ("k_ss", C.c_longlong),
         ("v_bs", C.c_longlong), ("v_ss", C.c_longlong), ("o_bs", C.c_longlong), ("o_ss", C.c_longlong),
         ("bias", _fp), ("scale", C.c_float), ("dbg", _fp),
+        ("ws", _fp), ("ws_bytes", C.c_longlong), ("nsplit", C.c_int),
     ]
 
 
@@ -70,7 +71,7 @@ def lib():
                 "(there is no CPU or PyTorch fallback for the sampler kernels)")
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
-        if _lib.pd_abi_version() != 1:
+        if _lib.pd_abi_version() != 2:
             raise RuntimeError("libphysdock_hip.so ABI version mismatch")
     return _lib
 

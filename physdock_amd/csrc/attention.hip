@@ -32,7 +32,10 @@ constexpr int LDVS = 32;    // V row stride
 
 // NW = waves (32-query tiles) per block: 4, or 8 for long query ranges - the K/V tiles staged through LDS are then shared
 // by twice as many MFMAs (half the global-load / LDS-write traffic per flop), at the same 4 waves per SIMD.
-template <int NW>
+// SPLIT: the key range is cut into p.nsplit chunks handled by different blocks (blockIdx.y = query block * nsplit + chunk);
+// each writes its un-normalised output and (running max, sum) to the workspace, attn_combine_kernel merges them.  For
+// launches that cannot fill the chip (few samples): every wave's key loop is serial, so only shorter loops cut latency.
+template <int NW, bool SPLIT>
 __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) {
     __shared__ __attribute__((aligned(16))) float sK[2][KT * LDKS];
     __shared__ __attribute__((aligned(16))) float sV[2][KT * LDVS];
@@ -43,7 +46,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) 
     // panels of one (batch, head) are resident together.  Two XCD-aware remappings of the block index (whole (query
     // block, head) groups per XCD, interleaved or contiguous) were measured: both raise the fetch traffic of the DiT atom
     // attention from 433 to 637 MB (FETCH_SIZE) at unchanged run time, so the plain order stays.
-    const int b = blockIdx.x, qb = blockIdx.y, h = blockIdx.z;
+    const int b = blockIdx.x, h = blockIdx.z;
+    const int qb = SPLIT ? blockIdx.y / p.nsplit : blockIdx.y, chunk = SPLIT ? blockIdx.y % p.nsplit : 0;
     const int q0 = qb * (32 * NW) + wave * 32;
     const int query = q0 + l31;
     const bool wave_active = q0 < p.nq;
@@ -100,9 +104,11 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) 
         }
     };
 
-    const int nit = (p.nk + KT - 1) / KT;
-    gload(0);
-    sstore(0);
+    const int nit_all = (p.nk + KT - 1) / KT;
+    const int it_lo = SPLIT ? (int)((long long)nit_all * chunk / p.nsplit) : 0;
+    const int nit = SPLIT ? (int)((long long)nit_all * (chunk + 1) / p.nsplit) : nit_all;
+    gload(it_lo * KT);
+    sstore(it_lo & 1);
     __syncthreads();
 
     // one 32-key sub-tile: S^T = K.Q^T (+bias), online softmax, O^T += V^T.P^T.  RAGGED is only instantiated for the
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) 
         dbg = reinterpret_cast<unsigned long long*>(p.dbg) + (((long long)blockIdx.y * 8 + blockIdx.x) * 4 + wave) * (4 * 64);
 #define PD_STAMP(slot) if (dbg && it < 64) dbg[it * 4 + slot] = __builtin_amdgcn_s_memtime()
 
-    for (int it = 0; it < nit; ++it) {
+    for (int it = it_lo; it < nit; ++it) {
         const int cur = it & 1;
         PD_STAMP(0);
         if (it + 1 < nit) gload((it + 1) * KT);
@@ -184,6 +190,24 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) 
     }
 #undef PD_STAMP
 
+    if constexpr (SPLIT) {
+        if (query < p.nq) {      // partial result of this key chunk: [chunk][b][query][h*32 + dim], (m, l) per (chunk, b, h, query)
+            const float l = pd_xhalf_sum(l_run);
+            const int C = p.nheads * 32;
+            float* wo = p.ws + (((long long)chunk * p.nbatch + b) * p.nq + query) * C + h * 32 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(wo + 8 * g) = v;
+            }
+            if (hh == 0) {
+                float* ml = p.ws + (long long)p.nsplit * p.nbatch * p.nq * C
+                            + ((((long long)chunk * p.nbatch + b) * p.nheads + h) * p.nq + query) * 2;
+                ml[0] = m_run; ml[1] = l;
+            }
+        }
+        return;
+    }
     if (query < p.nq) {
         const float l = pd_xhalf_sum(l_run);
         const float inv = 1.0f / l;
@@ -196,13 +220,54 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) 
     }
 }
 
+// merge the key chunks of a split launch: O = sum_s o_s 2^(m_s - M) / sum_s l_s 2^(m_s - M); 8 threads per (b, q, h)
+__global__ __launch_bounds__(256) void attn_combine_kernel(const pd_attn_args p) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int C = p.nheads * 32;
+    const long long total = (long long)p.nbatch * p.nq * p.nheads * 8;
+    if (t >= total) return;
+    const int d4 = (int)(t & 7);
+    const int h = (int)((t >> 3) % p.nheads);
+    const long long bq = (t >> 3) / p.nheads;
+    const int q = (int)(bq % p.nq), b = (int)(bq / p.nq);
+    const float* ml0 = p.ws + (long long)p.nsplit * p.nbatch * p.nq * C;
+    float M = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, ml0[((((long long)s * p.nbatch + b) * p.nheads + h) * p.nq + q) * 2]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const float* ml = ml0 + ((((long long)s * p.nbatch + b) * p.nheads + h) * p.nq + q) * 2;
+        const float w = __builtin_amdgcn_exp2f(ml[0] - M);
+        L += ml[1] * w;
+        acc += *reinterpret_cast<const f32x4*>(p.ws + (((long long)s * p.nbatch + b) * p.nq + q) * C + h * 32 + d4 * 4) * w;
+    }
+    *reinterpret_cast<f32x4*>(p.O + (long long)b * p.o_bs + (long long)q * p.o_ss + h * 32 + d4 * 4) = acc * (1.0f / L);
+}
+
 }  // namespace
+
+// number of key chunks pd_attention would use (1 = no split): only when the launch leaves most of the chip idle, the
+// key range is long enough and the caller supplied a workspace of nsplit * nbatch * nq * (32 + 2) * nheads floats
+static int attn_nsplit(const pd_attn_args* a) {
+    static const int on = [] { const char* e = getenv("PD_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
+    if (!on || !a->ws) return 1;
+    const long long blocks = (long long)a->nbatch * a->nheads * ((a->nq + 127) / 128);
+    const int nit = (a->nk + KT - 1) / KT;
+    if (blocks >= 512 || nit < 8) return 1;
+    long long s = 1024 / blocks;
+    s = s < nit / 4 ? s : nit / 4;
+    s = s < 8 ? s : 8;
+    while (s > 1 && a->ws_bytes < 4ll * s * a->nbatch * a->nq * a->nheads * 34) --s;
+    return s < 2 ? 1 : (int)s;
+}
 
 // waves per block pd_attention uses for these arguments (= template argument of attn_kernel; for profiling)
 PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
     if (!a) return PD_ERR_ARG;
     static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
     // 8-wave blocks pay off (+2 %) when they still fill the chip twice over; short query ranges / few batches keep 4 waves
+    const int ns = attn_nsplit(a);
+    if (ns > 1) return 4 + 100 * ns;                                   // split launch: 4-wave blocks, ns key chunks
     return (wide && a->nq >= 512 && (long long)a->nbatch * a->nheads * ((a->nq + 255) / 256) >= 1024) ? 8 : 4;
 }
 
@@ -214,12 +279,21 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     for (long long s : strides) if (s % 4) return PD_ERR_UNSUPPORTED;
     if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O | (uintptr_t)a->bias) & 15)
         return PD_ERR_UNSUPPORTED;
-    if (pd_attention_variant(a) == 8) {
+    const int variant = pd_attention_variant(a);
+    if (variant > 100) {
+        if (((uintptr_t)a->ws & 15) != 0) return PD_ERR_UNSUPPORTED;
+        pd_attn_args s = *a;
+        s.nsplit = variant / 100;
+        dim3 grid(a->nbatch, ((a->nq + 127) / 128) * s.nsplit, a->nheads);
+        hipLaunchKernelGGL((attn_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, s);
+        const long long total = (long long)a->nbatch * a->nq * a->nheads * 8;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s);
+    } else if (variant == 8) {
         dim3 grid(a->nbatch, (a->nq + 255) / 256, a->nheads);
-        hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((attn_kernel<8, false>), grid, dim3(512), 0, (hipStream_t)stream, *a);
     } else {
         dim3 grid(a->nbatch, (a->nq + 127) / 128, a->nheads);
-        hipLaunchKernelGGL(attn_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((attn_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, *a);
     }
     return pd_check_launch();
 }
@@ -227,6 +301,6 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
 // resident blocks per CU the runtime computes for the kernel (diagnostic, tools/attn_trace.py)
 PD_EXPORT int pd_attention_occupancy(void) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_kernel<4>, 256, 0) != hipSuccess) return PD_ERR_LAUNCH;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (attn_kernel<4, false>), 256, 0) != hipSuccess) return PD_ERR_LAUNCH;
     return n;
 }

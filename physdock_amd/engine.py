@@ -67,6 +67,11 @@ class Engine:
         ops.rowstats(x, st, M, C, mode=mode, eps=eps, kmajor=kmajor, ldx=ldx)
         return st
 
+    def attn_ws(self, nbatch, nq, nk, nheads):
+        """scratch for key-split attention launches (None when the launch fills the chip by itself)"""
+        n = ops.attn_split_ws_numel(nbatch, nq, nk, nheads)
+        return self.lws("attn_split", n) if n else None
+
     def lin(self, x, wname, M, out=None, **kw):
         """plain Linear by packed-weight name; returns the output tensor"""
         W, b, N, K, ldw = self.P.linear(wname)
@@ -99,7 +104,8 @@ class Engine:
         o = self.ws.get("attn_o", rows, C)
         st4 = (N * 4 * C, 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=nk or N, nbatch=nbatch, nheads=H,
-                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias)
+                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias,
+                      ws=self.attn_ws(nbatch, N, nk or N, H))
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         ops.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s)
 
@@ -371,7 +377,8 @@ class Engine:
         o = self.lws("dit_o", rows, C)
         st3 = (N * 3 * C, 3 * C)
         ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, nq=N, nk=nk, nbatch=B, nheads=H,
-                      q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias)
+                      q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias,
+                      ws=self.attn_ws(B, N, nk, H))
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         ops.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)
         st = self.stats(x, rows, C, LN, eps)

@@ -92,9 +92,20 @@ def rownorm(x, y, M, Cdim, *, res=None, w=None, b=None, mode=RMS, eps=1e-8, act=
           "pd_rownorm")
 
 
+def attn_split_ws_numel(nbatch, nq, nk, nheads):
+    """floats of scratch that let pd_attention split the key range of a launch too small to fill the chip (0: no split)"""
+    blocks = nbatch * nheads * ((nq + 127) // 128)
+    nit = (nk + 63) // 64
+    if blocks >= 512 or nit < 8:
+        return 0
+    s = min(8, 1024 // blocks, nit // 4)
+    return s * nbatch * nq * nheads * 34 if s >= 2 else 0
+
+
 def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_strides, o_strides, bias=None,
-              scale=1.0 / math.sqrt(32.0)):
-    """strides = (batch_stride, seq_stride) in floats; Q/K/V/O tensors or raw addresses."""
+              scale=1.0 / math.sqrt(32.0), ws=None):
+    """strides = (batch_stride, seq_stride) in floats; Q/K/V/O tensors or raw addresses.  ws: optional float scratch
+    tensor (attn_split_ws_numel) enabling key-split launches for small grids."""
     def P(x):
         return x if (x is None or isinstance(x, int)) else ptr(x)
     a = AttnArgs()
@@ -106,6 +117,8 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
     a.o_bs, a.o_ss = o_strides
     a.bias = P(bias)
     a.scale = scale
+    if ws is not None:
+        a.ws, a.ws_bytes = ptr(ws), ws.numel() * 4
     if ATTN_DBG is not None:
         a.dbg = ATTN_DBG.data_ptr()
     if ATTN_HOOK is not None:

@@ -20,7 +20,7 @@ def test_library_exports_every_header_symbol():
     for sym in declared:
         assert hasattr(L, sym), f"{sym} declared in physdock_hip.h but not exported"
         assert sym in _lib.SYMBOLS, f"{sym} has no ctypes signature"
-    assert L.pd_abi_version() == 1
+    assert L.pd_abi_version() == 2
 
 
 def test_product_package_never_imports_oracle():

@@ -324,6 +324,34 @@ def test_attention(ops, B, H, nq, nk, use_bias):
     close(o, ref, atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,nq,nk", [(1, 4, 2048, 2048), (5, 4, 1000, 1000), (2, 2, 300, 777), (3, 16, 256, 520)])
+def test_attention_key_split(ops, B, H, nq, nk):
+    """launches that cannot fill the chip split the key range over blocks (workspace supplied) and merge the chunks"""
+    import ctypes as C_
+    C = H * 32
+    q = torch.randn(B, nq, C, generator=g(1)); k = torch.randn(B, nk, C, generator=g(2))
+    v = torch.randn(B, nk, C, generator=g(3))
+    bias = 2 * torch.randn(H, nq, nk, generator=g(4))
+    bias[:, :, ::5] = -1e9
+    bias[:, 7, :] = -1e9
+    n = ops.attn_split_ws_numel(B, nq, nk, H)
+    assert n > 0
+    ws = torch.empty(n, device="cuda")
+    seen = []
+    ops.ATTN_HOOK = lambda a, launch: (seen.append(ops._lib.init().pd_attention_variant(C_.byref(a))), launch())
+    o = torch.empty(B, nq, C, device="cuda")
+    try:
+        ops.attention(dev(q), dev(k), dev(v), o, nq=nq, nk=nk, nbatch=B, nheads=H, q_strides=(nq * C, C),
+                      k_strides=(nk * C, C), v_strides=(nk * C, C), o_strides=(nq * C, C), bias=dev(ops.bias_to_frag(bias)), ws=ws)
+    finally:
+        ops.ATTN_HOOK = None
+    assert seen and seen[0] > 100          # 4 + 100 * nsplit
+    def heads(x):
+        return x.reshape(B, -1, H, 32).transpose(1, 2)
+    ref = ref_attention(heads(q), heads(k), heads(v), bias[None]).transpose(1, 2).reshape(B, nq, C)
+    close(o, ref, atol=2e-5, rtol=1e-4)
+
+
 def test_attention_strided_column(ops):
     # MSA column attention / transposed triangle attention: sequence axis is the slow axis of [S,T,C]
     S, T, H = 20, 9, 2
