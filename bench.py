@@ -139,7 +139,8 @@ class LaunchTimer:
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))
             self._add(name, e0, e1, 2.0 * a.M * a.N * a.K * nb, byt)
         def attn_hook(a, launch):
-            name = "attn_kernel<%d>" % L.pd_attention_variant(C.byref(a))
+            v = L.pd_attention_variant(C.byref(a))          # 4 / 8 waves per block, or 4 + 100 * key chunks
+            name = "attn_kernel<%d, %s>" % (v % 100, "true" if v > 100 else "false")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); launch(); e1.record()
             c = a.nheads * 32                    # q, o: nq rows; k, v: nk rows; the bias tile set is read once per launch
