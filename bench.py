@@ -126,12 +126,12 @@ class LaunchTimer:
 
         def gemm_hook(a, launch):
             v = L.pd_gemm_variant(C.byref(a))
-            streamed, epi, v = (v % 10000) >= 5000, v // 10000, v % 5000
+            streamed, epi, tcode, v = (v % 10000) >= 5000, (v // 10000) % 10, v // 100000, v % 5000
             cfg, lay, pro, scalar = (v % 1000) // 100, (v % 100) // 10, v % 10, v >= 1000
             name = "gemm_kernel<%s, %s, %s, %s, %d>" % (self.GEMM_NAMES[cfg], "true" if lay >= 1 else "false",
                                                          "true" if lay == 2 else "false", "false" if scalar else "true", pro)
             if streamed:        # persistent direct-epilogue variant (csrc/gemm_stream.hip)
-                name = "gemm_stream_kernel<%d, %d, %d>" % (pro, epi, 128 if cfg == 0 else 64)
+                name = "gemm_stream_kernel<%d, %d, Tile<%s>>" % (pro, epi, ("128, 128, 2", "64, 64, 2", "128, 64, 4")[tcode])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); launch(); e1.record()
             nb = max(a.batch, 1)

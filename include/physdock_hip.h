@@ -73,8 +73,8 @@ typedef struct pd_gemm_args {
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
 /* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling);
- * id % 10000 >= 5000: gemm_stream_kernel<id % 10, id / 10000, tile> (csrc/gemm_stream.hip) takes it,
- * tile = 128 for cfg 0, 64 for cfg 3 */
+ * id % 10000 >= 5000: gemm_stream_kernel<id % 10, (id / 10000) % 10, Tile> (csrc/gemm_stream.hip) takes it,
+ * Tile = id / 100000: 0 -> <128,128,2>, 1 -> <64,64,2>, 2 -> <128,64,4> */
 int pd_gemm_variant(const pd_gemm_args* args);
 
 /* ---- pd_rowstats: per-row (mean, rstd) for the GEMM prologue --------------------------

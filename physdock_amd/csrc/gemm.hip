@@ -579,7 +579,8 @@ static int select_variant(pd_gemm_args& p, int& cfg, bool& akm, bool& wkm, bool&
 // Ragged M for the streaming kernel: head = the whole row blocks of the tile size, tail = the remaining rows with every row-indexed
 // operand advanced.  Only when row groups (AdaLN prologue / gate tables) do not subdivide the rows.
 static bool split_rows(const pd_gemm_args& p, int pro, int tile, pd_gemm_args& head, pd_gemm_args& tail) {
-    const int M0 = p.M / tile * tile;
+    const int tm = tile == 64 ? 64 : 128;                   // row blocks of the tile code
+    const int M0 = p.M / tm * tm;
     if (M0 == p.M || M0 == 0 || p.batch != 1 || p.a_kmajor || p.out_mode != PD_OUT_ROWMAJOR) return false;
     if (pro == 2 && p.pro_rows_per_group < p.M) return false;
     if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group < p.M) return false;
@@ -596,24 +597,32 @@ static bool split_rows(const pd_gemm_args& p, int pro, int tile, pd_gemm_args& h
 }
 
 // block tile of gemm_stream.hip that corresponds to a tile configuration of this file (0 = none)
-static int stream_tile(int cfg) { return cfg == 0 ? 128 : cfg == 3 ? 64 : 0; }
+// (128 x 128 for cfg 0, 64 x 64 for cfg 3; GLU problems are always cfg 0 here and get the 128 x 64 tile, code 12864, when
+// they are too small to fill the chip with 128 x 128 tiles)
+static int stream_tile(int cfg, const pd_gemm_args& p) {
+    if (cfg == 3) return 64;
+    if (cfg != 0) return 0;
+    const long long blocks128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    return (p.glu && blocks128 < 384) ? 12864 : 128;
+}
 
 static bool use_stream() {
     static const int on = [] { const char* e = getenv("PD_GEMM_STREAM"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
 
-// variant id as documented above; + 5000 + 10000 * EPI when the launch goes to gemm_stream_kernel<pro, EPI>
+// variant id as documented above; + 5000 + 10000 * EPI + 100000 * tile (0: 128x128, 1: 64x64, 2: 128x64) when the launch
+// goes to gemm_stream_kernel<pro, EPI, Tile<...>>
 PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     if (!args) return PD_ERR_ARG;
     pd_gemm_args p = *args;
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
-    if (v >= 0 && use_stream() && stream_tile(cfg) && !p.dbg) {
+    if (v >= 0 && use_stream() && stream_tile(cfg, p) && !p.dbg) {
         pd_gemm_args head, tail;
-        const int tile = stream_tile(cfg);
+        const int tile = stream_tile(cfg, p);
         const int epi = pd_gemm_stream_try(split_rows(p, pro, tile, head, tail) ? &head : &p, pro, tile, nullptr, 2);
-        if (epi >= 0) return v + 5000 + 10000 * epi;
+        if (epi >= 0) return v + 5000 + 10000 * epi + 100000 * (tile == 128 ? 0 : tile == 64 ? 1 : 2);
     }
     return v;
 }
@@ -624,9 +633,9 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
-    if (use_stream() && stream_tile(cfg) && !p.dbg) {
+    if (use_stream() && stream_tile(cfg, p) && !p.dbg) {
         pd_gemm_args head, tail;
-        const int tile = stream_tile(cfg);
+        const int tile = stream_tile(cfg, p);
         if (!split_rows(p, pro, tile, head, tail)) {
             const int r = pd_gemm_stream_try(&p, pro, tile, stream, 0);
             if (r != PD_ERR_UNSUPPORTED) return r;

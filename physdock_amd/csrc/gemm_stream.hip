@@ -38,13 +38,17 @@ namespace {
 
 constexpr int BK = 32, LDK = BK + 4, NT = 256;
 
-// Block tile T x T (T = 128 or 64), 2 x 2 waves, each wave (T/2) x (T/2) = TF x TF MFMA fragments of 32 x 32.
-template <int T>
+// Block tile BM x BN, 4 waves laid out WM x WN, each wave TM x TN MFMA fragments of 32 x 32:
+//   Tile<128,128,2> 2 x 2 waves of 64 x 64     the hot shapes
+//   Tile<64,64,2>   2 x 2 waves of 32 x 32     problems that do not fill the chip with 128 x 128 tiles
+//   Tile<128,64,4>  4 x 1 waves of 32 x 64     the same for GLU epilogues (a wave must own both columns of a pair)
+template <int BM_, int BN_, int WM_>
 struct Tile {
-    static constexpr int BM = T, BN = T, TF = T / 64;
-    static constexpr int A_TILE = T * LDK, W_TILE = T * LDK;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = 4 / WM_;
+    static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    static constexpr int A_TILE = BM * LDK, W_TILE = BN * LDK;
     static constexpr int LDS_BYTES = 4 * 2 * (A_TILE + W_TILE);
-    static constexpr int BLOCKS_PER_CU = T == 128 ? 2 : 4;          // by LDS (73.7 / 36.9 KB) and registers
+    static constexpr int BLOCKS_PER_CU = LDS_BYTES > 60000 ? 2 : LDS_BYTES > 40000 ? 3 : 4;     // 73.7 / 55.3 / 36.9 KB of LDS
     static constexpr int GRID = 256 * BLOCKS_PER_CU;                // persistent grid
 };
 
@@ -90,11 +94,10 @@ enum { EPI_PLAIN = 0, EPI_HN = 1, EPI_GLU = 2, EPI_GATERES = 3, EPI_TGATERES = 4
 // Epilogue of one block tile straight from the accumulator fragments: lane = column, register r = row
 // (r&3)+8(r>>2)+4*half.  Tiles are always full (the launcher peels ragged rows off to gemm.hip).  Addresses are
 // (uniform row pointer)[lane offset]: SGPR base + one shared 32-bit VGPR offset per array, nothing per row in VGPRs.
-template <int EPI, int TF>
-__device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&acc)[TF][TF], const float (&c0)[TF],
-                                         const float (&c1)[TF], int bm0, int bn0, int wm, int wn, int l31, int hh) {
-    constexpr int TM = TF, TN = TF;
-    static_assert(EPI != EPI_GLU || TF == 2, "a GLU pair needs both column fragments in one wave");
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&acc)[TM][TN], const float (&c0)[TN],
+                                         const float (&c1)[TN], int bm0, int bn0, int wm, int wn, int l31, int hh) {
+    static_assert(EPI != EPI_GLU || TN == 2, "a GLU pair needs both column fragments in one wave");
     const int ldy = p.ldy, ldres = p.ldres, ldmul = p.ldmul;
     const int yoff = hh * 4 * ldy + l31;
 #pragma unroll
@@ -202,16 +205,16 @@ struct TileOrder {
     }
 };
 
-template <int PRO, int EPI, int T>
-__global__ __launch_bounds__(NT, Tile<T>::BLOCKS_PER_CU) void gemm_stream_kernel(const pd_gemm_args p) {
-    constexpr int BM = Tile<T>::BM, BN = Tile<T>::BN, TM = Tile<T>::TF, TN = Tile<T>::TF;
-    constexpr int A_TILE = Tile<T>::A_TILE, W_TILE = Tile<T>::W_TILE;
-    constexpr int XSLOTS = Tile<T>::GRID / 8;          // resident blocks per XCD
+template <int PRO, int EPI, class TL>
+__global__ __launch_bounds__(NT, TL::BLOCKS_PER_CU) void gemm_stream_kernel(const pd_gemm_args p) {
+    constexpr int BM = TL::BM, BN = TL::BN, TM = TL::TM, TN = TL::TN;
+    constexpr int A_TILE = TL::A_TILE, W_TILE = TL::W_TILE;
+    constexpr int XSLOTS = TL::GRID / 8;               // resident blocks per XCD
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sW = smem + 2 * A_TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / TL::WN, wn = wave % TL::WN;
     const int l31 = lane & 31, hh = lane >> 5;
     const int nMb = p.M / BM, nNb = p.N / BN;             // full tiles only (launcher)
     const int ntiles = nMb * nNb;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(NT, Tile<T>::BLOCKS_PER_CU) void gemm_stream_kernel
     f32x16 acc[TM][TN];
 
     // tile sequence of this block: XCD-aware patches for the persistent grid, plain M-fastest order otherwise
-    const bool grouped = gridDim.x == Tile<T>::GRID && nMb >= 8;
+    const bool grouped = gridDim.x == TL::GRID && nMb >= 8;
     TileOrder ord;
     ord.init(nMb, nNb, grouped ? blockIdx.x & 7 : 0, grouped ? 8 : 1, XSLOTS);
     const int t_step = grouped ? XSLOTS : gridDim.x;
@@ -356,46 +359,53 @@ __global__ __launch_bounds__(NT, Tile<T>::BLOCKS_PER_CU) void gemm_stream_kernel
             lw.load(p.W, p.ldw, PD_LT(bn0), p.N, 0, p.K, tid);
         }
 
-        epilogue<EPI, TM>(p, acc, c0, c1, cur_bm0, cur_bn0, wm, wn, l31, hh);
+        epilogue<EPI, TM, TN>(p, acc, c0, c1, cur_bm0, cur_bn0, wm, wn, l31, hh);
     }
 }
 
 }  // namespace
 
-// (PRO, EPI, T) instantiations: op 0 launch, 1 raise the dynamic-LDS limit
-template <int PRO, int EPI, int T>
+// (PRO, EPI, tile) instantiations: op 0 launch, 1 raise the dynamic-LDS limit
+template <int PRO, int EPI, class TL>
 static int run_stream(int op, const pd_gemm_args* p, hipStream_t s) {
-    auto k = gemm_stream_kernel<PRO, EPI, T>;
-    constexpr int lds = Tile<T>::LDS_BYTES;
+    auto k = gemm_stream_kernel<PRO, EPI, TL>;
+    constexpr int lds = TL::LDS_BYTES;
     if (op == 1)
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
-    const long long ntiles = (long long)(p->M / T) * (p->N / T);
-    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < Tile<T>::GRID ? ntiles : Tile<T>::GRID)), dim3(NT), lds, s, *p);
+    const long long ntiles = (long long)(p->M / TL::BM) * (p->N / TL::BN);
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < TL::GRID ? ntiles : TL::GRID)), dim3(NT), lds, s, *p);
     return pd_check_launch();
 }
 
+// tile codes of the C interface between gemm.hip and this file
+using T128 = Tile<128, 128, 2>;
+using T64 = Tile<64, 64, 2>;
+using T12864 = Tile<128, 64, 4>;
+static void tile_dims(int tile, int& bm, int& bn) { bm = tile == 64 ? 64 : 128; bn = tile == 128 ? 128 : 64; }
+
 static int dispatch_stream(int op, int pro, int epi, int tile, const pd_gemm_args* p, hipStream_t s) {
-#define PD_SCASE(P, E, T) if (pro == P && epi == E && tile == T) return run_stream<P, E, T>(op, p, s);
-    PD_SCASE(0, EPI_PLAIN, 128) PD_SCASE(1, EPI_PLAIN, 128)
-    PD_SCASE(1, EPI_HN, 128) PD_SCASE(2, EPI_HN, 128)
-    PD_SCASE(1, EPI_GLU, 128) PD_SCASE(2, EPI_GLU, 128)
-    PD_SCASE(0, EPI_GATERES, 128) PD_SCASE(0, EPI_TGATERES, 128)
-    // 64 x 64 tiles for problems that do not fill the chip with 128 x 128 ones (small sample counts, trunk side tracks)
-    PD_SCASE(0, EPI_PLAIN, 64) PD_SCASE(1, EPI_PLAIN, 64)
-    PD_SCASE(1, EPI_HN, 64) PD_SCASE(2, EPI_HN, 64)
-    PD_SCASE(0, EPI_GATERES, 64) PD_SCASE(0, EPI_TGATERES, 64)
+#define PD_SCASE(P, E, C, TL) if (pro == P && epi == E && tile == C) return run_stream<P, E, TL>(op, p, s);
+    PD_SCASE(0, EPI_PLAIN, 128, T128) PD_SCASE(1, EPI_PLAIN, 128, T128)
+    PD_SCASE(1, EPI_HN, 128, T128) PD_SCASE(2, EPI_HN, 128, T128)
+    PD_SCASE(1, EPI_GLU, 128, T128) PD_SCASE(2, EPI_GLU, 128, T128)
+    PD_SCASE(0, EPI_GATERES, 128, T128) PD_SCASE(0, EPI_TGATERES, 128, T128)
+    // smaller tiles for problems that do not fill the chip with 128 x 128 ones (few samples, trunk side tracks)
+    PD_SCASE(0, EPI_PLAIN, 64, T64) PD_SCASE(1, EPI_PLAIN, 64, T64)
+    PD_SCASE(1, EPI_HN, 64, T64) PD_SCASE(2, EPI_HN, 64, T64)
+    PD_SCASE(0, EPI_GATERES, 64, T64) PD_SCASE(0, EPI_TGATERES, 64, T64)
+    PD_SCASE(1, EPI_GLU, 12864, T12864) PD_SCASE(2, EPI_GLU, 12864, T12864)
 #undef PD_SCASE
     return PD_ERR_UNSUPPORTED;
 }
 
-// tile: 128 or 64 (the block tile pd_gemm's heuristic picked).  init_only: 0 launch, 1 raise the LDS limits (pd_init),
+// tile: 128, 64 or 12864 = 128 x 64 (the block tile pd_gemm's heuristic picked).  init_only: 0 launch, 1 raise the LDS limits (pd_init),
 // 2 query only (returns the EPI_* kind).  Returns PD_ERR_UNSUPPORTED when the arguments are outside this file's scope
 // (pd_gemm then uses gemm.hip).
 extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only) {
     if (init_only == 1) {
         int rc = PD_OK;
-        for (int T = 64; T <= 128; T += 64)
+        for (int T : {128, 64, 12864})
             for (int P = 0; P < 3; ++P)
                 for (int E = 0; E < 5; ++E) {
                     const int r = dispatch_stream(1, P, E, T, nullptr, nullptr);
@@ -404,9 +414,11 @@ extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, v
         return rc;
     }
     const pd_gemm_args& p = *args;
-    if (tile != 128 && tile != 64) return PD_ERR_UNSUPPORTED;
+    if (tile != 128 && tile != 64 && tile != 12864) return PD_ERR_UNSUPPORTED;
+    int tbm, tbn;
+    tile_dims(tile, tbm, tbn);
     if (p.a_kmajor || p.w_kmajor || !p.vecA || !p.vecW || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
-    if (p.M % tile != 0 || p.N % tile != 0) return PD_ERR_UNSUPPORTED;      // full tiles only
+    if (p.M % tbm != 0 || p.N % tbn != 0) return PD_ERR_UNSUPPORTED;        // full tiles only
     if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
     if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;

@@ -42,7 +42,7 @@ def _streamed(ops, fn):
         fn()
     finally:
         ops.GEMM_HOOK = None
-    assert seen and min(v % 10000 for v in seen) >= 5000, seen
+    assert seen and min(v % 10000 for v in seen) >= 5000, seen       # id % 10000 >= 5000: gemm_stream.hip
 
 
 @pytest.mark.parametrize("M,N,K", [(128 * 40, 128 * 26, 100), (128 * 64, 128 * 16, 40), (128 * 33, 128 * 32, 300),
