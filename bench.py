@@ -131,7 +131,7 @@ class LaunchTimer:
             name = "gemm_kernel<%s, %s, %s, %s, %d>" % (self.GEMM_NAMES[cfg], "true" if lay >= 1 else "false",
                                                          "true" if lay == 2 else "false", "false" if scalar else "true", pro)
             if streamed:        # persistent direct-epilogue variant (csrc/gemm_stream.hip)
-                name = "gemm_stream_kernel<%d, %d, Tile<%s>>" % (pro, epi, ("128, 128, 2", "64, 64, 2", "128, 64, 4")[tcode])
+                name = "gemm_stream_kernel<%d, %d, Tile<%s> >" % (pro, epi, ("128, 128, 2", "64, 64, 2", "128, 64, 4")[tcode])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); launch(); e1.record()
             nb = max(a.batch, 1)
