@@ -60,6 +60,21 @@ __device__ __forceinline__ float pd_xhalf_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Sum over the 32 lanes of each wave half, result in every lane, on the VALU only: four v_add_f32_dpp (quad_perm x2,
+// row_half_mirror, row_mirror) + one v_permlane16_swap.  __shfl_xor lowers to ds_bpermute (LDS crossbar + index math).
+template <int CTRL>
+__device__ __forceinline__ float pd_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float pd_half_sum32(float v) {
+    float s = v + pd_dpp<0xB1>(v);          // quad_perm [1,0,3,2]
+    s += pd_dpp<0x4E>(s);                   // quad_perm [2,3,0,1]
+    s += pd_dpp<0x141>(s);                  // row_half_mirror: the other quad of an 8-lane group
+    s += pd_dpp<0x140>(s);                  // row_mirror: the other 8-lane group of a 16-lane row
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);      // the other 16-lane row of the half
+}
+
 __device__ __forceinline__ int pd_frag_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 __device__ __forceinline__ float wave_sum(float v) {

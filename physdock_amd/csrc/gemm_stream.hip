@@ -146,9 +146,7 @@ __device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&a
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float v = acc[i][j][r] + c0[j];
-                            float ss = v * v;
-#pragma unroll
-                            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+                            const float ss = pd_half_sum32(v * v);        // a head = the 32 lanes of a wave half
                             PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], v * rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps) * c1[j]);
                         }
                     } else {
