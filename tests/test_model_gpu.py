@@ -356,3 +356,25 @@ def test_workspace_release_rebuilds_buffers_and_graphs(small):
     finally:
         model.workspace_limit_bytes = old
     assert torch.equal(x1, x2) and torch.equal(x1, x3)
+
+
+def test_interleaved_configurations_share_one_model(small):
+    """one model object serving calls of different sample counts / step counts / physics settings back to back:
+    cached workspaces and captured graphs must never leak between configurations (graph == eager for every call,
+    repeated configurations reproduce bit-exactly)"""
+    from physdock_amd.synthetic import reference_conformers
+    model, cfg, P, batch, dbatch = small
+    confs = reference_conformers(batch, n_conf=5).cuda()
+    calls = [(3, 5, False), (1, 6, True), (8, 5, True), (3, 5, False), (2, 7, False), (8, 5, True), (1, 6, True), (5, 4, True)]
+    first = {}
+    for B, steps, phys in calls:
+        kw = dict(num_sample=B, steps=steps, karras_noise_schedule_power=1000, seed=21, align_ref_pos=phys)
+        if phys:
+            kw.update(ref_mol_poses=confs, use_ref_mol_poses=True, mmff_gamma_0_factor=3.0)
+        xg = model.sample_diffusion(dbatch, use_graph=True, **kw)
+        xe = model.sample_diffusion(dbatch, use_graph=False, **kw)
+        assert torch.isfinite(xg).all() and rmsd(xg.cpu(), xe.cpu()) < 1e-4, (B, steps, phys)
+        key = (B, steps, phys)
+        if key in first:
+            assert torch.equal(first[key], xg), key
+        first[key] = xg.clone()
