@@ -166,9 +166,19 @@ class LaunchTimer:
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU) via torch.distributed.run
+        if torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+                                  os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the two must agree (one rank per GPU)")
     dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # launched by torch.distributed.run
     if dist:
         import torch.distributed as td
@@ -212,6 +222,11 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t)
     assert torch.isfinite(x).all()
+    if dist and rank == 0:      # the gathered blocks of the last call: every rank's poses arrived and the ranks' streams differ
+        assert all(bool(torch.isfinite(t).all()) for t in gathered), "non-finite poses in a gathered rank block"
+        assert torch.equal(gathered[0], x), "rank 0's own block changed in the gather"
+        assert all(not torch.equal(gathered[0], gathered[r]) for r in range(1, world)), \
+            "rank blocks are identical: sample_offset did not separate the ranks' Philox streams"
     poses = B * world * args.steps
     value = poses / elapsed
 

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 2
+#define PD_ABI_VERSION 3
 
 enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFRAG = 3 };
 
@@ -69,7 +69,6 @@ typedef struct pd_gemm_args {
     int T1, T2;                  /* OPM: T2 = tokens; BIASFRAG: rows m = (i,j), i<T1, j<T2   */
     int frag_transpose;          /* BIASFRAG: query = j, key = i                             */
     int vecA, vecW, vecY;        /* set by the launcher                                      */
-    void* dbg;                   /* optional phase-trace buffer (tools/gemm_trace.py); NULL in production      */
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
 /* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling);
@@ -97,7 +96,8 @@ typedef struct pd_attn_args {
     long long q_bs, q_ss, k_bs, k_ss, v_bs, v_ss, o_bs, o_ss;
     const float* bias;
     float scale;             /* 1/sqrt(32) */
-    void* dbg;               /* optional phase-trace buffer (tools/attn_trace.py); NULL in production */
+    int bias_nk;             /* key count the bias buffer was laid out for (pd_gemm PD_OUT_BIASFRAG's T2, i.e. the PADDED
+                                count when nk is the real one); 0 -> nk                                                  */
     float* ws;               /* optional scratch (16-byte aligned) for key-split launches, see below; may be NULL       */
     long long ws_bytes;
     int nsplit;              /* set by the launcher                                                                      */
@@ -164,6 +164,12 @@ int pd_pairwise_rmsd(const float* x, const int* idx, const float* ref, float* D,
 int pd_euler(const float* x_hat, const float* x_den, const float* x_proj, const float* w, float t_hat, float eta, float dt,
              float* x_next, int B, int A, void* stream);
 int pd_timestep_embed(const float* tau, float* emb, int n, void* stream);
+/* ligand rows of a pose batch, for the relaxation branch (model.py:252-257):
+ * pd_ligand_gather : lig[b,l,:] = x[b, lig_idx[l], :]                      (`x_denoised[:, is_ligand_atom]`)
+ * pd_ligand_scatter: dst = src with dst[b,a,:] = lig[b, atom_slot[a], :] where atom_slot[a] >= 0
+ *                    (`x_ref = deepcopy(x_denoised); x_ref[:, is_ligand_atom] = relaxed`); atom_slot[A] = ligand slot or -1 */
+int pd_ligand_gather(const float* x, const int* lig_idx, float* lig, int B, int A, int L, void* stream);
+int pd_ligand_scatter(float* dst, const float* src, const float* lig, const int* atom_slot, int B, int A, int L, void* stream);
 
 /* ---- hipGraph helpers (api.hip): capture the host-deterministic step loop once, replay it */
 int pd_graph_begin(void* stream);
@@ -173,6 +179,8 @@ int pd_graph_destroy(void* exec);
 
 /* ---- library management ------------------------------------------------------------- */
 int pd_abi_version(void);
+int pd_gemm_args_size(void);  /* sizeof(pd_gemm_args) / sizeof(pd_attn_args) as compiled: a binding checks its own struct  */
+int pd_attn_args_size(void);  /* mirror against these before the first call (a short struct would be read past its end)   */
 int pd_init(void);            /* sets per-kernel LDS limits; call once before graph capture */
 int pd_attention_occupancy(void);   /* diagnostic: resident attention blocks per CU (runtime's figure) */
 

@@ -406,12 +406,15 @@ def sample_diffusion(P, batch, noise, num_sample=5, steps=200, gamma_0=0.8, gamm
                      noise_scale_lambda=1.003, step_scale_eta=1.5, ode_step_scale_eta=1.0,
                      ref_mol_poses=None, mmff_gamma_0_factor=1.0, align_ref_pos=True,
                      karras_noise_schedule_power=7, sigma_data=16.0, inf=1e9, eps=1e-8,
-                     conditioning=None, return_trajectory=False):
+                     conditioning=None, return_trajectory=False, ref_mol=None, relax_fn=None, mmff_iters=5):
     """models/model.py:157-282 with every random draw supplied by ``noise`` (parity mode):
 
     noise = {"init":[B,A,3], "rot_u":[steps,4,B], "trans":[steps,B,3], "diffuse":[n_noisy,B,A,3]}
     (draw order of the reference: model.py:148; per step tensor_utils.py:549-557 x2, :582; model.py:77).
-    ``ref_mol`` (RDKit MMFF branch, model.py:252-261) is not restated: parity unpinned.
+    ``ref_mol`` / ``relax_fn``: the relaxation branch (model.py:252-261).  Its tensor ops and control flow are restated
+    here and pinned by golden set G8 (reference run with `get_next_step_pos` patched to a deterministic torch function);
+    the relaxation itself is the callable ``relax_fn(ref_mol, ligand_pos [B,L,3], mmff_iters) -> [B,L,3]`` - RDKit's own
+    MMFF94 arithmetic (model.py:26-52) stays parity-unpinned (RDKit is not installed here; see oracle/mmff_oracle.py).
     """
     x_exists = batch["a_mask"]
     lig_w = batch["is_ligand"][batch["atom_id_to_token_id"]]
@@ -443,6 +446,13 @@ def sample_diffusion(P, batch, noise, num_sample=5, steps=200, gamma_0=0.8, gamm
                 e = template_epsilon(x_den[:, is_lig], ref_dist)
                 batch_ref_pos[:, is_lig] = ref_mol_poses[torch.argmin(e, dim=-1)]
             lig_den = weighted_rigid_align(x_den * x_exists[..., None], batch_ref_pos, w)
+            d_lig = (x_hat - lig_den) / t_hat[:, None, None] * w[None, :, None]
+            d_cur = (x_hat - x_den) / t_hat[:, None, None] * (1 - w[None, :, None]) + d_lig
+        elif ref_mol is not None and t_cur <= gamma_min * mmff_gamma_0_factor:        # model.py:252-261
+            w = x_exists * lig_w
+            x_ref = x_den.clone()
+            x_ref[:, is_lig] = relax_fn(ref_mol, x_den[:, is_lig], mmff_iters)
+            lig_den = weighted_rigid_align(x_den * x_exists[..., None], x_ref, w)
             d_lig = (x_hat - lig_den) / t_hat[:, None, None] * w[None, :, None]
             d_cur = (x_hat - x_den) / t_hat[:, None, None] * (1 - w[None, :, None]) + d_lig
         else:

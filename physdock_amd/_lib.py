@@ -21,6 +21,23 @@ LOG2E = 1.4426950408889634
 _fp = C.c_void_p
 
 
+def _header_abi_version():
+    """PD_ABI_VERSION of include/physdock_hip.h - the single source of the number every check compares against"""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "physdock_hip.h")
+    return int(re.search(r"#define\s+PD_ABI_VERSION\s+(\d+)", open(hdr).read()).group(1))
+
+
+ABI_VERSION = _header_abi_version()
+
+
+def header_symbols():
+    """names of every function include/physdock_hip.h declares"""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "physdock_hip.h")
+    return sorted(set(re.findall(r"^\s*int\s+(pd_\w+)\s*\(", open(hdr).read(), flags=re.M)))
+
+
 class GemmArgs(C.Structure):
     _fields_ = [
         ("A", _fp), ("W", _fp), ("Y", _fp),
@@ -39,7 +56,7 @@ class GemmArgs(C.Structure):
         ("out_scale", C.c_float),
         ("res", _fp), ("ldres", C.c_int), ("res_row_mod", C.c_int), ("sRes", C.c_longlong),
         ("out_mode", C.c_int), ("T1", C.c_int), ("T2", C.c_int), ("frag_transpose", C.c_int),
-        ("vecA", C.c_int), ("vecW", C.c_int), ("vecY", C.c_int), ("dbg", _fp),
+        ("vecA", C.c_int), ("vecW", C.c_int), ("vecY", C.c_int),
     ]
 
 
@@ -49,7 +66,7 @@ class AttnArgs(C.Structure):
         ("nq", C.c_int), ("nk", C.c_int), ("nbatch", C.c_int), ("nheads", C.c_int),
         ("q_bs", C.c_longlong), ("q_ss", C.c_longlong), ("k_bs", C.c_longlong), ("k_ss", C.c_longlong),
         ("v_bs", C.c_longlong), ("v_ss", C.c_longlong), ("o_bs", C.c_longlong), ("o_ss", C.c_longlong),
-        ("bias", _fp), ("scale", C.c_float), ("dbg", _fp),
+        ("bias", _fp), ("scale", C.c_float), ("bias_nk", C.c_int),
         ("ws", _fp), ("ws_bytes", C.c_longlong), ("nsplit", C.c_int),
     ]
 
@@ -71,8 +88,11 @@ def lib():
                 "(there is no CPU or PyTorch fallback for the sampler kernels)")
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
-        if _lib.pd_abi_version() != 2:
-            raise RuntimeError("libphysdock_hip.so ABI version mismatch")
+        if _lib.pd_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libphysdock_hip.so ABI version {_lib.pd_abi_version()} != header {ABI_VERSION}: rebuild "
+                               "(python -m physdock_amd.build --force)")
+        if _lib.pd_gemm_args_size() != C.sizeof(GemmArgs) or _lib.pd_attn_args_size() != C.sizeof(AttnArgs):
+            raise RuntimeError("ctypes mirrors of pd_gemm_args / pd_attn_args differ in size from the compiled structs")
     return _lib
 
 
@@ -89,6 +109,8 @@ def _declare(L):
 
     i, f, p, ll = C.c_int, C.c_float, C.c_void_p, C.c_longlong
     sig("pd_abi_version")
+    sig("pd_gemm_args_size")
+    sig("pd_attn_args_size")
     sig("pd_init")
     sig("pd_attention_occupancy")
     sig("pd_gemm", C.POINTER(GemmArgs), p)
@@ -120,6 +142,8 @@ def _declare(L):
     sig("pd_euler", p, p, p, p, f, f, f, p, i, i, p)
     sig("pd_pairwise_rmsd", p, p, p, p, p, i, i, i, p)
     sig("pd_timestep_embed", p, p, i, p)
+    sig("pd_ligand_gather", p, p, p, i, i, i, p)
+    sig("pd_ligand_scatter", p, p, p, p, i, i, i, p)
 
 
 def ptr(t):

@@ -39,6 +39,8 @@ def build(force=False, verbose=True):
         objs.append(obj)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
+        if os.environ.get("PD_LAB"):          # lab build: in-kernel phase traces + getenv tuning overrides (never shipped)
+            cmd[1:1] = ["-DPD_LAB=1"]
         if os.environ.get("PD_BK") and os.path.basename(src) == "gemm.hip":
             cmd[1:1] = ["-DPD_BK=" + os.environ["PD_BK"]]
         if os.environ.get("PD_STREAM_NOEMIT") and os.path.basename(src) == "gemm_stream.hip":

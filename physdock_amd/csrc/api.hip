@@ -3,6 +3,8 @@
 #include "physdock_hip.h"
 
 PD_EXPORT int pd_abi_version(void) { return PD_ABI_VERSION; }
+PD_EXPORT int pd_gemm_args_size(void) { return (int)sizeof(pd_gemm_args); }
+PD_EXPORT int pd_attn_args_size(void) { return (int)sizeof(pd_attn_args); }
 
 // hipGraph helpers: the sampler's step loop is host-deterministic (the schedule, the
 // noise on/off switch and the physics branch of reference model.py:213,223,252 are known

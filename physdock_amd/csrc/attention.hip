@@ -30,6 +30,10 @@ constexpr int KT = 64;      // keys per LDS tile
 constexpr int LDKS = 36;    // K row stride (floats): conflict-free ds_read_b128
 constexpr int LDVS = 32;    // V row stride
 
+#ifdef PD_LAB
+__device__ unsigned long long* g_attn_trace = nullptr;
+#endif
+
 // NW = waves (32-query tiles) per block: 4, or 8 for long query ranges - the K/V tiles staged through LDS are then shared
 // by twice as many MFMAs (half the global-load / LDS-write traffic per flop), at the same 4 waves per SIMD.
 // SPLIT: the key range is cut into p.nsplit chunks handled by different blocks (blockIdx.y = query block * nsplit + chunk);
@@ -68,7 +72,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) 
         }
     }
 
-    const int nkt32 = (p.nk + 31) >> 5;
+    // tile pitch of the bias buffer = the (padded) key / query counts its writer used (pd_gemm PD_OUT_BIASFRAG T2 / T1),
+    // which exceed the reduction bound nk when the boundary padded the sequence with masked entries
+    const int nkt32 = ((p.bias_nk > 0 ? p.bias_nk : p.nk) + 31) >> 5;
     const int nqt32 = (p.nq + 31) >> 5;
     const float* bias_wave = nullptr;
     if (p.bias && wave_active)
@@ -165,10 +171,14 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_kernel(const pd_attn_args p) 
         }
     };
     const int nfull32 = p.nk >> 5;                 // sub-tiles with all 32 keys in range
-    unsigned long long* dbg = nullptr;             // optional phase trace (tools/attn_trace.py)
-    if (p.dbg && lane == 0 && blockIdx.x < 8 && blockIdx.y < 2 && blockIdx.z == 0 && wave < 4)
-        dbg = reinterpret_cast<unsigned long long*>(p.dbg) + (((long long)blockIdx.y * 8 + blockIdx.x) * 4 + wave) * (4 * 64);
+#ifdef PD_LAB                                      // lab build only (tools/attn_trace.py): in-kernel phase trace
+    unsigned long long* dbg = nullptr;
+    if (g_attn_trace && lane == 0 && blockIdx.x < 8 && blockIdx.y < 2 && blockIdx.z == 0 && wave < 4)
+        dbg = g_attn_trace + (((long long)blockIdx.y * 8 + blockIdx.x) * 4 + wave) * (4 * 64);
 #define PD_STAMP(slot) if (dbg && it < 64) dbg[it * 4 + slot] = __builtin_amdgcn_s_memtime()
+#else
+#define PD_STAMP(slot)
+#endif
 
     for (int it = it_lo; it < nit; ++it) {
         const int cur = it & 1;
@@ -249,8 +259,11 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const pd_attn_args p)
 // number of key chunks pd_attention would use (1 = no split): only when the launch leaves most of the chip idle, the
 // key range is long enough and the caller supplied a workspace of nsplit * nbatch * nq * (32 + 2) * nheads floats
 static int attn_nsplit(const pd_attn_args* a) {
+#ifdef PD_LAB
     static const int on = [] { const char* e = getenv("PD_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
-    if (!on || !a->ws) return 1;
+    if (!on) return 1;
+#endif
+    if (!a->ws) return 1;
     const long long blocks = (long long)a->nbatch * a->nheads * ((a->nq + 127) / 128);
     const int nit = (a->nk + KT - 1) / KT;
     if (blocks >= 512 || nit < 8) return 1;
@@ -264,7 +277,11 @@ static int attn_nsplit(const pd_attn_args* a) {
 // waves per block pd_attention uses for these arguments (= template argument of attn_kernel; for profiling)
 PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
     if (!a) return PD_ERR_ARG;
+#ifdef PD_LAB
     static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
+#else
+    constexpr int wide = 1;
+#endif
     // 8-wave blocks pay off (+2 %) when they still fill the chip twice over; short query ranges / few batches keep 4 waves
     const int ns = attn_nsplit(a);
     if (ns > 1) return 4 + 100 * ns;                                   // split launch: 4-wave blocks, ns key chunks
@@ -297,6 +314,13 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     }
     return pd_check_launch();
 }
+
+#ifdef PD_LAB
+extern "C" __attribute__((visibility("default"))) int pd_lab_set_attn_trace(void* buf) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &p, sizeof(p)) == hipSuccess ? PD_OK : PD_ERR_LAUNCH;
+}
+#endif
 
 // resident blocks per CU the runtime computes for the kernel (diagnostic, tools/attn_trace.py)
 PD_EXPORT int pd_attention_occupancy(void) {

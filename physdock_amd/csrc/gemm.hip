@@ -38,6 +38,14 @@ constexpr int RPP = 256 / CH; // rows staged per pass of the 256 threads
 constexpr int NT = 256;
 constexpr int PADM = 4;
 
+#ifdef PD_LAB      // lab build only (tools/gemm_trace.py): in-kernel phase trace buffer + host-side tuning overrides
+__device__ unsigned long long* g_gemm_trace = nullptr;
+bool g_gemm_trace_on = false;
+#define PD_TRACE_PTR g_gemm_trace
+#else
+#define PD_TRACE_PTR ((unsigned long long*)nullptr)
+#endif
+
 template <int BM, int BN, bool AKM, bool WKM>
 struct Cfg {
     static constexpr int A_TILE = AKM ? BK * (BM + PADM) : BM * LDK;
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
     float* sA = smem;                 // 2 stages
     float* sW = smem + 2 * A_TILE;    // 2 stages
 
-    const unsigned long long t_entry = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_entry = PD_TRACE_PTR ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -246,8 +254,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pd_gemm_args p) {
 
     // optional in-kernel phase trace (debug): lane 0 of every wave of blocks < 64 stamps the shader clock
     unsigned long long* dbg = nullptr;
-    if (p.dbg && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 64)
-        dbg = reinterpret_cast<unsigned long long*>(p.dbg) + ((long long)blockIdx.x * 4 + wave) * (5 * 64);
+    if (PD_TRACE_PTR && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 64)
+        dbg = PD_TRACE_PTR + ((long long)blockIdx.x * 4 + wave) * (5 * 64);
 #define PD_STAMP(slot) if (dbg && kt < 60) dbg[kt * 5 + slot] = __builtin_amdgcn_s_memtime()
     if (dbg) { dbg[60 * 5 + 0] = t_entry; dbg[60 * 5 + 1] = __builtin_amdgcn_s_memtime(); }
     for (int kt = 0; kt < nk; ++kt) {
@@ -569,10 +577,12 @@ static int select_variant(pd_gemm_args& p, int& cfg, bool& akm, bool& wkm, bool&
     else if (p.N <= 64) cfg = 1;
     else cfg = 0;
     if (pro == 2 && cfg != 0 && cfg != 3) cfg = 0;
+#ifdef PD_LAB
     if (const char* f = getenv("PD_GEMM_CFG")) {      // tuning override: force a tile configuration where legal
         const int c = atoi(f);
         if (c >= 0 && c <= 3 && !akm && !wkm && !p.glu && vec && pro != 2) cfg = c;
     }
+#endif
     return cfg * 100 + (akm ? (wkm ? 2 : 1) : 0) * 10 + pro + (vec ? 0 : 1000);
 }
 
@@ -607,9 +617,21 @@ static int stream_tile(int cfg, const pd_gemm_args& p) {
 }
 
 static bool use_stream() {
+#ifdef PD_LAB
     static const int on = [] { const char* e = getenv("PD_GEMM_STREAM"); return e ? atoi(e) : 1; }();
-    return on != 0;
+    return on != 0 && !g_gemm_trace_on;          // the phase trace lives in the general kernel
+#else
+    return true;
+#endif
 }
+
+#ifdef PD_LAB
+extern "C" __attribute__((visibility("default"))) int pd_lab_set_gemm_trace(void* buf) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(buf);
+    g_gemm_trace_on = buf != nullptr;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &q, sizeof(q)) == hipSuccess ? PD_OK : PD_ERR_LAUNCH;
+}
+#endif
 
 // variant id as documented above; + 5000 + 10000 * EPI + 100000 * tile (0: 128x128, 1: 64x64, 2: 128x64) when the launch
 // goes to gemm_stream_kernel<pro, EPI, Tile<...>>
@@ -618,7 +640,7 @@ PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     pd_gemm_args p = *args;
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
-    if (v >= 0 && use_stream() && stream_tile(cfg, p) && !p.dbg) {
+    if (v >= 0 && use_stream() && stream_tile(cfg, p)) {
         pd_gemm_args head, tail;
         const int tile = stream_tile(cfg, p);
         const int epi = pd_gemm_stream_try(split_rows(p, pro, tile, head, tail) ? &head : &p, pro, tile, nullptr, 2);
@@ -633,7 +655,7 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
-    if (use_stream() && stream_tile(cfg, p) && !p.dbg) {
+    if (use_stream() && stream_tile(cfg, p)) {
         pd_gemm_args head, tail;
         const int tile = stream_tile(cfg, p);
         if (!split_rows(p, pro, tile, head, tail)) {

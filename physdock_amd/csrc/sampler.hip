@@ -372,6 +372,28 @@ __global__ __launch_bounds__(256) void euler_kernel(const float* __restrict__ x_
     x_next[idx] = xh + (eta * dt) * d;
 }
 
+// ------------------------------------------------------------------ ligand rows in / out of a pose batch (model.py:253-255)
+// gather : lig[b,l,:] = x[b, idx[l], :]                     (`x_denoised[:, is_ligand_atom]`)
+// scatter: dst = src; dst[b, idx[l], :] = lig[b,l,:]          (`x_ref = deepcopy(x_denoised); x_ref[:, is_ligand_atom] = ...`)
+__global__ __launch_bounds__(256) void ligand_gather_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                           float* __restrict__ lig, int A, int L, long long n) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int k = t % 3, l = (t / 3) % L;
+    const long long b = t / (3ll * L);
+    lig[t] = x[(b * A + idx[l]) * 3 + k];
+}
+__global__ __launch_bounds__(256) void ligand_scatter_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                            const float* __restrict__ lig, const int* __restrict__ slot,
+                                                            int A, int L, long long n) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int k = t % 3, a = (t / 3) % A;
+    const long long b = t / (3ll * A);
+    const int l = slot[a];                      // ligand slot of atom a, -1 for every other atom
+    dst[t] = l >= 0 ? lig[(b * L + l) * 3 + k] : src[t];
+}
+
 // emb[n,:] = [cos(tau f_k) | sin(tau f_k)], f_k = exp(-ln(1e4) k/128)      (timestep_embeddings.py:64-81)
 __global__ void timestep_embed_kernel(const float* __restrict__ tau, float* __restrict__ emb, int n) {
     const int i = blockIdx.x, k = threadIdx.x;          // 128 threads
@@ -459,6 +481,23 @@ PD_EXPORT int pd_euler(const float* x_hat, const float* x_den, const float* x_pr
     const long long n = (long long)B * A * 3;
     hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_hat, x_den, x_proj,
                        w, t_hat, eta, dt, x_next, A, n);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_ligand_gather(const float* x, const int* lig_idx, float* lig, int B, int A, int L, void* stream) {
+    if (!x || !lig_idx || !lig || B <= 0 || A <= 0 || L <= 0) return PD_ERR_ARG;
+    const long long n = 3ll * B * L;
+    hipLaunchKernelGGL(ligand_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, lig_idx, lig,
+                       A, L, n);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_ligand_scatter(float* dst, const float* src, const float* lig, const int* atom_slot, int B, int A, int L,
+                                void* stream) {
+    if (!dst || !src || !lig || !atom_slot || B <= 0 || A <= 0 || L <= 0) return PD_ERR_ARG;
+    const long long n = 3ll * B * A;
+    hipLaunchKernelGGL(ligand_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, lig,
+                       atom_slot, A, L, n);
     return pd_check_launch();
 }
 

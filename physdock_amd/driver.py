@@ -14,9 +14,11 @@ What the reference does per system, and what is kept here:
     closest to this round's poses under the sampler's own soft distance-difference metric (device, pd_template_match);
   * top-up with rejected poses when fewer than one round's worth was accepted (:336-337), alignment of every kept
     pose into the ground-truth frame with pocket weights (:341-342) and ranking (ranking.py, :357-423).
-Conformer generation (ETKDG, :231-243) is an input (`ref_mol_poses [C,L,3]`); the MMFF relaxation branch of the
-sampler needs an RDKit molecule and stays unavailable (model.sample_diffusion raises for ref_mol != None), so the
-ODE step scale follows the reference's no-molecule setting (`ode_step_scale_eta = 1.5`, :295).
+Conformer generation (ETKDG, :231-243) is an input (`ref_mol_poses [C,L,3]`).  `ref_mol` (an RDKit molecule, a
+`physdock_amd.mmff.MMFFTerms` table, or any object with `sampler_kwargs={"relax_fn": ...}`) is handed to the sampler in
+every round as the reference does (:292), which switches on the relaxation branch below the adaptive threshold; as in the
+reference a molecule whose atom count differs from the crop's ligand is dropped and the ODE step scale becomes 1.5
+(`ref_mol_num_error`, :195-196,292,296).
 """
 from __future__ import annotations
 
@@ -75,7 +77,15 @@ def next_gamma_factor(factor: float, any_accepted: bool) -> float:
     return factor * 1.15 if any_accepted else max(factor * 0.7, 1.0)
 
 
-def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol_poses: Optional[torch.Tensor] = None,
+def _mol_num_atoms(ref_mol) -> Optional[int]:
+    for attr in ("GetNumAtoms", "num_atoms"):
+        v = getattr(ref_mol, attr, None)
+        if v is not None:
+            return int(v() if callable(v) else v)
+    return None
+
+
+def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses: Optional[torch.Tensor] = None,
            accept_fn: Optional[Callable[[torch.Tensor], bool]] = None, physics_correction: bool = False,
            max_samples: int = 5, max_rounds: int = 10, num_samples_per_round: int = 5, steps: int = 40,
            mmff_gamma_0_factor_start: float = 6.0, karras_noise_schedule_power: float = 1000, use_pocket: bool = True,
@@ -89,6 +99,8 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol_poses: Optional[tor
         raise ValueError("physics correction needs reference conformers (ref_mol_poses [C,L,3]); the reference generates "
                          "them with RDKit ETKDG (redocking.py:231-243), which this build does not include")
     batch = dict(batch)
+    if ref_mol_poses is not None:            # the reference accepts host conformers (`.to(device)`, model.py:185)
+        ref_mol_poses = ref_mol_poses.to(batch["x_gt"].device)
     is_lig = ligand_atom_mask(batch)
     ligand_idx = torch.nonzero(is_lig).flatten().to(torch.int32)
     accept: List[torch.Tensor] = []
@@ -98,6 +110,8 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol_poses: Optional[tor
     factor = float(mmff_gamma_0_factor_start)
     log = []
     kw = dict(sampler_kwargs or {})
+    n_mol = _mol_num_atoms(ref_mol) if ref_mol is not None else None
+    ref_mol_num_error = ref_mol is None or (n_mol is not None and n_mol != int(is_lig.sum()))     # redocking.py:195-196
     for rnd in range(max_rounds):
         if rnd > 0 and not physics_correction:
             break
@@ -108,8 +122,10 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol_poses: Optional[tor
             batch["msa_feat"] = batch["batch_msa_feat"][rnd]
         templates = torch.stack(ligand_templates + reference_templates, 0) if rnd > 0 else None
         call = dict(num_sample=num_samples_per_round, steps=steps, mmff_gamma_0_factor=factor, align_ref_pos=rnd > 0,
-                    ref_mol=None, ref_mol_poses=templates, use_ref_mol_poses=rnd != 0 and physics_correction,
-                    ode_step_scale_eta=1.5, karras_noise_schedule_power=karras_noise_schedule_power)
+                    ref_mol=None if ref_mol_num_error else ref_mol, ref_mol_poses=templates,
+                    use_ref_mol_poses=rnd != 0 and physics_correction,
+                    ode_step_scale_eta=1.5 if ref_mol_num_error else 1.0,
+                    karras_noise_schedule_power=karras_noise_schedule_power)
         if seed is not None:
             call.update(seed=seed + rnd)
         call.update(kw)

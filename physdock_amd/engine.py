@@ -104,7 +104,7 @@ class Engine:
         o = self.ws.get("attn_o", rows, C)
         st4 = (N * 4 * C, 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=nk or N, nbatch=nbatch, nheads=H,
-                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias,
+                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias, bias_nk=N,
                       ws=self.attn_ws(nbatch, N, nk or N, H))
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         ops.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s)
@@ -162,7 +162,7 @@ class Engine:
         else:
             st4, sto = (4 * C, T * 4 * C), (C, T * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
-                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias)
+                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T)
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         ops.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z)
 
@@ -377,7 +377,7 @@ class Engine:
         o = self.lws("dit_o", rows, C)
         st3 = (N * 3 * C, 3 * C)
         ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, nq=N, nk=nk, nbatch=B, nheads=H,
-                      q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias,
+                      q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias, bias_nk=N,
                       ws=self.attn_ws(B, N, nk, H))
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         ops.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)

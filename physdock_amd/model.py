@@ -11,8 +11,8 @@ without the built library or without a GPU the calls raise.
 Extensions (keyword-only, not in the reference): ``noise=`` injects pre-drawn random
 numbers (parity mode; same draw order as the reference, see oracle), ``seed=`` /
 ``sample_offset=`` select the on-device Philox streams (perf / multi-GPU mode),
-``use_graph=`` replays the step loop from a hipGraph, ``lanes=`` sets the number of concurrent sample lanes
-(independent sample groups on forked HIP streams; experimental, default 1).
+``use_graph=`` replays the step loop from a hipGraph, ``relax_fn=`` / ``mmff_backend=`` choose how the ``ref_mol``
+relaxation branch runs (physics.py), ``conditioning=`` / ``return_conditioning=`` share one trunk run between calls.
 """
 from __future__ import annotations
 
@@ -57,8 +57,8 @@ class PhysDock(nn.Module):
             _register(self, name, torch.zeros(shape))
         self._packed: Optional[PackedWeights] = None
         self._engine: Optional[Engine] = None
-        self._graphs = {}
-        self._side_streams = []
+        self._graphs = {}                 # step-loop hipGraphs, LRU-ordered (dict insertion order)
+        self.max_cached_graphs = 16
         #: workspace buffers are cached per shape (288 GB of HBM make re-allocation pointless for a stream of
         #: same-size crops); when systems of many different sizes pass through, the cache is dropped beyond this size
         self.workspace_limit_bytes = 160 * 2 ** 30
@@ -68,15 +68,17 @@ class PhysDock(nn.Module):
     def _invalidate(self):
         self._packed = None
         self._engine = None
+        self._drop_graphs()
+
+    def _drop_graphs(self):
         for g in self._graphs.values():
-            ops._lib.lib().pd_graph_destroy(g["exec"])
+            for ex in g["exec"]:
+                ops._lib.lib().pd_graph_destroy(ex)
         self._graphs = {}
 
     def release_workspace(self):
         """free every cached activation buffer and captured step-loop graph (they are rebuilt on the next call)"""
-        for g in self._graphs.values():
-            ops._lib.lib().pd_graph_destroy(g["exec"])
-        self._graphs = {}
+        self._drop_graphs()
         if self._engine is not None:
             torch.cuda.synchronize(self._engine.device)
             self._engine.ws.bufs.clear()
@@ -209,11 +211,17 @@ class PhysDock(nn.Module):
             seed: int = 0,
             sample_offset: int = 0,
             use_graph: bool = True,
-            lanes: int = 0,
             conditioning=None,
             return_conditioning: bool = False,
+            relax_fn=None,
+            mmff_backend: str = "auto",
     ) -> torch.Tensor:
-        """reference models/model.py:157-282.  Returns x_next [num_sample, A, 3] on the batch device."""
+        """reference models/model.py:157-282.  Returns x_next [num_sample, A, 3] on the batch device.
+
+        `ref_mol` switches on the relaxation branch (model.py:252-261) exactly as in the reference; how the relaxed
+        ligand is produced is described in physics.py (device MMFF94 kernel, host RDKit, or an injected `relax_fn` with
+        the signature of the reference's `get_next_step_pos`)."""
+        from . import physics
         device = batch["x_gt"].device
         eng = self.engine(device)
         if eng.ws.nbytes() > self.workspace_limit_bytes:
@@ -225,16 +233,21 @@ class PhysDock(nn.Module):
         A = batch["ref_pos"].shape[0]            # padded atom count
         A_real = batch["_A_real"]
         sp = ops.stream()
+        if B <= 0:
+            return torch.empty(0, A_real, 3, device=device)
 
-        if ref_mol is not None:
-            raise NotImplementedError(
-                "ref_mol (RDKit MMFF94 relaxation on the host, reference model.py:26-52,252-261) needs RDKit, which "
-                "is not available in this build; pass ref_mol=None (template projection via ref_mol_poses is supported)")
-        if ref_mol_poses is None and use_ref_mol_poses:
-            raise NotImplementedError("conformer generation (RDKit ETKDG, model.py:188-203) is not available; pass ref_mol_poses")
+        relaxer = physics.resolve_relaxer(ref_mol, relax_fn, mmff_backend)
+        if ref_mol_poses is None and use_ref_mol_poses:      # model.py:188-203: ETKDG conformers of the reference molecule
+            if not (ref_mol is not None and physics.have_rdkit() and physics._is_rdkit_mol(ref_mol)):
+                raise RuntimeError("use_ref_mol_poses=True without ref_mol_poses needs an RDKit ref_mol (and RDKit) to embed "
+                                   "conformers (reference model.py:188-203); pass ref_mol_poses [C,L,3]")
+            n_lig_real = int((batch["is_ligand"][batch["atom_id_to_token_id"]][:A_real] > 0).sum())
+            ref_mol_poses = physics.rdkit_ref_mol_poses(ref_mol, 512)[:, :n_lig_real]
 
         sig, plan = self._step_plan(steps, gamma_0, gamma_min, step_scale_eta, ode_step_scale_eta, mmff_gamma_0_factor,
                                     align_ref_pos, karras_noise_schedule_power)
+        for p in plan:                                        # the elif of model.py:252 is only reachable with a molecule
+            p["mmff"] = bool(p["mmff"] and not p["align"] and relaxer.kind != "none")
 
         # ---- per-call setup: conditioning trunk, hoisted biases, AdaLN tables
         a, ap, s, z = conditioning if conditioning is not None else eng.conditioning(batch)
@@ -243,142 +256,173 @@ class PhysDock(nn.Module):
         prep = eng.prepare_dit(a, ap, s, z, batch, tau)
 
         # Everything the step loop reads is staged in workspace buffers: a captured hipGraph replays raw addresses, so
-        # no caller-owned or per-call temporary tensor may be referenced from inside the loop.
+        # no caller-owned or per-call temporary tensor may be referenced from inside the loop (a / s included: a graph
+        # captured with the trunk's own outputs must stay valid when a later call passes conditioning=, and vice versa).
         def staged(name, t):
             buf = ws.get("loop:" + name, *t.shape, dtype=t.dtype)
             buf.copy_(t)
             return buf
-        if conditioning is not None:
-            a, s = staged("a", a), staged("s", s)
+        cond_out = (a, ap, s, z)
+        a, s = staged("a", a), staged("s", s)
         batch = dict(batch)
-        for k in ("a_mask", "atom_id_to_token_id", "_tok_start"):
+        for k in ("a_mask", "atom_id_to_token_id", "_tok_start", "ref_pos"):
             batch[k] = staged(k, batch[k])
+        lig_flag = batch["is_ligand"][batch["atom_id_to_token_id"]]          # index gather on metadata, once per call
         lig_w = ws.get("lig_w", A)
-        lig_w.copy_(batch["a_mask"] * batch["is_ligand"][batch["atom_id_to_token_id"]])   # index gather: metadata
+        lig_w.copy_(batch["a_mask"] * lig_flag)
         any_align = any(p["align"] for p in plan)
-        ref_dist = poses = lig_idx = None
+        any_mmff = any(p["mmff"] for p in plan)
+        ref_dist = poses = lig_idx = atom_slot = None
         n_conf = n_lig = 0
+        if (any_align and ref_mol_poses is not None) or any_mmff:
+            lig_idx = torch.nonzero(lig_flag > 0).flatten().to(torch.int32)
+            n_lig = int(lig_idx.numel())
+            lig_idx = staged("lig_idx", lig_idx)
         if any_align:
             bref = ws.get("batch_ref_pos", B, A, 3)
-            bref.copy_(batch["ref_pos"][None].expand(B, A, 3))
-            if ref_mol_poses is not None:
-                lig_idx = torch.nonzero(batch["is_ligand"][batch["atom_id_to_token_id"]] > 0).flatten().to(torch.int32)
-                n_lig = int(lig_idx.numel())
-                lig_idx = staged("lig_idx", lig_idx)
-                if ref_mol_poses.shape[1] == n_lig:      # mismatch: reference silently keeps ref_pos (model.py:229-243)
-                    poses = staged("poses", ref_mol_poses.to(device).float())
-                    n_conf = poses.shape[0]
-                    ref_dist = ws.get("ref_dist", n_conf, n_lig, n_lig)
-                    ops.check(L.pd_pose_dist(ops.ptr(poses), ops.ptr(ref_dist), n_conf, n_lig, sp), "pose_dist")
+            if ref_mol_poses is not None and ref_mol_poses.shape[1] == n_lig:   # mismatch: reference silently keeps ref_pos (model.py:229-243)
+                poses = staged("poses", ref_mol_poses.to(device).float())
+                n_conf = poses.shape[0]
+                ref_dist = ws.get("ref_dist", n_conf, n_lig, n_lig)
+                ops.check(L.pd_pose_dist(ops.ptr(poses), ops.ptr(ref_dist), n_conf, n_lig, sp), "pose_dist")
+        if any_mmff:
+            if n_lig == 0:
+                raise ValueError("ref_mol given but the crop has no ligand atoms")
+            x_ref = ws.get("x_ref", B, A, 3)
+            if relaxer.kind == "host":
+                slot = torch.full((A,), -1, dtype=torch.int32, device=device)
+                slot[lig_idx.long()] = torch.arange(n_lig, dtype=torch.int32, device=device)
+                atom_slot = staged("atom_slot", slot)
+                lig_in = ws.get("lig_in", B, n_lig, 3)
+                lig_out = ws.get("lig_out", B, n_lig, 3)
+            else:
+                mm = relaxer.terms.device_tables(device, n_lig)
+                mm_ws = ws.get("mmff_ws", relaxer.terms.workspace_numel(B), dtype=torch.float64)
 
-        # ---- sample lanes: the B samples are split into independent groups that run the whole loop on their own
-        #      HIP streams (forked branches of one hipGraph).  Samples never interact (model.py:211-281), and two
-        #      de-phased kernel streams fill each other's launch / epilogue ramps.
-        n_lanes = max(1, min(int(lanes) if lanes else 1, B))   # measured on MI355X: forked lanes do not overlap better than one stream
-        bounds = [(h * B) // n_lanes for h in range(n_lanes + 1)]
-        lane_rng = [(bounds[h], bounds[h + 1] - bounds[h]) for h in range(n_lanes)]
-        while len(self._side_streams) < n_lanes - 1:
-            self._side_streams.append(torch.cuda.Stream(device=device))
-
-        # ---- random numbers: parity mode copies the caller's draws into fixed (per-lane contiguous) buffers
+        # ---- random numbers: parity mode copies the caller's draws into fixed buffers
         x_a = ws.get("x_a", B, A, 3)
         x_hat = ws.get("x_hat", B, A, 3)
         x_den = ws.get("x_den", B, A, 3)
         x_proj = ws.get("x_proj", B, A, 3)
         n_noisy = sum(p["noisy"] for p in plan)
-        lane_noise = []
         if noise is not None:
-            for h, (b0, Bh) in enumerate(lane_rng):
-                n_init = ws.get(f"n_init@{h}", Bh, A, 3, zero=True); n_init[:, :A_real].copy_(noise["init"][b0:b0 + Bh])
-                n_rot = ws.get(f"n_rot@{h}", steps, 4, Bh); n_rot.copy_(noise["rot_u"][:, :, b0:b0 + Bh])
-                n_tr = ws.get(f"n_trans@{h}", steps, Bh, 3); n_tr.copy_(noise["trans"][:, b0:b0 + Bh])
-                n_dif = ws.get(f"n_diffuse@{h}", max(n_noisy, 1), Bh, A, 3, zero=True)
-                if n_noisy:
-                    n_dif[:n_noisy, :, :A_real].copy_(noise["diffuse"][:, b0:b0 + Bh])
-                lane_noise.append((n_init, n_rot, n_tr, n_dif))
+            n_init = ws.get("n_init", B, A, 3, zero=True); n_init[:, :A_real].copy_(noise["init"])
+            n_rot = ws.get("n_rot", steps, 4, B); n_rot.copy_(noise["rot_u"])
+            n_tr = ws.get("n_trans", steps, B, 3); n_tr.copy_(noise["trans"])
+            n_dif = ws.get("n_diffuse", max(n_noisy, 1), B, A, 3, zero=True)
+            if n_noisy:
+                n_dif[:n_noisy, :, :A_real].copy_(noise["diffuse"])
             seed_buf = None
         else:
             seed_buf = ws.get("seed", 1, dtype=torch.int64)
             seed_buf.fill_(int(seed))
+        k_noisy = [sum(q["noisy"] for q in plan[:i]) for i in range(steps)]
 
-        def lane_step(h, i, p, k_noisy):
-            """one reverse-diffusion step of lane h (reference model.py:212-281) on the current stream"""
-            b0, Bh = lane_rng[h]
+        def step_head(i):
+            """model.py:212-221: augmentation, noise injection, denoiser (and the ligand read-out of a host relaxation)"""
+            p = plan[i]
             sp_ = ops.stream()
-            xa, xh, xd, xp = x_a[b0:b0 + Bh], x_hat[b0:b0 + Bh], x_den[b0:b0 + Bh], x_proj[b0:b0 + Bh]
+            if i == 0 and any_align:     # `batch_ref_pos = ref_pos[None].repeat(...)` (model.py:183): part of the replayed loop
+                bref.copy_(batch["ref_pos"][None].expand(B, A, 3))
             if noise is not None:
-                n_init, n_rot, n_tr, n_dif = lane_noise[h]
-                ru, tr = off(n_rot, i * 4 * Bh), off(n_tr, i * Bh * 3)
-                nz = off(n_dif, k_noisy * Bh * A * 3) if p["noisy"] else None
+                ru, tr = off(n_rot, i * 4 * B), off(n_tr, i * B * 3)
+                nz = off(n_dif, k_noisy[i] * B * A * 3) if p["noisy"] else None
                 sd_ptr = None
-                src, x_scale = (n_init, float(sig[0])) if i == 0 else (xa, 1.0)
+                src, x_scale = (n_init, float(sig[0])) if i == 0 else (x_a, 1.0)
             else:
                 ru = tr = nz = None
                 sd_ptr = ops.ptr(seed_buf)
-                src, x_scale = xa, 1.0
+                src, x_scale = x_a, 1.0
                 if i == 0:
-                    ops.check(L.pd_init_noise(ops.ptr(xa), sd_ptr, sample_offset + b0, float(sig[0]), Bh, A, sp_), "init_noise")
+                    ops.check(L.pd_init_noise(ops.ptr(x_a), sd_ptr, sample_offset, float(sig[0]), B, A, sp_), "init_noise")
             ops.check(L.pd_augment(ops.ptr(src), x_scale, ops.ptr(batch["a_mask"]), ru, tr, nz, float(noise_scale_lambda),
-                                   p["sdev"], sd_ptr, i, sample_offset + b0, ops.ptr(xh), Bh, A, sp_), "augment")
-            eng.lane = h
-            eng.af3_dit(batch, xh, xd, a, s, prep, Bh, p, row=i)
+                                   p["sdev"], sd_ptr, i, sample_offset, ops.ptr(x_hat), B, A, sp_), "augment")
+            eng.af3_dit(batch, x_hat, x_den, a, s, prep, B, p, row=i)
+            if p["mmff"] and relaxer.kind == "host":
+                ops.check(L.pd_ligand_gather(ops.ptr(x_den), ops.ptr(lig_idx), ops.ptr(lig_in), B, A, n_lig, sp_), "ligand_gather")
+
+        def step_tail(i):
+            """model.py:223-281: physics correction and Euler update"""
+            p = plan[i]
+            sp_ = ops.stream()
             if p["align"]:
-                br = bref[b0:b0 + Bh]
                 if poses is not None:
-                    ops.check(L.pd_template_match(ops.ptr(xd), ops.ptr(lig_idx), ops.ptr(ref_dist), ops.ptr(poses),
-                                                  ops.ptr(br), None, None, Bh, A, n_lig, n_conf, sp_), "template_match")
-                ops.check(L.pd_kabsch_align(ops.ptr(xd), ops.ptr(batch["a_mask"]), ops.ptr(br), A * 3, ops.ptr(lig_w),
-                                            ops.ptr(xp), Bh, A, sp_), "kabsch")
-                ops.check(L.pd_euler(ops.ptr(xh), ops.ptr(xd), ops.ptr(xp), ops.ptr(lig_w), p["t_hat"], p["eta"],
-                                     p["dt"], ops.ptr(xa), Bh, A, sp_), "euler")
+                    ops.check(L.pd_template_match(ops.ptr(x_den), ops.ptr(lig_idx), ops.ptr(ref_dist), ops.ptr(poses),
+                                                  ops.ptr(bref), None, None, B, A, n_lig, n_conf, sp_), "template_match")
+                target, tstride = bref, A * 3
+            elif p["mmff"]:
+                if relaxer.kind == "host":
+                    ops.check(L.pd_ligand_scatter(ops.ptr(x_ref), ops.ptr(x_den), ops.ptr(lig_out), ops.ptr(atom_slot),
+                                                  B, A, n_lig, sp_), "ligand_scatter")
+                else:
+                    relaxer.terms.launch_relax(mm, x_den, lig_idx, x_ref, mm_ws, B, A, int(mmff_iters), sp_)
+                target, tstride = x_ref, A * 3
             else:
-                ops.check(L.pd_euler(ops.ptr(xh), ops.ptr(xd), None, None, p["t_hat"], p["eta"], p["dt"],
-                                     ops.ptr(xa), Bh, A, sp_), "euler")
+                ops.check(L.pd_euler(ops.ptr(x_hat), ops.ptr(x_den), None, None, p["t_hat"], p["eta"], p["dt"],
+                                     ops.ptr(x_a), B, A, sp_), "euler")
+                return
+            ops.check(L.pd_kabsch_align(ops.ptr(x_den), ops.ptr(batch["a_mask"]), ops.ptr(target), tstride, ops.ptr(lig_w),
+                                        ops.ptr(x_proj), B, A, sp_), "kabsch")
+            ops.check(L.pd_euler(ops.ptr(x_hat), ops.ptr(x_den), ops.ptr(x_proj), ops.ptr(lig_w), p["t_hat"], p["eta"],
+                                 p["dt"], ops.ptr(x_a), B, A, sp_), "euler")
 
-        def run_loop():
-            """the hot loop: no host sync, no allocation -> capturable; lanes fork from / join to the current stream"""
-            main = torch.cuda.current_stream()
-            streams = [main] + self._side_streams[:n_lanes - 1]
-            if n_lanes > 1:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                for st_ in streams[1:]:
-                    st_.wait_event(ev)
-            k_noisy = 0
-            for i, p in enumerate(plan):
-                for h in range(n_lanes):
-                    with torch.cuda.stream(streams[h]):
-                        lane_step(h, i, p, k_noisy)
-                k_noisy += int(p["noisy"])
-            for st_ in streams[1:]:
-                ev = torch.cuda.Event()
-                ev.record(st_)
-                main.wait_event(ev)
-            eng.lane = 0
+        # The loop is host-deterministic except for a host relaxation, which needs the denoised ligand on the host in
+        # the middle of a step: segments end after the head of such a step and the next one starts with its tail.
+        segments, cur = [], []
+        for i, p in enumerate(plan):
+            cur.append((step_head, i))
+            if p["mmff"] and relaxer.kind == "host":
+                segments.append((cur, i))
+                cur = []
+            cur.append((step_tail, i))
+        segments.append((cur, None))
 
+        def run_segment(seg):
+            for fn, i in seg:
+                fn(i)
+
+        def host_relax():
+            lig_out.copy_(relaxer(lig_in.clone(), int(mmff_iters)).to(device=device, dtype=torch.float32))
+
+        graphs = None
         if use_graph:
-            key = (B, A, batch["target_feat"].shape[0], steps, noise is not None, poses is not None and (n_conf, n_lig), n_lanes,
-                   tuple((p["t_hat"], p["align"], p["eta"]) for p in plan), float(noise_scale_lambda), sample_offset)
-            g = self._graphs.get(key)
-            if g is None:
-                run_loop()                      # eager warm-up: allocates every workspace buffer before capture
+            key = (B, A, batch["target_feat"].shape[0], steps, noise is not None, poses is not None and (n_conf, n_lig),
+                   relaxer.kind, relaxer.kind == "device" and relaxer.terms.signature(), any_mmff and int(mmff_iters),
+                   tuple((p["t_hat"], p["align"], p["mmff"], p["eta"]) for p in plan), float(noise_scale_lambda), sample_offset)
+            graphs = self._graphs.get(key)
+            if graphs is not None:
+                self._graphs[key] = self._graphs.pop(key)          # LRU order
+        if graphs is not None:
+            for (seg, brk), g in zip(segments, graphs["exec"]):
+                ops.check(L.pd_graph_launch(g, sp), "graph_launch")
+                if brk is not None:
+                    host_relax()
+        else:
+            # eager pass: it produces this call's result AND allocates every workspace buffer, so the capture below
+            # (which only records) needs no launch of its own - a cache miss costs one loop, not two
+            for seg, brk in segments:
+                run_segment(seg)
+                if brk is not None:
+                    host_relax()
+            if use_graph:
                 torch.cuda.synchronize()
+                execs = []
                 cap = torch.cuda.Stream()
                 with torch.cuda.stream(cap):
-                    ops.check(L.pd_graph_begin(ops.stream()), "graph_begin")
-                    run_loop()
-                    ex = C.c_void_p()
-                    ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
-                g = {"exec": ex}
-                self._graphs[key] = g
-                if any_align:                   # the warm-up run modified batch_ref_pos
-                    bref.copy_(batch["ref_pos"][None].expand(B, A, 3))
-            ops.check(L.pd_graph_launch(g["exec"], sp), "graph_launch")
-        else:
-            run_loop()
+                    for seg, brk in segments:
+                        ops.check(L.pd_graph_begin(ops.stream()), "graph_begin")
+                        run_segment(seg)
+                        ex = C.c_void_p()
+                        ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
+                        execs.append(ex)
+                self._graphs[key] = {"exec": execs}
+                while len(self._graphs) > self.max_cached_graphs:
+                    old = self._graphs.pop(next(iter(self._graphs)))
+                    for ex in old["exec"]:
+                        L.pd_graph_destroy(ex)
         out = x_a[:, :A_real].clone()
         if return_conditioning:
-            return out, (a, ap, s, z)
+            return out, tuple(t.clone() for t in cond_out)
         return out
 
     @torch.no_grad()

@@ -63,18 +63,21 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
     a.out_scale = out_scale
     a.res, a.ldres, a.res_row_mod, a.sRes = P(res), (ldres or n_out), res_row_mod, sRes
     a.out_mode, a.T1, a.T2, a.frag_transpose = out_mode, T1, T2, int(frag_transpose)
-    if GEMM_DBG is not None:
-        a.dbg = GEMM_DBG.data_ptr()
     if GEMM_HOOK is not None:
         return GEMM_HOOK(a, lambda: check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm"))
     check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm")
 
 
-#: optional in-kernel phase-trace buffer for the attention kernel (int64, 16*4*4*64 entries), see tools/attn_trace.py
-ATTN_DBG = None
+def lab_set_trace(kind, buf):
+    """Lab builds only (PD_LAB=1 python -m physdock_amd.build --force): point the in-kernel phase trace of the GEMM
+    ("gemm": int64 tensor of 64*4*5*64 entries, tools/gemm_trace.py) or attention kernel ("attn": 16*4*4*64,
+    tools/attn_trace.py) at `buf` (None: off).  The production library has no trace code and no such symbol."""
+    fn = getattr(_lib.init(), f"pd_lab_set_{kind}_trace", None)
+    if fn is None:
+        raise RuntimeError("phase traces need a lab build: PD_LAB=1 python -m physdock_amd.build --force")
+    fn.argtypes = [C.c_void_p]
+    check(fn(buf.data_ptr() if buf is not None else None), "pd_lab_set_trace")
 
-#: optional in-kernel phase-trace buffer (int64 tensor of 64*4*5*64 entries), see tools/gemm_trace.py
-GEMM_DBG = None
 
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None
@@ -103,9 +106,10 @@ def attn_split_ws_numel(nbatch, nq, nk, nheads):
 
 
 def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_strides, o_strides, bias=None,
-              scale=1.0 / math.sqrt(32.0), ws=None):
+              scale=1.0 / math.sqrt(32.0), ws=None, bias_nk=0):
     """strides = (batch_stride, seq_stride) in floats; Q/K/V/O tensors or raw addresses.  ws: optional float scratch
-    tensor (attn_split_ws_numel) enabling key-split launches for small grids."""
+    tensor (attn_split_ws_numel) enabling key-split launches for small grids.  bias_nk: key count the bias buffer was laid
+    out for (the padded count when nk is the real one)."""
     def P(x):
         return x if (x is None or isinstance(x, int)) else ptr(x)
     a = AttnArgs()
@@ -117,10 +121,9 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
     a.o_bs, a.o_ss = o_strides
     a.bias = P(bias)
     a.scale = scale
+    a.bias_nk = bias_nk
     if ws is not None:
         a.ws, a.ws_bytes = ptr(ws), ws.numel() * 4
-    if ATTN_DBG is not None:
-        a.dbg = ATTN_DBG.data_ptr()
     if ATTN_HOOK is not None:
         return ATTN_HOOK(a, lambda: check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention"))
     check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention")

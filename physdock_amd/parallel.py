@@ -25,9 +25,9 @@ def shard_range(num_sample: int, rank: int, world: int):
 def gather_poses(x_local: torch.Tensor, num_sample: int, dst: int = 0):
     """Gather per-rank pose blocks [B_r, A, 3] to `dst`; returns [num_sample, A, 3] there, None elsewhere.
     Blocks may differ in size by one sample, so every rank pads to the largest block."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return x_local
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = dist.get_world_size(), dist.get_rank()     # world size 1 still goes through the collective (RCCL self-test)
     bmax = max(shard_range(num_sample, r, world)[1] - shard_range(num_sample, r, world)[0] for r in range(world))
     pad = x_local.new_zeros((bmax,) + tuple(x_local.shape[1:]))
     pad[: x_local.shape[0]] = x_local
@@ -45,10 +45,19 @@ def gather_poses(x_local: torch.Tensor, num_sample: int, dst: int = 0):
 def sample_diffusion_parallel(model, batch, num_sample: int, **kw):
     """Strong-scaling form of `model.sample_diffusion`: the `num_sample` poses of one call are split
     over the ranks; rank 0 gets all of them back (others get None)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return model.sample_diffusion(batch, num_sample=num_sample, **kw)
     lo, hi = shard_range(num_sample, dist.get_rank(), dist.get_world_size())
-    x = model.sample_diffusion(batch, num_sample=hi - lo, sample_offset=kw.pop("sample_offset", 0) + lo, **kw)
+    if kw.get("noise") is not None:      # parity mode: every rank consumes its own block of the caller's draws
+        nz = kw["noise"]
+        kw["noise"] = {"init": nz["init"][lo:hi], "rot_u": nz["rot_u"][:, :, lo:hi], "trans": nz["trans"][:, lo:hi],
+                       "diffuse": nz["diffuse"][:, lo:hi]}
+    offset = kw.pop("sample_offset", 0) + lo
+    if hi > lo:
+        x = model.sample_diffusion(batch, num_sample=hi - lo, sample_offset=offset, **kw)
+    else:                                # more ranks than samples: an empty block still takes part in the gather
+        ref = batch["x_gt"]
+        x = ref.new_zeros((0,) + tuple(ref.shape[-2:]), dtype=torch.float32)
     return gather_poses(x, num_sample)
 
 

@@ -1,0 +1,112 @@
+"""Host side of the sampler's molecule-dependent physics correction (reference models/model.py:26-52,188-203,252-261).
+
+The reference relaxes the denoised ligand of every sample with RDKit's MMFF94 (`get_next_step_pos`, model.py:26-52: set the
+conformer, `MMFFOptimizeMolecule(maxIters=mmff_iters, ignoreInterfragInteractions=True)`, read the conformer back) on the
+host, once per step while `t_cur <= gamma_min * mmff_gamma_0_factor`, and generates reference conformers with ETKDG when
+asked to use them without being given any (model.py:188-203).  RDKit is a third-party dependency (pip `rdkit==2024.3.3`)
+and its arithmetic is not restated by the reference, so this module offers three ways to run the branch, all behind the
+unchanged `sample_diffusion(ref_mol=...)` argument:
+
+* **device** - `ref_mol` is (or converts to) a table of MMFF94 terms (`mmff.MMFFTerms`): the relaxation runs in the HIP
+  kernel `pd_mmff_relax` inside the captured step loop, no host round trip (mmff.py, csrc/mmff.hip);
+* **host RDKit** - `ref_mol` is an RDKit molecule and RDKit is importable: the reference's own call sequence, per step, on
+  the host (`rdkit_get_next_step_pos`); the step loop is then captured in segments around the host calls;
+* **injected** - `relax_fn(ref_mol, ligand_pos [B,L,3], mmff_iters) -> [B,L,3]` (same signature as the reference's
+  `get_next_step_pos`): what the parity fixtures use, with the identical function patched into the reference.
+
+Nothing here computes on tensors: gather / scatter / Kabsch / Euler around the relaxation are launchers of libphysdock_hip.so.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+
+def have_rdkit() -> bool:
+    try:
+        import rdkit.Chem.AllChem  # noqa: F401
+        from rdkit.Chem import AllChem
+        return hasattr(AllChem, "MMFFOptimizeMolecule")
+    except Exception:
+        return False
+
+
+def _is_rdkit_mol(obj) -> bool:
+    return hasattr(obj, "GetConformer") and hasattr(obj, "GetNumAtoms")
+
+
+def rdkit_get_next_step_pos(ref_mol, current_step_pos: torch.Tensor, mmff_iters: int = 5) -> torch.Tensor:
+    """The reference's host relaxation (model.py:26-52) as a call sequence on RDKit: for every sample write the ligand
+    coordinates into the molecule's conformer, run `mmff_iters` MMFF94 BFGS iterations, read the coordinates back.
+    One conformer object is reused by all samples (every coordinate is overwritten first)."""
+    from rdkit.Chem import AllChem
+    from rdkit.Geometry import Point3D
+    n_atoms = ref_mol.GetNumAtoms()
+    pos = current_step_pos.detach().to("cpu", torch.float64)
+    out = torch.empty(pos.shape[0], n_atoms, 3, dtype=torch.float64)
+    for b in range(pos.shape[0]):
+        conf = ref_mol.GetConformer()
+        for i, (x, y, z) in enumerate(pos[b].tolist()[:conf.GetNumAtoms()]):
+            conf.SetAtomPosition(i, Point3D(x, y, z))
+        AllChem.MMFFOptimizeMolecule(ref_mol, mmffVariant="MMFF94", maxIters=int(mmff_iters),
+                                     ignoreInterfragInteractions=True)
+        conf = ref_mol.GetConformer()
+        for i in range(n_atoms):
+            p = conf.GetAtomPosition(i)
+            out[b, i, 0], out[b, i, 1], out[b, i, 2] = p.x, p.y, p.z
+    return out.to(current_step_pos.device, current_step_pos.dtype)
+
+
+def rdkit_ref_mol_poses(ref_mol, num_confs: int = 512) -> torch.Tensor:
+    """model.py:188-203: ETKDG conformers of the reference molecule -> [num_confs, n_atoms, 3] (zeros for failed embeddings,
+    as the reference leaves them)."""
+    import copy
+    from rdkit.Chem import AllChem
+    mol = copy.deepcopy(ref_mol)
+    cids = list(AllChem.EmbedMultipleConfs(mol, numConfs=num_confs, enforceChirality=True))
+    n = mol.GetNumAtoms()
+    xyz = torch.zeros(num_confs, n, 3)
+    for row, cid in enumerate(cids):
+        conf = mol.GetConformer(cid)
+        for j in range(n):
+            p = conf.GetAtomPosition(j)
+            xyz[row, j, 0], xyz[row, j, 1], xyz[row, j, 2] = p.x, p.y, p.z
+    return xyz
+
+
+class Relaxer:
+    """How the `elif ref_mol is not None and t_cur <= ...` branch (model.py:252-261) gets its relaxed ligand."""
+
+    def __init__(self, kind: str, fn: Optional[Callable] = None, terms=None, ref_mol=None):
+        assert kind in ("none", "host", "device")
+        self.kind, self.fn, self.terms, self.ref_mol = kind, fn, terms, ref_mol
+
+    def __call__(self, ligand_pos: torch.Tensor, mmff_iters: int) -> torch.Tensor:
+        out = self.fn(self.ref_mol, ligand_pos, mmff_iters)
+        if out.shape != ligand_pos.shape:
+            raise ValueError(f"relaxation returned {tuple(out.shape)} for ligand coordinates {tuple(ligand_pos.shape)}: the "
+                             "molecule's atom count differs from the number of ligand atoms in the crop")
+        return out
+
+
+def resolve_relaxer(ref_mol, relax_fn: Optional[Callable], mmff_backend: str = "auto") -> Relaxer:
+    """Pick the execution mode of the relaxation branch for this call (see module docstring)."""
+    if ref_mol is None:
+        return Relaxer("none")
+    if relax_fn is not None:
+        return Relaxer("host", fn=relax_fn, ref_mol=ref_mol)
+    from . import mmff
+    if isinstance(ref_mol, mmff.MMFFTerms):
+        return Relaxer("device", terms=ref_mol, ref_mol=ref_mol)
+    if _is_rdkit_mol(ref_mol):
+        if not have_rdkit():
+            raise RuntimeError("ref_mol is an RDKit molecule but RDKit is not importable in this process; pass "
+                               "physdock_amd.mmff.MMFFTerms (device relaxation) or relax_fn=")
+        if mmff_backend in ("auto", "device"):
+            terms = mmff.terms_from_rdkit(ref_mol, strict=(mmff_backend == "device"))
+            if terms is not None:
+                return Relaxer("device", terms=terms, ref_mol=ref_mol)
+        return Relaxer("host", fn=rdkit_get_next_step_pos, ref_mol=ref_mol)
+    raise TypeError(f"ref_mol of type {type(ref_mol).__name__}: expected an RDKit Mol (with RDKit installed), a "
+                    "physdock_amd.mmff.MMFFTerms table, or any object together with relax_fn=")

@@ -174,3 +174,14 @@ def reference_conformers(batch, n_conf=8, seed=1):
                           [2 * (a * c - b * w), 2 * (b * c + a * w), 1 - 2 * (a * a + b * b)]])
         out.append((x + 0.3 * torch.randn(x.shape, generator=g)) @ R.T)
     return torch.stack(out, 0).to(batch["x_gt"].dtype)
+
+
+def toy_relax_fn(ref_mol, ligand_pos, mmff_iters=5):
+    """Deterministic stand-in for the reference's `get_next_step_pos(ref_mol, pos, mmff_iters)` (model.py:26-52) used by
+    the parity fixtures: pulls every sample's ligand a fixed fraction towards a target conformer placed at the sample's
+    own centroid.  Pure torch, so the identical function can be patched into the reference (tools/make_golden.py G8/G9),
+    the oracle and the HIP path (`relax_fn=`).  `ref_mol` is the dict {"conf": [L,3]} the fixtures pass as the molecule."""
+    tgt = ref_mol["conf"].to(ligand_pos.device, ligand_pos.dtype)
+    tgt = tgt - tgt.mean(0, keepdim=True)
+    centre = ligand_pos.mean(1, keepdim=True)
+    return ligand_pos + (0.02 * mmff_iters) * (tgt[None] + centre - ligand_pos)

@@ -180,6 +180,24 @@ def test_g6_template_branch(small_model_inputs):
     assert rmsd(x, g["x_pred"]) < 1e-3
 
 
+@pytest.mark.parametrize("tag", ["round0", "template"])
+def test_g8_relaxation_branch(small_model_inputs, tag):
+    """model.py:252-261 (every tensor op and branch around the relaxation) against the reference run with the same
+    injected deterministic relaxation; RDKit's own MMFF arithmetic is not part of this fixture (parity unpinned)"""
+    from physdock_amd.synthetic import toy_relax_fn
+    cfg, P, batch = small_model_inputs
+    g = load_golden(f"g8_relax_{tag}")
+    kw = dict(align_ref_pos=False) if tag == "round0" else dict(align_ref_pos=True, ref_mol_poses=g["ref_mol_poses"])
+    x = orc.sample_diffusion(P, batch, golden_noise(g), num_sample=3, steps=g["steps"], ref_mol={"conf": g["mol_conf"]},
+                             relax_fn=toy_relax_fn, mmff_iters=g["mmff_iters"], mmff_gamma_0_factor=g["mmff_gamma_0_factor"],
+                             karras_noise_schedule_power=1000, **kw)
+    assert rmsd(x, g["x_pred"]) < 1e-3
+    # the branch matters: without the molecule the trajectory ends somewhere else
+    x0 = orc.sample_diffusion(P, batch, golden_noise(g), num_sample=3, steps=g["steps"],
+                              mmff_gamma_0_factor=g["mmff_gamma_0_factor"], karras_noise_schedule_power=1000, **kw)
+    assert rmsd(x0, g["x_pred"]) > 1e-2
+
+
 def test_g7_reselect():
     g = load_golden("g7_reselect")
     rd = torch.norm(g["ref_mol_poses"][:, :, None] - g["ref_mol_poses"][:, None], dim=-1)

@@ -14,9 +14,9 @@ run = lambda: ops.attention(q.data_ptr(), q.data_ptr() + 4 * C, q.data_ptr() + 8
 for _ in range(3):
     run()
 dbg = torch.zeros(16 * 4 * 4 * 64, dtype=torch.int64, device="cuda")
-ops.ATTN_DBG = dbg
+ops.lab_set_trace("attn", dbg)
 run(); torch.cuda.synchronize()
-ops.ATTN_DBG = None
+ops.lab_set_trace("attn", None)
 nit = min((n + 63) // 64, 64)
 d = dbg.cpu().reshape(16, 4, 64, 4)[:, :, :nit].double()
 ph = d[..., 1:] - d[..., :-1]

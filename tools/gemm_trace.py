@@ -10,10 +10,10 @@ A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda"); Y = 
 for _ in range(3):
     ops.gemm(A, W, Y, M, N, K)
 dbg = torch.zeros(64 * 4 * 5 * 64, dtype=torch.int64, device="cuda")
-ops.GEMM_DBG = dbg
+ops.lab_set_trace("gemm", dbg)
 ops.gemm(A, W, Y, M, N, K)
 torch.cuda.synchronize()
-ops.GEMM_DBG = None
+ops.lab_set_trace("gemm", None)
 nk = min((K + 31) // 32, 60)
 d = dbg.cpu().reshape(64, 4, 64, 5)[:, :, :nk].double()          # block, wave, kt, slot
 ph = d[..., 1:] - d[..., :-1]                                      # per-slice phase durations

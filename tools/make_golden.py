@@ -10,7 +10,13 @@ and outputs only.  Golden sets follow SURVEY §8(c): G1 primitives, G2 AF3DiT /
 DiffusionConditioning, G3 schedules, G4 augmentation / rigid align, G5 trajectories with
 all noise recorded, G6 template-projection branch, G7 template re-selection.
 
-    python tools/make_golden.py            # regenerates every fixture
+G8 pins the relaxation branch (model.py:252-261) by running the reference with `get_next_step_pos` patched to the
+deterministic torch function `physdock_amd.synthetic.toy_relax_fn`; G9 captures reference trajectories at the BENCHMARK
+shapes (medium model; cfg1 T=256/A=2048, a ragged T=256/A=1803 crop, cfg2 T=512/A=4096) so the GPU tests compare the HIP
+path with the reference itself at full size (the reference needs minutes of CPU per fixture; ~30 GB RAM for cfg2).
+
+    python tools/make_golden.py                 # regenerates every fixture (G9: ~10 minutes on 8 cores)
+    python tools/make_golden.py --sets g8,g9    # only the named sets (g1..g7 form one group: they share an RNG stream)
 """
 import json
 import os
@@ -68,8 +74,12 @@ def npz(name, **arrays):
 
 
 def main():
+    import argparse
     import warnings
     warnings.filterwarnings("ignore")
+    ap_ = argparse.ArgumentParser()
+    ap_.add_argument("--sets", default="g1-7,g8,g9")
+    sets = set(ap_.parse_args().sets.split(","))
     install_shims()
     os.makedirs(OUT, exist_ok=True)
 
@@ -88,6 +98,134 @@ def main():
     from physdock_amd.synthetic import small_batch, reference_conformers
 
     torch.set_num_threads(8)
+    if "g8" in sets or "g9" in sets:
+        import PhysDock.models.model as ref_model_module
+        from physdock_amd.synthetic import toy_relax_fn, make_batch, cfg1_batch, cfg2_batch
+    if "g1-7" in sets:
+        main_g1_g7(RefPhysDock, RefConfig, rp, rt, rdc, rtu, mlc)
+    if "g8" in sets:
+        main_g8(RefPhysDock, mlc, ref_model_module)
+    if "g9" in sets:
+        main_g9(RefPhysDock, RefConfig, ref_model_module)
+
+
+class Recorder:
+    """wraps torch.normal / torch.rand while the reference runs and logs every draw in call order"""
+
+    def __init__(self):
+        self.log = []
+
+    def __enter__(self):
+        self._n, self._r = torch.normal, torch.rand
+
+        def normal(*a, **k):
+            out = self._n(*a, **k)
+            self.log.append(("normal", out.clone()))
+            return out
+
+        def rand(*a, **k):
+            out = self._r(*a, **k)
+            self.log.append(("rand", out.clone()))
+            return out
+        torch.normal, torch.rand = normal, rand
+        return self
+
+    def __exit__(self, *e):
+        torch.normal, torch.rand = self._n, self._r
+
+
+def split_draws(log, B, steps, A):
+    """reference draw order -> the oracle's noise dict"""
+    kind, init = log[0]
+    assert kind == "normal" and init.shape == (B, A, 3)
+    rot, trans, dif = [], [], []
+    rest = list(log[1:])
+    i = 0
+    for _ in range(steps):
+        us = []
+        for _ in range(4):
+            assert rest[i][0] == "rand" and rest[i][1].shape == (B,)
+            us.append(rest[i][1]); i += 1
+        rot.append(torch.stack(us))
+        assert rest[i][0] == "normal" and rest[i][1].shape == (B, 3)
+        trans.append(rest[i][1]); i += 1
+        if i < len(rest) and rest[i][0] == "normal" and rest[i][1].shape == (B, A, 3):
+            dif.append(rest[i][1]); i += 1
+    assert i == len(rest)
+    return {"init": init, "rot_u": torch.stack(rot), "trans": torch.stack(trans),
+            "diffuse": torch.stack(dif) if dif else torch.zeros(0, B, A, 3)}
+
+
+def main_g8(RefPhysDock, mlc, ref_model_module):
+    """G8: relaxation branch of the sampler (model.py:252-261) with an injected deterministic relaxation"""
+    from physdock_amd.configs import small_config
+    from physdock_amd.params import param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import small_batch, reference_conformers, toy_relax_fn
+    cfg = small_config()
+    ref_model = RefPhysDock(mlc.ConfigDict(cfg.to_dict()))
+    ref_model.load_state_dict(seeded_state_dict(param_shapes(cfg), seed=0), strict=True)
+    ref_model.eval()
+    batch = small_batch(seed=0)
+    A = batch["ref_pos"].shape[0]
+    confs = reference_conformers(batch, n_conf=6, seed=1)
+    mol = {"conf": confs[2]}                 # the "molecule": opaque to the sampler, consumed by the relaxation only
+    ref_model_module.get_next_step_pos = toy_relax_fn
+    # (a) round 0 of redocking.py: align_ref_pos=False, molecule given -> relaxation below the threshold, plain steps above
+    # (b) rounds >= 1: template projection above the threshold, relaxation below
+    for tag, kw in (("round0", dict(align_ref_pos=False, ref_mol_poses=None, use_ref_mol_poses=False, mmff_gamma_0_factor=6.0)),
+                    ("template", dict(align_ref_pos=True, ref_mol_poses=confs, use_ref_mol_poses=True, mmff_gamma_0_factor=3.0,
+                                      ode_step_scale_eta=1.0, mmff_iters=3))):
+        B, steps = 3, 20
+        torch.manual_seed(21 + len(tag))
+        with Recorder() as r:
+            x_pred = ref_model.sample_diffusion(batch, num_sample=B, steps=steps, ref_mol=mol,
+                                                karras_noise_schedule_power=1000, **kw)
+        nz = split_draws(r.log, B, steps, A)
+        extra = {} if kw["ref_mol_poses"] is None else {"ref_mol_poses": confs}
+        npz(f"g8_relax_{tag}", x_pred=x_pred, steps=steps, mol_conf=mol["conf"], mmff_gamma_0_factor=kw["mmff_gamma_0_factor"],
+            mmff_iters=kw.get("mmff_iters", 5), **extra, **{"noise_" + k: v for k, v in nz.items()})
+
+
+def main_g9(RefPhysDock, RefConfig, ref_model_module):
+    """G9: reference trajectories at the benchmark shapes (medium model, seeded weights regenerated on both sides)"""
+    import time
+    from physdock_amd.configs import PhysDockConfig
+    from physdock_amd.params import param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import make_batch, cfg1_batch, cfg2_batch, reference_conformers, toy_relax_fn
+    ref_model = RefPhysDock(RefConfig(model_name="medium"))
+    ref_model.load_state_dict(seeded_state_dict(param_shapes(PhysDockConfig(model_name="medium")), seed=0), strict=True)
+    ref_model.eval()
+    ref_model_module.get_next_step_pos = toy_relax_fn
+    cases = (
+        # cfg1 with every physics branch: template projection above 6*gamma_min, relaxation below
+        ("cfg1", cfg1_batch(0), 2, 10, True),
+        # un-padded real crops are ragged: T = 256 (a multiple of 32) with A % 4 = 3 makes the boundary pad tokens too
+        ("ragged", make_batch(221, 8, 35, 64, 2), 1, 6, False),
+        ("cfg2", cfg2_batch(0), 1, 4, False),
+    )
+    for tag, batch, B, steps, physics in cases:
+        A = batch["ref_pos"].shape[0]
+        kw, extra = dict(align_ref_pos=False, ref_mol=None), {}
+        if physics:
+            confs = reference_conformers(batch, n_conf=8, seed=1)
+            kw = dict(align_ref_pos=True, ref_mol={"conf": confs[3]}, ref_mol_poses=confs, use_ref_mol_poses=True,
+                      mmff_gamma_0_factor=6.0)
+            extra = dict(ref_mol_poses=confs, mol_conf=confs[3], mmff_gamma_0_factor=6.0)
+        torch.manual_seed(900 + steps)
+        t0 = time.time()
+        with Recorder() as r:
+            x_pred = ref_model.sample_diffusion(batch, num_sample=B, steps=steps, karras_noise_schedule_power=1000, **kw)
+        nz = split_draws(r.log, B, steps, A)
+        print(f"  reference medium/{tag}: T={batch['target_feat'].shape[0]} A={A} B={B} steps={steps}: {time.time() - t0:.0f} s")
+        npz(f"g9_medium_{tag}", x_pred=x_pred, steps=steps, **extra, **{"noise_" + k: v for k, v in nz.items()})
+
+
+def main_g1_g7(RefPhysDock, RefConfig, rp, rt, rdc, rtu, mlc):
+    from physdock_amd.configs import PhysDockConfig, small_config, SMALL_OVERRIDES
+    from physdock_amd.params import param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import small_batch, reference_conformers
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    g_out = OUT
 
     # ---------------------------------------------------------------- parameter-name contract
     for tag, ref_cfg, my_cfg in (
@@ -213,50 +351,8 @@ def main():
         s200_p7=ref_model.karras_noise_schedule(num_steps=200, p=7),
         s40_p7=ref_model.karras_noise_schedule(num_steps=40, p=7))
 
-    # ---------------------------------------------------------------- recording RNG
-    class Recorder:
-        def __init__(self):
-            self.log = []
-
-        def __enter__(self):
-            self._n, self._r = torch.normal, torch.rand
-
-            def normal(*a, **k):
-                out = self._n(*a, **k)
-                self.log.append(("normal", out.clone()))
-                return out
-
-            def rand(*a, **k):
-                out = self._r(*a, **k)
-                self.log.append(("rand", out.clone()))
-                return out
-            torch.normal, torch.rand = normal, rand
-            return self
-
-        def __exit__(self, *e):
-            torch.normal, torch.rand = self._n, self._r
-
     def split_log(log, B, steps):
-        """reference draw order -> the oracle's noise dict"""
-        it = iter(log)
-        kind, init = next(it)
-        assert kind == "normal" and init.shape == (B, A, 3)
-        rot, trans, dif = [], [], []
-        rest = list(it)
-        i = 0
-        for _ in range(steps):
-            us = []
-            for _ in range(4):
-                assert rest[i][0] == "rand" and rest[i][1].shape == (B,)
-                us.append(rest[i][1]); i += 1
-            rot.append(torch.stack(us))
-            assert rest[i][0] == "normal" and rest[i][1].shape == (B, 3)
-            trans.append(rest[i][1]); i += 1
-            if i < len(rest) and rest[i][0] == "normal" and rest[i][1].shape == (B, A, 3):
-                dif.append(rest[i][1]); i += 1
-        assert i == len(rest)
-        return {"init": init, "rot_u": torch.stack(rot), "trans": torch.stack(trans),
-                "diffuse": torch.stack(dif) if dif else torch.zeros(0, B, A, 3)}
+        return split_draws(log, B, steps, A)
 
     # ---------------------------------------------------------------- G4 augmentation / align
     with torch.no_grad():

@@ -10,10 +10,10 @@ A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda"); Y = 
 for _ in range(3):
     ops.gemm(A, W, Y, M, N, K)
 dbg = torch.zeros(8 * 8 * 64 * 8, dtype=torch.int64, device="cuda")
-ops.GEMM_DBG = dbg
+ops.lab_set_trace("gemm", dbg)
 ops.gemm(A, W, Y, M, N, K)
 torch.cuda.synchronize()
-ops.GEMM_DBG = None
+ops.lab_set_trace("gemm", None)
 d = dbg.cpu().reshape(8, 8, 64, 8).double()      # block, wave (0-3 group 0, 4-7 group 1), phase, slot
 for grp in (0, 1):
     w = d[:, 4 * grp:4 * grp + 4]
