@@ -171,6 +171,38 @@ int pd_timestep_embed(const float* tau, float* emb, int n, void* stream);
 int pd_ligand_gather(const float* x, const int* lig_idx, float* lig, int B, int A, int L, void* stream);
 int pd_ligand_scatter(float* dst, const float* src, const float* lig, const int* atom_slot, int B, int A, int L, void* stream);
 
+/* ---- MMFF94 ligand relaxation on the device (mmff.hip) ----------------------------------------
+ * replaces the host loop `get_next_step_pos` (models/model.py:26-52): per sample
+ * AllChem.MMFFOptimizeMolecule(ref_mol, mmffVariant="MMFF94", maxIters=mmff_iters, ignoreInterfragInteractions=True)
+ * (RDKit: ForceField::minimize -> BFGSOpt::minimize over the MMFF94 contribs).  The molecule arrives as plain term
+ * tables (device pointers; int32 atom indices into the ligand, float64 parameters):
+ *   bond   [n][2] i,j      | kb, r0
+ *   angle  [n][3] i,j,k    | ka, theta0 (deg), linear flag (0/1)            j = central atom
+ *   strbnd [n][3] i,j,k    | kbaIJK, kbaKJI, r0_ij, r0_kj, theta0
+ *   oop    [n][4] i,j,k,l  | koop                                            j central, l the out-of-plane atom
+ *   tors   [n][4] i,j,k,l  | V1, V2, V3
+ *   vdw_R / vdw_eps / ele_qq [L][L] symmetric dense pair tables: R*_ij, eps_ij (0: pair excluded), q_i q_j / D with the
+ *                            0.75 1-4 factor folded in (0: excluded)
+ *   inc_ptr [L+1], inc: atom -> incident bonded terms (CSR); entry = kind << 28 | slot << 24 | term index,
+ *                       kind 0..4 in the order above, slot = position of the atom in the term's index row          */
+typedef struct pd_mmff_terms {
+    int n_atoms, n_bond, n_angle, n_strbnd, n_oop, n_tors;
+    const int* bond_idx;   const double* bond_par;
+    const int* angle_idx;  const double* angle_par;
+    const int* strbnd_idx; const double* strbnd_par;
+    const int* oop_idx;    const double* oop_par;
+    const int* tors_idx;   const double* tors_par;
+    const double* vdw_R;   const double* vdw_eps;  const double* ele_qq;
+    const int* inc_ptr;    const int* inc;
+} pd_mmff_terms;
+/* energy[b] (kcal/mol) and grad[b][L][3] of B conformations pos[b][L][3] (float64; either output may be NULL) */
+int pd_mmff_energy_grad(const pd_mmff_terms* terms, const double* pos, double* energy, double* grad, int B, void* stream);
+/* x_ref = x [B][A][3] with the rows lig_idx[0..L) replaced by their relaxed coordinates (`x_ref = deepcopy(x_denoised);
+ * x_ref[:, is_ligand_atom] = get_next_step_pos(...)`, model.py:253-255); max_iters = mmff_iters.
+ * ws: B * (9 L^2 + 24 L) float64 of scratch (inverse Hessian + BFGS vectors per sample)                            */
+int pd_mmff_relax(const pd_mmff_terms* terms, const float* x, const int* lig_idx, float* x_ref, double* ws,
+                  long long ws_doubles, int B, int A, int max_iters, void* stream);
+
 /* ---- hipGraph helpers (api.hip): capture the host-deterministic step loop once, replay it */
 int pd_graph_begin(void* stream);
 int pd_graph_end(void* stream, void** exec_out);

@@ -142,6 +142,8 @@ def _declare(L):
     sig("pd_euler", p, p, p, p, f, f, f, p, i, i, p)
     sig("pd_pairwise_rmsd", p, p, p, p, p, i, i, i, p)
     sig("pd_timestep_embed", p, p, i, p)
+    sig("pd_mmff_energy_grad", p, p, p, p, i, p)
+    sig("pd_mmff_relax", p, p, p, p, p, ll, i, i, i, p)
     sig("pd_ligand_gather", p, p, p, i, i, i, p)
     sig("pd_ligand_scatter", p, p, p, p, i, i, i, p)
 
@@ -149,7 +151,7 @@ def _declare(L):
 def ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.int64), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.float64, torch.int32, torch.int64), (t.device, t.dtype)
     return t.data_ptr()
 
 
