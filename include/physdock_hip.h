@@ -30,6 +30,11 @@ enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFR
 typedef struct pd_gemm_args {
     const float* A;          /* [M,K] row-major (lda) or, if a_kmajor, [K,M] */
     const float* W;          /* [N,K] row-major (ldw) or, if w_kmajor, [K,N] */
+    const void* W3;          /* optional: W pre-split into three bf16 parts, [3][N][Kp] with Kp = 32*ceil(K/32), zero padded
+                                (w = hi + mid + lo exactly).  When given and the problem is one of the full-tile row-major
+                                shapes, the contraction runs as six bf16 MFMAs per block with fp32 accumulation
+                                (csrc/gemm_split.hip: at least the accuracy of the fp32 MFMA, 2.67x its peak rate); W must
+                                still be valid (ragged row remainders and ineligible shapes use it).  NULL: fp32 MFMA.   */
     float* Y;
     int M, N, K;
     int lda, ldw, ldy;
@@ -73,7 +78,8 @@ typedef struct pd_gemm_args {
 int pd_gemm(const pd_gemm_args* args, void* stream);
 /* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling);
  * id % 10000 >= 5000: gemm_stream_kernel<id % 10, (id / 10000) % 10, Tile> (csrc/gemm_stream.hip) takes it,
- * Tile = id / 100000: 0 -> <128,128,2>, 1 -> <64,64,2>, 2 -> <128,64,4> */
+ * Tile = (id / 100000) % 10: 0 -> <128,128,2>, 1 -> <64,64,2>, 2 -> <128,64,4>; id >= 1000000: the split-operand
+ * kernel gemm_split_kernel<...> (csrc/gemm_split.hip) with the same template arguments */
 int pd_gemm_variant(const pd_gemm_args* args);
 
 /* ---- pd_rowstats: per-row (mean, rstd) for the GEMM prologue --------------------------

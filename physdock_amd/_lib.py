@@ -40,7 +40,7 @@ def header_symbols():
 
 class GemmArgs(C.Structure):
     _fields_ = [
-        ("A", _fp), ("W", _fp), ("Y", _fp),
+        ("A", _fp), ("W", _fp), ("W3", _fp), ("Y", _fp),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("lda", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int),
         ("batch", C.c_int),

@@ -529,9 +529,22 @@ inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 // gemm_stream.hip: persistent variant with a direct-from-fragment epilogue for large full-tile row-major problems
 extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only);
+// gemm_split.hip: the same persistent structure on the bf16 matrix pipe (3 x bf16 split operands, needs args->W3)
+extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only);
+
+// the persistent kernel family a launch goes to: split-operand bf16 when the caller supplied pre-split weights, else fp32
+static int persistent_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only, bool* split = nullptr) {
+    if (args && args->W3) {
+        const int r = pd_gemm_split_try(args, pro, tile, stream, init_only);
+        if (r != PD_ERR_UNSUPPORTED) { if (split) *split = true; return r; }
+    }
+    if (split) *split = false;
+    return pd_gemm_stream_try(args, pro, tile, stream, init_only);
+}
 
 PD_EXPORT int pd_init(void) {
     int rc = pd_gemm_stream_try(nullptr, 0, 0, nullptr, 1);
+    { const int r = pd_gemm_split_try(nullptr, 0, 0, nullptr, 1); if (r != PD_OK) rc = r; }
     for (int cfg = 0; cfg < 4; ++cfg)
         for (int lay = 0; lay < 3; ++lay)
             for (int vec = 0; vec < 2; ++vec)
@@ -634,7 +647,7 @@ extern "C" __attribute__((visibility("default"))) int pd_lab_set_gemm_trace(void
 #endif
 
 // variant id as documented above; + 5000 + 10000 * EPI + 100000 * tile (0: 128x128, 1: 64x64, 2: 128x64) when the launch
-// goes to gemm_stream_kernel<pro, EPI, Tile<...>>
+// goes to gemm_stream_kernel<pro, EPI, Tile<...>>, + 1000000 more when it goes to gemm_split_kernel<pro, EPI, STile<...>>
 PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     if (!args) return PD_ERR_ARG;
     pd_gemm_args p = *args;
@@ -643,8 +656,9 @@ PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     if (v >= 0 && use_stream() && stream_tile(cfg, p)) {
         pd_gemm_args head, tail;
         const int tile = stream_tile(cfg, p);
-        const int epi = pd_gemm_stream_try(split_rows(p, pro, tile, head, tail) ? &head : &p, pro, tile, nullptr, 2);
-        if (epi >= 0) return v + 5000 + 10000 * epi + 100000 * (tile == 128 ? 0 : tile == 64 ? 1 : 2);
+        bool split = false;
+        const int epi = persistent_try(split_rows(p, pro, tile, head, tail) ? &head : &p, pro, tile, nullptr, 2, &split);
+        if (epi >= 0) return v + 5000 + 10000 * epi + 100000 * (tile == 128 ? 0 : tile == 64 ? 1 : 2) + (split ? 1000000 : 0);
     }
     return v;
 }
@@ -659,11 +673,11 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
         pd_gemm_args head, tail;
         const int tile = stream_tile(cfg, p);
         if (!split_rows(p, pro, tile, head, tail)) {
-            const int r = pd_gemm_stream_try(&p, pro, tile, stream, 0);
+            const int r = persistent_try(&p, pro, tile, stream, 0);
             if (r != PD_ERR_UNSUPPORTED) return r;
-        } else if (pd_gemm_stream_try(&head, pro, tile, nullptr, 2) >= 0) {
+        } else if (persistent_try(&head, pro, tile, nullptr, 2) >= 0) {
             // whole row blocks on the streaming kernel, the ragged remainder (< one tile of rows) on the general one
-            const int r = pd_gemm_stream_try(&head, pro, tile, stream, 0);
+            const int r = persistent_try(&head, pro, tile, stream, 0);
             if (r != PD_OK) return r;
             int tcfg, tpro; bool takm, twkm, tvec;
             const int tv = select_variant(tail, tcfg, takm, twkm, tvec, tpro);

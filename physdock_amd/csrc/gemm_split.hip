@@ -1,0 +1,317 @@
+// fp32-accurate GEMM on the bf16 matrix pipe: error-free 3-way operand splitting ("bf16 x 6").
+//
+// Every fp32 operand is split into three bf16 values a = a_h + a_m + a_l (exact for normal fp32: 3 x 8 significand
+// bits + the residual signs cover the 24-bit significand); a product a.b is then the sum of the partial products of the
+// parts, each EXACT in fp32 (8 x 8 significand bits).  Dropping the three terms below 2^-24 |a b| (m.l, l.m, l.l) leaves six
+// v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block, accumulated in fp32 by the matrix pipe.  Measured on MI355X
+// (tools/micro/bf16x3_probe.hip, K = 512, wide dynamic range): max error / sum|a b| = 7.3e-7 against 1.09e-6 for
+// v_mfma_f32_32x32x2_f32 (which is bitwise an fmaf chain: one rounding per product; the bf16 pipe rounds once per 16
+// products), rms 7.8e-8 against 1.0e-7 - i.e. at least fp32-MFMA accuracy, and nine products add nothing measurable.
+// Rate: six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 32 x 32 x 16 block: 2.67 x the fp32
+// matrix peak (2.5 PF / 6 = 419 TF effective).  The reference computes these contractions with fp32 F.linear on CPU
+// and with TF32 on its own GPUs (models/model.py:5); parity is held to the same 1e-3 A bar as before.
+//
+// Structure = gemm_stream.hip (persistent blocks, XCD-aware tile order, norm prologue applied while staging A,
+// compile-time specialised epilogues straight from the accumulator fragments - the C fragment layout of the bf16 MFMA is
+// the same 32 x 32 layout, so gemm_tile_common.h is shared).  What differs:
+//   * W arrives PRE-SPLIT (packing.py: [3][N][Kp] bf16, Kp = K rounded up to 32, zero padded) - weights are constants;
+//   * A is split while it is staged: global fp32 -> registers -> (norm prologue) -> 3 x bf16 -> LDS;
+//   * LDS holds two stages of 16 k (one MFMA k-step) = one 32-k slice; rows are 48 bytes apart so that a ds_read_b128
+//     fragment read (row = lane & 31, 16 bytes at 16 * (lane >> 5)) is bank-conflict free (3 r mod 16 is a bijection on
+//     each of the instruction's 16-lane groups);
+//   * the next 32-k slice is requested from global memory before the MFMA block of the first stage and written into a
+//     stage right after every wave has finished reading it (LDS-only barriers: no vmcnt drain).
+#include <stdlib.h>
+#include "gemm_tile_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SNT = 256;
+constexpr int KS = 16;               // k per LDS stage = one v_mfma_f32_32x32x16_bf16 step
+constexpr int PITCH = 24;            // bf16 per LDS row (48 bytes)
+
+template <int BM_, int BN_, int WM_>
+struct STile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = 4 / WM_;
+    static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    static constexpr int STAGE = 3 * (BM + BN) * PITCH;                 // bf16 elements per stage
+    static constexpr int LDS_BYTES = 2 * STAGE * 2;
+    static constexpr int BLOCKS_PER_CU = LDS_BYTES > 60000 ? 2 : LDS_BYTES > 40000 ? 3 : 4;
+    static constexpr int GRID = 256 * BLOCKS_PER_CU;
+};
+
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0); outstanding global loads stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// a = h + m + l with bf16 parts (round-to-nearest-even conversions; the residuals are exact in fp32)
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r1 = v[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;
+        h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+    }
+}
+
+template <int PRO, int EPI, class TL>
+__global__ __launch_bounds__(SNT, TL::BLOCKS_PER_CU) void gemm_split_kernel(const pd_gemm_args p) {
+    constexpr int BM = TL::BM, BN = TL::BN, TM = TL::TM, TN = TL::TN;
+    constexpr int XSLOTS = TL::GRID / 8;
+    constexpr int TPR_A = SNT / BM;              // threads per A row (2 or 4); a row of a 32-k slice = 8 f32x4 chunks
+    constexpr int CPH_A = 4 / TPR_A;             // chunks per thread per 16-k half
+    constexpr int TPR_W = SNT / BN;              // threads per W row; a row of a 32-k slice of one part = 4 bf16x8 chunks
+    constexpr int NW = 4 / TPR_W;                // W chunks per thread per part per slice (2: one per half; 1: one half only)
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / TL::WN, wn = wave % TL::WN;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int nMb = p.M / BM, nNb = p.N / BN;
+    const int ntiles = nMb * nNb;
+    const int nk = (p.K + 31) / 32;
+    const int Kp = nk * 32;                       // row pitch of the pre-split weight parts
+    const __bf16* __restrict__ W3 = reinterpret_cast<const __bf16*>(p.W3);
+    const long long wpart = (long long)p.N * Kp;
+
+    // stage s: [3 parts][BM rows][PITCH] for A, then [3][BN][PITCH] for W
+    auto sA = [&](int s, int part) { return lds + s * TL::STAGE + part * BM * PITCH; };
+    auto sW = [&](int s, int part) { return lds + s * TL::STAGE + 3 * BM * PITCH + part * BN * PITCH; };
+
+    const int a_row = tid / TPR_A, a_q = tid % TPR_A;
+    const int w_row = tid / TPR_W, w_q = tid % TPR_W;
+    f32x4 ra[2][CPH_A];                          // [half][i]: chunk 4*half + a_q + TPR_A*i of the thread's row
+    bf16x8 rw[3][NW];                            // [part][i]: NW == 2 -> chunk w_q + 2 i (half i); NW == 1 -> chunk w_q (half w_q >> 1)
+
+    auto gload = [&](int bm0, int bn0, int k0) {
+        const int r = bm0 + a_row;                // full tiles only: always < M
+        const float* ap = p.A + (long long)r * p.lda + k0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < CPH_A; ++i) {
+                int kc = 16 * h + 4 * (a_q + TPR_A * i);
+                kc = k0 + kc < p.K ? kc : 0;      // clamped address; zeroed in `stage` (K % 4 == 0 is required)
+                ra[h][i] = *reinterpret_cast<const f32x4*>(ap + kc);
+            }
+        const __bf16* wp = W3 + (long long)(bn0 + w_row) * Kp + k0;
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                rw[part][i] = *reinterpret_cast<const bf16x8*>(wp + part * wpart + 8 * (NW == 2 ? w_q + 2 * i : w_q));
+    };
+
+    f32x16 acc[TM][TN];
+    const bool grouped = gridDim.x == TL::GRID && nMb >= 8;
+    TileOrder ord;
+    ord.init(nMb, nNb, grouped ? blockIdx.x & 7 : 0, grouped ? 8 : 1, XSLOTS);
+    const int t_step = grouped ? XSLOTS : gridDim.x;
+    const int t_end = grouped ? ord.ntiles : ntiles;
+    int tile = grouped ? blockIdx.x >> 3 : blockIdx.x;
+    if (tile >= t_end) return;
+    auto coords = [&](int t, int& bm0, int& bn0) {
+        int mb, nb;
+        if (grouped) ord.get(t, mb, nb);
+        else { mb = t % nMb; nb = t / nMb; }
+        bm0 = mb * BM; bn0 = nb * BN;
+    };
+    int bm0, bn0;
+    coords(tile, bm0, bn0);
+    gload(bm0, bn0, 0);
+
+    for (; tile < t_end; tile += t_step) {
+        const int n0 = bn0 + wn * (32 * TN) + l31;
+        float c0[TN], c1[TN];
+        const int gate_row = bm0 + wm * (32 * TM);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            c0[j] = p.bias ? p.bias[n0 + 32 * j] : 0.f;
+            c1[j] = 1.f;
+            if constexpr (EPI == EPI_HN) c1[j] = p.hn_w[((n0 + 32 * j) / p.hn_split) * 32 + l31];
+            if constexpr (EPI == EPI_GATERES)
+                c1[j] = p.mul ? p.mul[(long long)(gate_row / p.mul_rows_per_group) * p.mul_gstride + n0 + 32 * j] : 1.f;
+        }
+        // prologue state of the one A row this thread stages
+        float st_mean = 0.f, st_rstd = 1.f;
+        int grp_off = 0;
+        if constexpr (PRO != 0) {
+            const int m = bm0 + a_row;
+            st_mean = p.stats[2 * (long long)m];
+            st_rstd = p.stats[2 * (long long)m + 1];
+            if constexpr (PRO == 2) grp_off = (m / p.pro_rows_per_group) * p.pro_gstride;
+        }
+        // norm prologue + k-tail zeroing + split + LDS store of one 16-k half of the slice held in ra / rw
+        auto stage = [&](int h, int k0) {
+#pragma unroll
+            for (int i = 0; i < CPH_A; ++i) {
+                const int c = a_q + TPR_A * i;                    // chunk inside the half
+                const int kc = k0 + 16 * h + 4 * c;
+                f32x4 v = ra[h][i];
+                if constexpr (PRO != 0) {
+                    const int kl = kc < p.K ? kc : 0;
+                    const f32x4 pw = *reinterpret_cast<const f32x4*>(p.pro_w + grp_off + kl);
+                    const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pro_b + grp_off + kl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] - st_mean) * st_rstd * pw[e] + pb[e];
+                }
+                if (p.pro_act == PD_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (p.pro_act == PD_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pd_silu(v[e]);
+                }
+                if (kc >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x4 ph, pm, pl;
+                split4(v, ph, pm, pl);
+                const int o = a_row * PITCH + 4 * c;
+                *reinterpret_cast<bf16x4*>(sA(h, 0) + o) = ph;
+                *reinterpret_cast<bf16x4*>(sA(h, 1) + o) = pm;
+                *reinterpret_cast<bf16x4*>(sA(h, 2) + o) = pl;
+            }
+            if (NW == 2 || (w_q >> 1) == h) {
+                const int i = NW == 2 ? h : 0;
+                const int c = NW == 2 ? w_q : (w_q & 1);          // 16-byte chunk inside the half
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+                    *reinterpret_cast<bf16x8*>(sW(h, part) + w_row * PITCH + 8 * c) = rw[part][i];
+            }
+        };
+        // 6 partial products per (i, j) fragment pair of one 16-k stage
+        auto mma = [&](int s) {
+            bf16x8 fa[TM][3], fw[TN][3];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i][part] = *reinterpret_cast<const bf16x8*>(sA(s, part) + (wm * (32 * TM) + i * 32 + l31) * PITCH + 8 * hh);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fw[j][part] = *reinterpret_cast<const bf16x8*>(sW(s, part) + (wn * (32 * TN) + j * 32 + l31) * PITCH + 8 * hh);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fw[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fw[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fw[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fw[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fw[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fw[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // slice 0 of this tile is in ra / rw (requested before the previous tile's epilogue)
+        lds_barrier();                            // every wave has finished the previous tile's last stage
+        stage(0, 0);
+        stage(1, 0);
+        lds_barrier();
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more) gload(bm0, bn0, (kt + 1) * 32);
+            mma(0);
+            if (more) {
+                lds_barrier();                    // stage 0 has been read by every wave
+                stage(0, (kt + 1) * 32);
+            }
+            mma(1);
+            if (more) {
+                lds_barrier();                    // stage 1 read by every wave; the stage-0 stores above are visible
+                stage(1, (kt + 1) * 32);          // (visible to the next mma(1) through the barrier after the next mma(0))
+            }
+        }
+        const int cur_bm0 = bm0, cur_bn0 = bn0;
+        if (tile + t_step < t_end) {
+            coords(tile + t_step, bm0, bn0);
+            gload(bm0, bn0, 0);
+        }
+        epilogue<EPI, TM, TN>(p, acc, c0, c1, cur_bm0, cur_bn0, wm, wn, l31, hh);
+    }
+}
+
+template <int PRO, int EPI, class TL>
+int run_split(int op, const pd_gemm_args* p, hipStream_t s) {
+    auto k = gemm_split_kernel<PRO, EPI, TL>;
+    constexpr int lds = TL::LDS_BYTES;
+    if (op == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    const long long ntiles = (long long)(p->M / TL::BM) * (p->N / TL::BN);
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < TL::GRID ? ntiles : TL::GRID)), dim3(SNT), lds, s, *p);
+    return pd_check_launch();
+}
+
+using S128 = STile<128, 128, 2>;
+using S64 = STile<64, 64, 2>;
+using S12864 = STile<128, 64, 4>;
+
+int dispatch_split(int op, int pro, int epi, int tile, const pd_gemm_args* p, hipStream_t s) {
+#define PD_SCASE(P, E, C, TL) if (pro == P && epi == E && tile == C) return run_split<P, E, TL>(op, p, s);
+    PD_SCASE(0, EPI_PLAIN, 128, S128) PD_SCASE(1, EPI_PLAIN, 128, S128)
+    PD_SCASE(1, EPI_HN, 128, S128) PD_SCASE(2, EPI_HN, 128, S128)
+    PD_SCASE(1, EPI_GLU, 128, S128) PD_SCASE(2, EPI_GLU, 128, S128)
+    PD_SCASE(0, EPI_GATERES, 128, S128) PD_SCASE(0, EPI_TGATERES, 128, S128)
+    PD_SCASE(0, EPI_PLAIN, 64, S64) PD_SCASE(1, EPI_PLAIN, 64, S64)
+    PD_SCASE(1, EPI_HN, 64, S64) PD_SCASE(2, EPI_HN, 64, S64)
+    PD_SCASE(0, EPI_GATERES, 64, S64) PD_SCASE(0, EPI_TGATERES, 64, S64)
+    PD_SCASE(1, EPI_GLU, 12864, S12864) PD_SCASE(2, EPI_GLU, 12864, S12864)
+#undef PD_SCASE
+    return PD_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// Same contract as pd_gemm_stream_try (gemm_stream.hip); additionally needs the pre-split weights (args->W3) and
+// 16-byte aligned A rows with K % 4 == 0.  init_only: 0 launch, 1 raise the LDS limits, 2 query (returns the EPI kind).
+extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only) {
+    if (init_only == 1) {
+        int rc = PD_OK;
+        for (int T : {128, 64, 12864})
+            for (int P = 0; P < 3; ++P)
+                for (int E = 0; E < 5; ++E) {
+                    const int r = dispatch_split(1, P, E, T, nullptr, nullptr);
+                    if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
+                }
+        return rc;
+    }
+    const pd_gemm_args& p = *args;
+    if (!p.W3 || p.K % 4 != 0) return PD_ERR_UNSUPPORTED;
+    if (tile != 128 && tile != 64 && tile != 12864) return PD_ERR_UNSUPPORTED;
+    const int tbm = tile == 64 ? 64 : 128, tbn = tile == 128 ? 128 : 64;
+    if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
+    if (((uintptr_t)p.W3 & 15) != 0) return PD_ERR_UNSUPPORTED;
+    if (p.M % tbm != 0 || p.N % tbn != 0) return PD_ERR_UNSUPPORTED;
+    if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
+    int epi;
+    if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
+    else if (p.hn_w) epi = (p.mul || p.res || p.act) ? -1 : EPI_HN;
+    else if (p.res) {
+        epi = (p.mul && p.mul_rows_per_group <= 0) ? EPI_TGATERES : EPI_GATERES;
+        if (p.act || p.res_row_mod > 0) epi = -1;
+        if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group % 64 != 0) epi = -1;
+    } else epi = p.mul ? -1 : EPI_PLAIN;
+    if (epi < 0) return PD_ERR_UNSUPPORTED;
+    if (init_only == 2) {
+        const int r = dispatch_split(1, pro, epi, tile, nullptr, nullptr);
+        return r == PD_OK ? epi : r;
+    }
+    return dispatch_split(0, pro, epi, tile, &p, (hipStream_t)stream);
+}

@@ -28,11 +28,7 @@
 #define PD_LT(x) (x)
 #endif
 
-#ifdef PD_STREAM_NOEMIT
-#define PD_ST(dst, val) do { const float v_ = (val); if (v_ == 123.456f) (dst) = v_; } while (0)   // experiment: no stores
-#else
-#define PD_ST(dst, val) (dst) = (val)
-#endif
+#include "gemm_tile_common.h"
 
 namespace {
 
@@ -79,127 +75,6 @@ struct Loader {     // ROWS rows x 32 k, [row][k] layout; thread -> rows (tid>>3
     __device__ __forceinline__ void store(float* __restrict__ s, int tid) const {
 #pragma unroll
         for (int i = 0; i < NP; ++i) *reinterpret_cast<f32x4*>(s + ((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4) = reg[i];
-    }
-};
-
-// Epilogue kinds (compile-time, so that the epilogue is a few straight-line instructions per element; a flag-driven
-// fragment epilogue cost ~75 instructions per element = 12 us per 128x128 tile).
-//   PLAIN   : Y = act(acc + bias)
-//   HN      : Y = headnorm(acc + bias) on columns < hn_cols (q | k), plain beyond (v)        [no act]
-//   GLU     : Y = silu(a + ba) * (b + bb)  |  (a + ba) * sigmoid(b + bb)   on packed column pairs
-//   GATERES : Y = (acc + bias) * gate[row group] + res          (gate optional; res may alias Y)
-//   TGATERES: Y = (acc + bias) * gate[row, col] + res           (gate tensor, e.g. the sigmoid gate of an attention)
-enum { EPI_PLAIN = 0, EPI_HN = 1, EPI_GLU = 2, EPI_GATERES = 3, EPI_TGATERES = 4 };
-
-// Epilogue of one block tile straight from the accumulator fragments: lane = column, register r = row
-// (r&3)+8(r>>2)+4*half.  Tiles are always full (the launcher peels ragged rows off to gemm.hip).  Addresses are
-// (uniform row pointer)[lane offset]: SGPR base + one shared 32-bit VGPR offset per array, nothing per row in VGPRs.
-template <int EPI, int TM, int TN>
-__device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&acc)[TM][TN], const float (&c0)[TN],
-                                         const float (&c1)[TN], int bm0, int bn0, int wm, int wn, int l31, int hh) {
-    static_assert(EPI != EPI_GLU || TN == 2, "a GLU pair needs both column fragments in one wave");
-    const int ldy = p.ldy, ldres = p.ldres, ldmul = p.ldmul;
-    const int yoff = hh * 4 * ldy + l31;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int mb = bm0 + wm * (32 * TM) + i * 32;
-        if constexpr (EPI == EPI_GLU) {
-            float* __restrict__ Yo = p.Y + (long long)mb * ldy + ((bn0 + wn * (32 * TN)) >> 1);
-            if (p.glu == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu(acc[i][0][r] + c0[0]) * (acc[i][TN - 1][r] + c0[TN - 1]));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], (acc[i][0][r] + c0[0]) * pd_sigmoid(acc[i][TN - 1][r] + c0[TN - 1]));
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int ncol0 = bn0 + wn * (32 * TN) + j * 32;
-                float* __restrict__ Yo = p.Y + (long long)mb * ldy + ncol0;
-                if constexpr (EPI == EPI_GATERES || EPI == EPI_TGATERES) {
-                    const float* __restrict__ Ro = p.res + (long long)mb * ldres + ncol0;
-                    const int roff = hh * 4 * ldres + l31;
-                    float gv[16];
-                    if constexpr (EPI == EPI_TGATERES) {       // gate pass first: 16 loads in flight, not 32
-                        const float* __restrict__ Go = p.mul + (long long)mb * ldmul + ncol0;
-                        const int goff = hh * 4 * ldmul + l31;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) gv[r] = (Go + pd_frag_row(r, 0) * ldmul)[goff];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) gv[r] = (acc[i][j][r] + c0[j]) * gv[r];
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) gv[r] = (acc[i][j][r] + c0[j]) * c1[j];
-                    }
-                    float rv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = (Ro + pd_frag_row(r, 0) * ldres)[roff];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], gv[r] + rv[r]);
-                    __builtin_amdgcn_sched_barrier(0);      // keep the 16/32 loads of one fragment from piling up with the next
-                } else if constexpr (EPI == EPI_HN) {
-                    if (ncol0 < p.hn_cols) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float v = acc[i][j][r] + c0[j];
-                            const float ss = pd_half_sum32(v * v);        // a head = the 32 lanes of a wave half
-                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], v * rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps) * c1[j]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], acc[i][j][r] + c0[j]);
-                    }
-                } else {
-                    if (p.act == PD_ACT_SILU) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu(acc[i][j][r] + c0[j]));
-                    } else if (p.act == PD_ACT_NONE) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], acc[i][j][r] + c0[j]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_act(acc[i][j][r] + c0[j], p.act));
-                    }
-                }
-            }
-        }
-    }
-}
-
-// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.
-// A persistent grid of 512 (1024 for 64x64 tiles) blocks gives every XCD 64 (128) concurrently running tiles; they are chosen as a compact patch of
-// GM row blocks x (64 / GM) column blocks inside a contiguous range of row blocks owned by that XCD, so that an A panel
-// fetched by one tile is an L2 hit for the tiles of the other column blocks (M-fastest order re-fetches A once per
-// column block: measured 8x the algorithmic read traffic for N = 2816), and W panels are shared by GM tiles.
-struct TileOrder {
-    int nMb, nNb, mb_lo, nmb, gm, per_group, ntiles;      // this XCD's row-block range, patch height, tiles per patch
-    __device__ __forceinline__ void init(int nMb_, int nNb_, int xcd, int nxcd, int slots) {
-        nMb = nMb_; nNb = nNb_;
-        mb_lo = (int)((long long)nMb * xcd / nxcd);
-        nmb = (int)((long long)nMb * (xcd + 1) / nxcd) - mb_lo;
-        gm = slots / nNb;
-        gm = gm < 1 ? 1 : gm;
-        gm = gm > nmb ? (nmb > 0 ? nmb : 1) : gm;
-        per_group = gm * nNb;
-        ntiles = nmb * nNb;
-    }
-    // t-th tile of this XCD -> (row block, column block); only the last patch may be shorter than gm
-    __device__ __forceinline__ void get(int t, int& mb, int& nb) const {
-        int g = t / per_group;
-        const int ngroups = (nmb + gm - 1) / gm;
-        g = g < ngroups - 1 ? g : ngroups - 1;
-        const int r = t - g * per_group;
-        const int h = nmb - g * gm < gm ? nmb - g * gm : gm;
-        mb = mb_lo + g * gm + r % h;
-        nb = r / h;
     }
 };
 

@@ -58,6 +58,16 @@ class Engine:
         self.inf, self.eps = float(dc.inf), float(dc.eps)
 
     # ------------------------------------------------------------------ small helpers
+    def gemm(self, A, W, Y, M, N, K, **kw):
+        """ops.gemm with the pre-split (3 x bf16) copy of a weight operand attached when W is a packed weight matrix, so
+        that eligible shapes run on the bf16 matrix pipe at fp32 accuracy (csrc/gemm_split.hip).  Activation x activation
+        contractions (raw addresses, k-major / batched operands) stay on the fp32 MFMA."""
+        w3 = None
+        if isinstance(W, torch.Tensor) and W.dim() == 2 and W.shape[0] == N and K % 4 == 0 and kw.get("batch", 1) == 1 \
+                and not kw.get("a_kmajor") and not kw.get("w_kmajor") and kw.get("out_mode", 0) == 0 and N % 64 == 0:
+            w3 = self.P.w3(W, K)
+        ops.gemm(A, W, Y, M, N, K, W3=w3, **kw)
+
     def lws(self, name, *shape):
         """lane-private scratch: concurrent sample lanes never share a DiT intermediate"""
         return self.ws.get(f"{name}@{self.lane}", *shape)
@@ -78,7 +88,7 @@ class Engine:
         if out is None:
             out = self.ws.get("lin:" + wname, M, N)
         lda = kw.pop("lda", K)
-        ops.gemm(x, W, out, M, N, K, lda=lda, ldw=ldw, bias=b, **kw)
+        self.gemm(x, W, out, M, N, K, lda=lda, ldw=ldw, bias=b, **kw)
         return out
 
     # ------------------------------------------------------------------ shared blocks
@@ -88,7 +98,7 @@ class Engine:
         W, _, H, K, ldw = P.linear(prefix + ".linear_z")
         if st is None:
             st = self.stats(z, T1 * T2, C, RMS, self.eps, "stats_pb")
-        ops.gemm(z, W, out, T1 * T2, H, C, ldw=ldw, stats=st, pro_w=norm_w, out_mode=OUT_BIASFRAG, T1=T1, T2=T2,
+        self.gemm(z, W, out, T1 * T2, H, C, ldw=ldw, stats=st, pro_w=norm_w, out_mode=OUT_BIASFRAG, T1=T1, T2=T2,
                  frag_transpose=transpose, maskadd=mask, maskval=-self.inf, out_scale=LOG2E)
         return H
 
@@ -100,14 +110,14 @@ class Engine:
         st = self.stats(s, rows, C, RMS, self.eps)
         W, b = P.qkvg(prefix)
         qkvg = self.ws.get("qkvg", rows, 4 * C)
-        ops.gemm(s, W, qkvg, rows, 4 * C, C, stats=st, pro_w=P[f"{prefix}.{norm_name}.weight"], bias=b)
+        self.gemm(s, W, qkvg, rows, 4 * C, C, stats=st, pro_w=P[f"{prefix}.{norm_name}.weight"], bias=b)
         o = self.ws.get("attn_o", rows, C)
         st4 = (N * 4 * C, 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=nk or N, nbatch=nbatch, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias, bias_nk=N,
                       ws=self.attn_ws(nbatch, N, nk or N, H))
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
-        ops.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s)
+        self.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s)
 
     def transition(self, prefix, x, rows, C):
         """x += W2(silu(W1 RMSNorm(x)) * W3 RMSNorm(x))                    (transitions.py:15-18)"""
@@ -115,9 +125,9 @@ class Engine:
         st = self.stats(x, rows, C, RMS, self.eps)
         W13, hidden = P.glu(prefix + ".feed_forward")
         h = self.ws.get("ffn_h", rows, hidden)
-        ops.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_w=P[prefix + ".ffn_norm.weight"], glu=1)
+        self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_w=P[prefix + ".ffn_norm.weight"], glu=1)
         W2, _, _, _, ldw = P.linear(prefix + ".feed_forward.w2")
-        ops.gemm(h, W2, x, rows, C, hidden, ldw=ldw, res=x)
+        self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, res=x)
 
     def triangle_update(self, prefix, z, T, C, mask, transpose):
         """z += TriangleUpdate(z)                                          (attentions.py:157-171)"""
@@ -127,21 +137,21 @@ class Engine:
         nw = P[prefix + ".norm_in.weight"]
         Wqk, bqk = P.tri_qk(prefix)                       # packed [qx|q|kx|k] -> 64 outputs (q 32 | k 32)
         qk = self.ws.get("tri_qk", 64, M)
-        ops.gemm(z, Wqk, qk, M, 128, C, stats=st, pro_w=nw, bias=bqk, glu=2, rowscale=mask,
+        self.gemm(z, Wqk, qk, M, 128, C, stats=st, pro_w=nw, bias=bqk, glu=2, rowscale=mask,
                  out_mode=OUT_TRANSPOSED, ldy=M)
         Wg, bg, _, _, ldw = P.linear(prefix + ".linear_g")
         g = self.ws.get("tri_g", M, C)
-        ops.gemm(z, Wg, g, M, C, C, ldw=ldw, stats=st, pro_w=nw, bias=bg, act=ACT_SIGMOID)
+        self.gemm(z, Wg, g, M, C, C, ldw=ldw, stats=st, pro_w=nw, bias=bg, act=ACT_SIGMOID)
         o = self.ws.get("tri_o", 32, M)
         Tr = self.Tr          # the sum over j runs over REAL tokens only (padded j never enter a reduction)
         if not transpose:   # o[c,i,I] = sum_j q[c,i,j] k[c,I,j]
-            ops.gemm(off(qk, 0), off(qk, 32 * M), o, T, T, Tr, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M)
+            self.gemm(off(qk, 0), off(qk, 32 * M), o, T, T, Tr, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M)
         else:               # o[c,a,b] = sum_j k[c,j,a] q[c,j,b]
-            ops.gemm(off(qk, 32 * M), off(qk, 0), o, T, T, Tr, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M,
+            self.gemm(off(qk, 32 * M), off(qk, 0), o, T, T, Tr, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M,
                      a_kmajor=True, w_kmajor=True)
         st2 = self.stats(o, M, 32, RMS, self.eps, "stats_tri", kmajor=True, ldx=M)
         Wz, bz, _, _, ldw = P.linear(prefix + ".linear_z")
-        ops.gemm(o, Wz, z, M, C, 32, a_kmajor=True, lda=M, ldw=ldw, stats=st2, pro_w=P[prefix + ".norm_out.weight"],
+        self.gemm(o, Wz, z, M, C, 32, a_kmajor=True, lda=M, ldw=ldw, stats=st2, pro_w=P[prefix + ".norm_out.weight"],
                  bias=bz, mul=g, ldmul=C, res=z)
 
     def triangle_attention(self, prefix, z, T, C, mask, transpose):
@@ -153,7 +163,7 @@ class Engine:
         nw = P[prefix + ".norm.weight"]
         W, b = P.qkvg(prefix)
         qkvg = self.ws.get("qkvg", M, 4 * C)
-        ops.gemm(z, W, qkvg, M, 4 * C, C, stats=st, pro_w=nw, bias=b)
+        self.gemm(z, W, qkvg, M, 4 * C, C, stats=st, pro_w=nw, bias=b)
         bias = self.ws.get("tri_bias", ops.bias_frag_numel(H, T, T), zero=True)
         self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, st=st)
         o = self.ws.get("attn_o", M, C)
@@ -164,7 +174,7 @@ class Engine:
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T)
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
-        ops.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z)
+        self.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z)
 
     def triangle_block(self, prefix, z, T, C, mask, maskT):
         """layers/transformers.py:48-54.  The reference transposes z for the column variants but NOT the mask
@@ -212,8 +222,8 @@ class Engine:
         h = ws.get("ap_ffn_h", chunk, hidden)
         for r0 in range(0, A * A, chunk):
             rows = min(chunk, A * A - r0)
-            ops.gemm(off(ap, r0 * Cap), W13, h, rows, 2 * hidden, Cap, glu=1)
-            ops.gemm(h, W2, off(ap, r0 * Cap), rows, Cap, hidden, ldw=ldw2, res=off(ap, r0 * Cap), ldres=Cap)
+            self.gemm(off(ap, r0 * Cap), W13, h, rows, 2 * hidden, Cap, glu=1)
+            self.gemm(h, W2, off(ap, r0 * Cap), rows, Cap, hidden, ldw=ldw2, res=off(ap, r0 * Cap), ldres=Cap)
         Ha = Ca // 32
         abias = ws.get("atom_bias", ops.bias_frag_numel(Ha, A, A), zero=True)
         for b in range(dc.no_blocks_atom):
@@ -305,13 +315,13 @@ class Engine:
         st = self.stats(m, rows, C, RMS, self.eps)
         W, b = P.qkvg(prefix)
         qkvg = self.ws.get("qkvg", rows, 4 * C)
-        ops.gemm(m, W, qkvg, rows, 4 * C, C, stats=st, pro_w=P[prefix + ".norm_m.weight"], bias=b)
+        self.gemm(m, W, qkvg, rows, 4 * C, C, stats=st, pro_w=P[prefix + ".norm_m.weight"], bias=b)
         o = self.ws.get("attn_o", rows, C)
         st4 = (4 * C, T * 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=S, nk=S, nbatch=T, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(C, T * C), bias=None)
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
-        ops.gemm(o, Wo, m, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=m)
+        self.gemm(o, Wo, m, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=m)
 
     def outer_product_mean(self, prefix, m, z, S, T, Cm, Cz):
         """z += RMSNorm(W_o . sum_s q_s (x) k_s + b)                       (outer_product_mean.py:23-31)"""
@@ -322,7 +332,7 @@ class Engine:
         q = self.lin(m, prefix + ".linear_q", rows, stats=st, pro_w=nw)
         k = self.lin(m, prefix + ".linear_k", rows, stats=st, pro_w=nw)
         outer = self.ws.get("opm_outer", T * T, 1024)
-        ops.gemm(q, k, outer, T * 32, T * 32, S, a_kmajor=True, w_kmajor=True, lda=T * 32, ldw=T * 32,
+        self.gemm(q, k, outer, T * 32, T * 32, S, a_kmajor=True, w_kmajor=True, lda=T * 32, ldw=T * 32,
                  out_mode=OUT_OPM, T2=T)
         raw = self.lin(outer, prefix + ".linear_o", T * T)
         ops.rownorm(raw, z, T * T, Cz, res=z, w=P[prefix + ".norm_out.weight"], mode=RMS, eps=self.eps)
@@ -341,12 +351,12 @@ class Engine:
         Wa, ba_, na = P.dit_bias("atom")                  # [2*nb_atom*H, Cap] with LN affine folded
         st = self.stats(ap, A * A, Cap, LN, 1e-5, "stats_pb")
         fa = ws.get("dit_atom_bias", ops.bias_frag_numel(na, A, A), zero=True)
-        ops.gemm(ap, Wa, fa, A * A, na, Cap, stats=st, bias=ba_, out_mode=OUT_BIASFRAG, T1=A, T2=A,
+        self.gemm(ap, Wa, fa, A * A, na, Cap, stats=st, bias=ba_, out_mode=OUT_BIASFRAG, T1=A, T2=A,
                  maskadd=batch["ap_mask"], maskval=-self.inf, out_scale=LOG2E)
         Wt, bt_, nt = P.dit_bias("token")
         st = self.stats(z, T * T, Cz, LN, 1e-5, "stats_pb")
         ft = ws.get("dit_token_bias", ops.bias_frag_numel(nt, T, T), zero=True)
-        ops.gemm(z, Wt, ft, T * T, nt, Cz, stats=st, bias=bt_, out_mode=OUT_BIASFRAG, T1=T, T2=T,
+        self.gemm(z, Wt, ft, T * T, nt, Cz, stats=st, bias=bt_, out_mode=OUT_BIASFRAG, T1=T, T2=T,
                  maskadd=batch["z_mask"], maskval=-self.inf, out_scale=LOG2E)
         # --- AdaLN tables: t = MLP(sincos(tau)); table = Linear(silu(t)) with 1 folded into the scale bias
         emb = ws.get("t_emb", n, 256)
@@ -357,8 +367,8 @@ class Engine:
         Wtt, btt = P.adaln("token")
         tab_a = ws.get("adaln_atom", n, Wta.shape[0])
         tab_t = ws.get("adaln_token", n, Wtt.shape[0])
-        ops.gemm(t, Wta, tab_a, n, Wta.shape[0], 256, bias=bta, pro_act=ACT_SILU)
-        ops.gemm(t, Wtt, tab_t, n, Wtt.shape[0], 256, bias=btt, pro_act=ACT_SILU)
+        self.gemm(t, Wta, tab_a, n, Wta.shape[0], 256, bias=bta, pro_act=ACT_SILU)
+        self.gemm(t, Wtt, tab_t, n, Wtt.shape[0], 256, bias=btt, pro_act=ACT_SILU)
         return {"atom_bias": fa, "token_bias": ft, "tab_atom": tab_a, "tab_token": tab_t}
 
     def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample, nk):
@@ -371,7 +381,7 @@ class Engine:
         mgrp = dict(mul_rows_per_group=N if per_sample else rows, mul_gstride=tab_ld if per_sample else 0)
         st = self.stats(x, rows, C, LN, eps)
         qkv = self.lws("dit_qkv", rows, 3 * C)
-        ops.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
+        self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
                  pro_w=off(tab, tab_off + C), hn_w=P.headnorm(prefix + ".attention"), hn_cols=2 * C, hn_split=C,
                  hn_eps=eps, **grp)
         o = self.lws("dit_o", rows, C)
@@ -380,14 +390,14 @@ class Engine:
                       q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias, bias_nk=N,
                       ws=self.attn_ws(B, N, nk, H))
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
-        ops.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)
+        self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)
         st = self.stats(x, rows, C, LN, eps)
         W13, hidden = P.glu(prefix + ".transition.feed_forward")
         h = self.lws("dit_h", rows, hidden)
         o2 = tab_off + 3 * C
-        ops.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, o2), pro_w=off(tab, o2 + C), glu=1, **grp)
+        self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, o2), pro_w=off(tab, o2 + C), glu=1, **grp)
         W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
-        ops.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, o2 + 2 * C), res=x, **mgrp)
+        self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, o2 + 2 * C), res=x, **mgrp)
 
     def af3_dit(self, batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=False):
         """AF3DiT.forward (transformers.py:235-262) for one noise level.

@@ -34,7 +34,7 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
          pro_gstride=0, pro_act=ACT_NONE, rowscale_acc=None, bias=None, sBias=0, hn_w=None, hn_cols=0,
          hn_split=32, hn_eps=0.0, act=ACT_NONE, glu=0, rowscale=None, maskadd=None, maskval=0.0,
          mul=None, ldmul=0, mul_rows_per_group=0, mul_gstride=0, out_scale=1.0, res=None, ldres=0,
-         res_row_mod=0, sRes=0, out_mode=OUT_ROWMAJOR, T1=0, T2=0, frag_transpose=False):
+         res_row_mod=0, sRes=0, out_mode=OUT_ROWMAJOR, T1=0, T2=0, frag_transpose=False, W3=None):
     """Y = epilogue(prologue(A) @ W^T); see include/physdock_hip.h pd_gemm_args.
     A/W/Y and the optional operands may be tensors or raw device addresses (ints)."""
     def P(x):
@@ -47,6 +47,7 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
             pro_b = const_vec(0.0, K)
     a = GemmArgs()
     a.A, a.W, a.Y = P(A), P(W), P(Y)
+    a.W3 = W3.data_ptr() if (W3 is not None and SPLIT_GEMM) else None
     a.M, a.N, a.K = M, N, K
     a.lda = lda if lda is not None else (M if a_kmajor else K)
     a.ldw = ldw if ldw is not None else (N if w_kmajor else K)
@@ -78,6 +79,10 @@ def lab_set_trace(kind, buf):
     fn.argtypes = [C.c_void_p]
     check(fn(buf.data_ptr() if buf is not None else None), "pd_lab_set_trace")
 
+
+#: use the pre-split bf16 x 6 contraction (csrc/gemm_split.hip) where a launcher is given split weights; False forces the
+#: fp32-MFMA kernels everywhere (A/B comparisons in the tests and the bench)
+SPLIT_GEMM = True
 
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None

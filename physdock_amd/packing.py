@@ -31,6 +31,20 @@ def pad_k(W):
     return out
 
 
+def split3_bf16(W):
+    """[N,K] fp32 -> [3][N][Kp] bf16 with W = hi + mid + lo exactly (round-to-nearest-even splits; the residuals are exact
+    in fp32), Kp = K rounded up to a multiple of 32, zero padded: the B operand of csrc/gemm_split.hip."""
+    N, K = W.shape
+    Kp = (K + 31) // 32 * 32
+    out = torch.zeros(3, N, Kp, dtype=torch.bfloat16, device=W.device)
+    r = W.float()
+    for part in range(3):
+        h = r.to(torch.bfloat16)
+        out[part, :, :K] = h
+        r = r - h.float()
+    return out.contiguous()
+
+
 class PackedWeights:
     """Device-resident fp32 views of a reference-named state dict + cached packed forms."""
 
@@ -41,6 +55,17 @@ class PackedWeights:
 
     def __getitem__(self, name):
         return self.p[name]
+
+    def w3(self, W, K=None):
+        """cached bf16 x 3 split of a packed weight matrix [N, ld] (only its first K columns when ld is a padded K)"""
+        if not isinstance(W, torch.Tensor) or W.dim() != 2:
+            return None
+        key = ("w3", W.data_ptr(), tuple(W.shape), K)
+        v = self.cache.get(key)
+        if v is None:
+            v = (W, split3_bf16(W if K is None else W[:, :K]))       # holding W keeps its address from being reused
+            self.cache[key] = v
+        return v[1]
 
     def _c(self, key, fn):
         v = self.cache.get(key)

@@ -1,0 +1,118 @@
+"""csrc/gemm_split.hip: the fp32-accurate contraction on the bf16 matrix pipe (three-way error-free operand split, six
+partial products, fp32 accumulation).  Every epilogue / prologue kind of the persistent kernel family is re-run with
+pre-split weights attached, and the accuracy claim (at least that of the fp32 MFMA) is checked against float64."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+import test_kernels_gpu as tk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def split_ops():
+    """physdock_amd.ops with every weight operand's bf16 x 3 split attached, recording the kernel ids pd_gemm picks"""
+    from physdock_amd import ops
+    from physdock_amd.packing import split3_bf16
+    real = ops.gemm
+    seen, keep = [], []
+    L = ops._lib.init()
+
+    def gemm(A, W, Y, M, N, K, **kw):
+        if isinstance(W, torch.Tensor) and "W3" not in kw:
+            kw["W3"] = split3_bf16(W.reshape(N, -1)[:, :K])
+            keep.append(kw["W3"])
+        return real(A, W, Y, M, N, K, **kw)
+
+    def hook(a, launch):
+        seen.append(L.pd_gemm_variant(C.byref(a)))
+        launch()
+    ops.gemm = gemm
+    yield ops, seen
+    ops.gemm = real
+    ops.GEMM_HOOK = None
+
+
+def _run_split(split_ops, fn):
+    ops, seen = split_ops
+    real_streamed = tk._streamed
+
+    def streamed(ops_, call):             # the imported tests assert "persistent kernel"; here: the SPLIT persistent kernel
+        ops_.GEMM_HOOK = lambda a, launch: (seen.append(ops_._lib.init().pd_gemm_variant(C.byref(a))), launch())
+        try:
+            call()
+        finally:
+            ops_.GEMM_HOOK = None
+    tk._streamed = streamed
+    try:
+        fn(ops)
+    finally:
+        tk._streamed = real_streamed
+    main = [v for v in seen if v % 10000 >= 5000]
+    assert main and all(v >= 1000000 for v in main), seen       # every full-tile launch went to gemm_split_kernel
+
+
+@pytest.mark.parametrize("M,N,K", [(128 * 40, 128 * 26, 100), (128 * 33, 128 * 32, 300), (128 * 70 + 37, 128 * 3, 72),
+                                   (128 * 200 + 1, 128, 128)])
+def test_split_bias_act_res_gate(split_ops, M, N, K):
+    _run_split(split_ops, lambda ops: tk.test_gemm_stream_bias_act_res(ops, M, N, K))
+
+
+@pytest.mark.parametrize("glu", [1, 2])
+def test_split_glu_norm_prologue(split_ops, glu):
+    _run_split(split_ops, lambda ops: tk.test_gemm_stream_glu_norm_prologue(ops, glu))
+
+
+def test_split_adaln_headnorm_rowgroup_gate(split_ops):
+    _run_split(split_ops, lambda ops: tk.test_gemm_stream_adaln_shapes(ops))
+
+
+@pytest.mark.parametrize("M,N,K", [(64 * 20, 64 * 5, 512), (128 * 6, 64 * 3, 96)])
+def test_split_small_tiles(split_ops, M, N, K):
+    """problems that do not fill the chip with 128 x 128 tiles take the 64 x 64 split tile"""
+    ops, seen = split_ops
+    gen = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=gen); W = torch.randn(N, K, generator=gen) / math.sqrt(K)
+    R = torch.randn(M, N, generator=gen)
+    Y = R.cuda()
+    ops.GEMM_HOOK = lambda a, launch: (seen.append(ops._lib.init().pd_gemm_variant(C.byref(a))), launch())
+    ops.gemm(A.cuda(), W.cuda(), Y, M, N, K, res=Y)
+    ops.GEMM_HOOK = None
+    assert seen[-1] >= 1000000 and (seen[-1] // 100000) % 10 == 1, seen
+    torch.testing.assert_close(Y.cpu(), A @ W.T + R, atol=1e-4, rtol=2e-5)
+
+
+@pytest.mark.parametrize("K", [128, 512, 1408])
+def test_split_accuracy_is_at_least_fp32_mfma(K):
+    """error against float64, normalised by sum |a b|: the split contraction must not be worse than the fp32 MFMA path"""
+    from physdock_amd import ops
+    from physdock_amd.packing import split3_bf16
+    M, N = 128 * 16, 128 * 8
+    gen = torch.Generator().manual_seed(K)
+    A = torch.randn(M, K, generator=gen) * torch.exp(1.5 * torch.randn(M, K, generator=gen))     # wide dynamic range
+    W = torch.randn(N, K, generator=gen)
+    Ad, Wd = A.cuda(), W.cuda()
+    ref = (Ad.double() @ Wd.double().T)
+    mag = (Ad.double().abs() @ Wd.double().abs().T)
+    Y32, Y6 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.gemm(Ad, Wd, Y32, M, N, K)
+    ops.gemm(Ad, Wd, Y6, M, N, K, W3=split3_bf16(Wd))
+    e32 = ((Y32.double() - ref).abs() / mag)
+    e6 = ((Y6.double() - ref).abs() / mag)
+    print(f"K={K}: fp32 MFMA max {float(e32.max()):.2e} rms {float(e32.pow(2).mean().sqrt()):.2e} | "
+          f"bf16x6 max {float(e6.max()):.2e} rms {float(e6.pow(2).mean().sqrt()):.2e}")
+    assert float(e6.pow(2).mean().sqrt()) <= 1.1 * float(e32.pow(2).mean().sqrt())
+    assert float(e6.max()) <= 1.5 * float(e32.max())
+    assert not torch.equal(Y32, Y6)                       # the two paths really are different kernels
+
+
+def test_split_weights_are_an_exact_decomposition():
+    from physdock_amd.packing import split3_bf16
+    W = torch.randn(96, 77) * torch.exp(3 * torch.randn(96, 77))
+    s = split3_bf16(W)
+    assert s.shape == (3, 96, 96) and s.dtype == torch.bfloat16
+    assert torch.equal(s.float().sum(0)[:, :77], W)       # hi + mid + lo reproduces every fp32 weight bit for bit
+    assert float(s[:, :, 77:].abs().max()) == 0.0

@@ -31,7 +31,11 @@ def main():
         A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda")
         Y = torch.empty(M, N // 2 if glu else N, device="cuda")
         t = timeit(lambda: ops.gemm(A, W, Y, M, N, K, glu=glu))
-        print(f"gemm {tag:14s} M={M:7d} N={N:5d} K={K:5d}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:7.1f} TF")
+        from physdock_amd.packing import split3_bf16
+        W3 = split3_bf16(W)
+        t6 = timeit(lambda: ops.gemm(A, W, Y, M, N, K, glu=glu, W3=W3))
+        print(f"gemm {tag:14s} M={M:7d} N={N:5d} K={K:5d}: fp32 MFMA {t*1e6:9.1f} us {2*M*N*K/t/1e12:7.1f} TF | "
+              f"bf16x6 {t6*1e6:9.1f} us {2*M*N*K/t6/1e12:7.1f} TF")
     for (nb, H, n, tag) in [(B, 4, 2048, "dit atom"), (B, 16, 256, "dit token"), (256, 4, 256, "triangle"),
                             (1, 4, 2048, "trunk atom"), (128, 8, 256, "msa row")]:
         C = H * 32
