@@ -24,7 +24,13 @@ def needs_build():
 
 #: per-source extra flags.  attention.hip: the SLP vectoriser packs the softmax's f32 adds/muls into v_pk_*_f32,
 #: which issue slower beside MFMAs on gfx950 (cdna guide: packed f32 VALU is an anti-lever next to MFMA).
-EXTRA_FLAGS = {}     # (-fno-slp-vectorize on attention.hip measured neutral)
+#: gemm_split.hip: with SLP vectorisation hipcc (ROCm 7.2) packs the norm prologue into v_pk_add/mul/fma_f32 on a
+#: register pair that a global_load_dwordx2 has just returned; on MI355X the kernel then intermittently stages wrong A
+#: rows for lanes 48-63 of a wave (the last VALU pass) in the first staging after a tile change - seen only in the
+#: multi-tile 32x64 / 64x64 wave layouts, gone with any perturbation of the schedule, and gone in every shape / 6 x
+#: repetition of tools/diag_split3.py without the packed ops (NOTES.md).  Scalar f32 VALU is also what the CDNA guide
+#: recommends beside MFMAs.  tests/test_gemm_split_gpu.py::test_split_multi_tile_stress guards it.
+EXTRA_FLAGS = {"gemm_split.hip": ["-fno-slp-vectorize"]}
 
 
 def build(force=False, verbose=True):

@@ -29,19 +29,23 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SNT = 256;
 constexpr int KS = 16;               // k per LDS stage = one v_mfma_f32_32x32x16_bf16 step
 constexpr int PITCH = 24;            // bf16 per LDS row (48 bytes)
 
-template <int BM_, int BN_, int WM_>
+// Block tile BM x BN computed by NWAVES waves laid out WM x WN.  The hot 128 x 128 tile runs on EIGHT waves (64 x 32 per
+// wave; 32 x 64 for GLU epilogues, where a wave must own both columns of a pair): with two blocks per CU that is four
+// waves per SIMD at <= 128 VGPRs, so the matrix pipe always has a wave with MFMAs to issue while others stage operands -
+// the six short bf16 MFMAs per block leave 2.67 x less matrix time per staged byte than the fp32 kernel has to hide it in.
+template <int BM_, int BN_, int WM_, int NWAVES_>
 struct STile {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = 4 / WM_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = NWAVES_ / WM_, NT = 64 * NWAVES_;
     static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     static constexpr int STAGE = 3 * (BM + BN) * PITCH;                 // bf16 elements per stage
     static constexpr int LDS_BYTES = 2 * STAGE * 2;
     static constexpr int BLOCKS_PER_CU = LDS_BYTES > 60000 ? 2 : LDS_BYTES > 40000 ? 3 : 4;
     static constexpr int GRID = 256 * BLOCKS_PER_CU;
 };
+
 
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
@@ -63,9 +67,10 @@ __device__ __forceinline__ void split4(const f32x4& v, bf16x4& h, bf16x4& m, bf1
 }
 
 template <int PRO, int EPI, class TL>
-__global__ __launch_bounds__(SNT, TL::BLOCKS_PER_CU) void gemm_split_kernel(const pd_gemm_args p) {
+__global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(const pd_gemm_args p) {
     constexpr int BM = TL::BM, BN = TL::BN, TM = TL::TM, TN = TL::TN;
     constexpr int XSLOTS = TL::GRID / 8;
+    constexpr int SNT = TL::NT;
     constexpr int TPR_A = SNT / BM;              // threads per A row (2 or 4); a row of a 32-k slice = 8 f32x4 chunks
     constexpr int CPH_A = 4 / TPR_A;             // chunks per thread per 16-k half
     constexpr int TPR_W = SNT / BN;              // threads per W row; a row of a 32-k slice of one part = 4 bf16x8 chunks
@@ -228,10 +233,10 @@ __global__ __launch_bounds__(SNT, TL::BLOCKS_PER_CU) void gemm_split_kernel(cons
             const bool more = kt + 1 < nk;
             if (more) gload(bm0, bn0, (kt + 1) * 32);
             mma(0);
-            if (more) {
-                lds_barrier();                    // stage 0 has been read by every wave
-                stage(0, (kt + 1) * 32);
-            }
+            // every wave has read stage 0, and the stage-1 stores of the previous iteration (issued after ITS second
+            // barrier) become visible to the mma(1) below - so this barrier is needed in the last iteration too
+            if (nk > 1) lds_barrier();
+            if (more) stage(0, (kt + 1) * 32);
             mma(1);
             if (more) {
                 lds_barrier();                    // stage 1 read by every wave; the stage-0 stores above are visible
@@ -255,29 +260,35 @@ int run_split(int op, const pd_gemm_args* p, hipStream_t s) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
     const long long ntiles = (long long)(p->M / TL::BM) * (p->N / TL::BN);
-    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < TL::GRID ? ntiles : TL::GRID)), dim3(SNT), lds, s, *p);
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < TL::GRID ? ntiles : TL::GRID)), dim3(TL::NT), lds, s, *p);
     return pd_check_launch();
 }
 
-using S128 = STile<128, 128, 2>;
-using S64 = STile<64, 64, 2>;
-using S12864 = STile<128, 64, 4>;
+using S128 = STile<128, 128, 2, 8>;        // 2 x 4 waves of 64 x 32
+using S128G = STile<128, 128, 4, 8>;       // 4 x 2 waves of 32 x 64 (GLU)
+using S128W4 = STile<128, 128, 2, 4>;      // 2 x 2 waves of 64 x 64
+using S64 = STile<64, 64, 2, 4>;
+using S12864 = STile<128, 64, 4, 4>;
 
 int dispatch_split(int op, int pro, int epi, int tile, const pd_gemm_args* p, hipStream_t s) {
 #define PD_SCASE(P, E, C, TL) if (pro == P && epi == E && tile == C) return run_split<P, E, TL>(op, p, s);
     PD_SCASE(0, EPI_PLAIN, 128, S128) PD_SCASE(1, EPI_PLAIN, 128, S128)
     PD_SCASE(1, EPI_HN, 128, S128) PD_SCASE(2, EPI_HN, 128, S128)
-    PD_SCASE(1, EPI_GLU, 128, S128) PD_SCASE(2, EPI_GLU, 128, S128)
+    PD_SCASE(1, EPI_GLU, 128, S128G) PD_SCASE(2, EPI_GLU, 128, S128G)
     PD_SCASE(0, EPI_GATERES, 128, S128) PD_SCASE(0, EPI_TGATERES, 128, S128)
     PD_SCASE(0, EPI_PLAIN, 64, S64) PD_SCASE(1, EPI_PLAIN, 64, S64)
     PD_SCASE(1, EPI_HN, 64, S64) PD_SCASE(2, EPI_HN, 64, S64)
     PD_SCASE(0, EPI_GATERES, 64, S64) PD_SCASE(0, EPI_TGATERES, 64, S64)
     PD_SCASE(1, EPI_GLU, 12864, S12864) PD_SCASE(2, EPI_GLU, 12864, S12864)
+#ifdef PD_LAB      // experiments: 32 x 64 wave tiles with a plain epilogue; the 4-wave 64 x 64 layout with a GLU epilogue
+    PD_SCASE(1, EPI_PLAIN, 1284, S128G) PD_SCASE(1, EPI_GLU, 1282, S128W4)
+#endif
 #undef PD_SCASE
     return PD_ERR_UNSUPPORTED;
 }
 
 }  // namespace
+
 
 // Same contract as pd_gemm_stream_try (gemm_stream.hip); additionally needs the pre-split weights (args->W3) and
 // 16-byte aligned A rows with K % 4 == 0.  init_only: 0 launch, 1 raise the LDS limits, 2 query (returns the EPI kind).
@@ -294,6 +305,13 @@ extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, vo
     }
     const pd_gemm_args& p = *args;
     if (!p.W3 || p.K % 4 != 0) return PD_ERR_UNSUPPORTED;
+#ifdef PD_LAB
+    if (const char* f = getenv("PD_SPLIT_TILE")) { if (tile == 128) tile = atoi(f); }
+    if (tile == 1284 || tile == 1282) {
+        if (init_only == 2) return p.glu ? EPI_GLU : EPI_PLAIN;
+        return dispatch_split(0, pro, p.glu ? EPI_GLU : EPI_PLAIN, tile, &p, (hipStream_t)stream);
+    }
+#endif
     if (tile != 128 && tile != 64 && tile != 12864) return PD_ERR_UNSUPPORTED;
     const int tbm = tile == 64 ? 64 : 128, tbn = tile == 128 ? 128 : 64;
     if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;

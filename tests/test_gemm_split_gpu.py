@@ -116,3 +116,32 @@ def test_split_weights_are_an_exact_decomposition():
     assert s.shape == (3, 96, 96) and s.dtype == torch.bfloat16
     assert torch.equal(s.float().sum(0)[:, :77], W)       # hi + mid + lo reproduces every fp32 weight bit for bit
     assert float(s[:, :, 77:].abs().max()) == 0.0
+
+
+def test_split_multi_tile_stress():
+    """persistent blocks that walk several tiles, every wave layout, repeated: the bf16 x 6 result must equal the fp32-MFMA
+    kernel's to rounding every time (guards the staging hazard described in physdock_amd/build.py EXTRA_FLAGS)"""
+    from physdock_amd import ops
+    from physdock_amd.packing import split3_bf16
+    torch.manual_seed(0)
+    for (M, N, K, glu, pro) in [(128 * 48, 128 * 24, 128, 1, 1), (128 * 48, 128 * 24, 32, 1, 1), (128 * 48, 128 * 25, 96, 1, 1),
+                                (128 * 48, 128 * 24, 128, 0, 1), (128 * 128, 128 * 22, 512, 1, 1), (128 * 256, 768, 128, 1, 1),
+                                (128 * 256, 384, 128, 0, 1), (128 * 256, 128, 384, 0, 0)]:
+        A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / K ** 0.5
+        W3 = split3_bf16(W)
+        kw = dict(glu=glu)
+        if pro:
+            st = torch.empty(M, 2, device="cuda")
+            ops.rowstats(A, st, M, K, mode=ops.LN, eps=1e-5)
+            kw.update(stats=st, pro_w=1 + 0.1 * torch.randn(K, device="cuda"), pro_b=0.1 * torch.randn(K, device="cuda"))
+        No = N // 2 if glu else N
+        Y0, Y1 = torch.empty(M, No, device="cuda"), torch.empty(M, No, device="cuda")
+        ops.SPLIT_GEMM = False
+        try:
+            ops.gemm(A, W, Y0, M, N, K, W3=W3, **kw)
+        finally:
+            ops.SPLIT_GEMM = True
+        for rep in range(5):
+            ops.gemm(A, W, Y1, M, N, K, W3=W3, **kw)
+            bad = int(((Y0 - Y1).abs() > 1e-4 * (1 + Y0.abs())).sum())
+            assert bad == 0, (M, N, K, glu, pro, rep, bad)
