@@ -112,6 +112,7 @@ class LaunchTimer:
     def __init__(self, ops):
         self.ops = ops
         self.rec = {}      # kernel symbol -> [events, flops]
+        self.split = {}    # kernel symbol -> runs on the bf16 matrix pipe (split operands)
 
     def _add(self, name, e0, e1, flops, nbytes=0.0):
         r = self.rec.setdefault(name, [[], 0.0, 0.0])
@@ -126,18 +127,23 @@ class LaunchTimer:
 
         def gemm_hook(a, launch):
             v = L.pd_gemm_variant(C.byref(a))
+            split, v = v >= 1000000, v % 1000000
             streamed, epi, tcode, v = (v % 10000) >= 5000, (v // 10000) % 10, v // 100000, v % 5000
             cfg, lay, pro, scalar = (v % 1000) // 100, (v % 100) // 10, v % 10, v >= 1000
             name = "gemm_kernel<%s, %s, %s, %s, %d>" % (self.GEMM_NAMES[cfg], "true" if lay >= 1 else "false",
                                                          "true" if lay == 2 else "false", "false" if scalar else "true", pro)
             if streamed:        # persistent direct-epilogue variant (csrc/gemm_stream.hip)
                 name = "gemm_stream_kernel<%d, %d, Tile<%s> >" % (pro, epi, ("128, 128, 2", "64, 64, 2", "128, 64, 4")[tcode])
+                if split:       # 3 x bf16 split-operand variant (csrc/gemm_split.hip)
+                    name = "gemm_split_kernel<%d, %d, STile<%s> >" % (
+                        pro, epi, (("128, 128, 4, 8" if epi == 2 else "128, 128, 2, 8"), "64, 64, 2, 4", "128, 64, 4, 4")[tcode])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); launch(); e1.record()
             nb = max(a.batch, 1)
             n_out = a.N // 2 if a.glu else a.N
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))
             self._add(name, e0, e1, 2.0 * a.M * a.N * a.K * nb, byt)
+            self.split[name] = split
         def attn_hook(a, launch):
             v = L.pd_attention_variant(C.byref(a))          # 4 / 8 waves per block, or 4 + 100 * key chunks
             name = "attn_kernel<%d, %s>" % (v % 100, "true" if v > 100 else "false")

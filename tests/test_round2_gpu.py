@@ -134,12 +134,12 @@ def test_pair_init_z_multichain_relpos():
     L = ops._lib.init()
     zeros = torch.zeros(T, CZ, device="cuda")
     z = torch.empty(T * T, CZ, device="cuda")
-    WT = W.t().contiguous().cuda()
-    ops.check(L.pd_pair_init_z(ops.ptr(zeros), ops.ptr(zeros), ops.ptr(WT), ops.ptr(torch.zeros(CZ, device="cuda")),
-                               ops.ptr(g["asym_id"].int().cuda()), ops.ptr(g["sym_id"].int().cuda()),
-                               ops.ptr(g["entity_id"].int().cuda()), ops.ptr(g["residue_index"].long().cuda()),
-                               ops.ptr(g["rel_tok_feat"].float().contiguous().cuda()), ops.ptr(torch.zeros(T, T, device="cuda")),
-                               ops.ptr(z), T, CZ, ops.stream()), "pair_init_z")
+    # (every operand is held in a variable: a temporary's device block may be recycled by the next allocation)
+    WT, wb, bonds = W.t().contiguous().cuda(), torch.zeros(CZ, device="cuda"), torch.zeros(T, T, device="cuda")
+    asym, sym, ent = g["asym_id"].int().cuda(), g["sym_id"].int().cuda(), g["entity_id"].int().cuda()
+    res, rtf = g["residue_index"].long().cuda(), g["rel_tok_feat"].float().contiguous().cuda()
+    ops.check(L.pd_pair_init_z(ops.ptr(zeros), ops.ptr(zeros), ops.ptr(WT), ops.ptr(wb), ops.ptr(asym), ops.ptr(sym), ops.ptr(ent),
+                               ops.ptr(res), ops.ptr(rtf), ops.ptr(bonds), ops.ptr(z), T, CZ, ops.stream()), "pair_init_z")
     d = float((z.cpu().reshape(T, T, CZ) - g["y"]).abs().max())
     print(f"pair_init_z multi-chain RelPos: max |diff| {d:.2e} at |y| max {float(g['y'].abs().max()):.2f}")
     torch.testing.assert_close(z.cpu().reshape(T, T, CZ), g["y"], atol=1e-4, rtol=1e-4)
@@ -150,12 +150,12 @@ def test_augment_kernel_vs_reference_fixture():
     from physdock_amd import ops
     g = load_golden("g4_augment_align")
     x, mask = g["x"].cuda().contiguous(), g["mask"].cuda().contiguous()
+    rot_u, trans = g["rot_u"].cuda().contiguous(), g["trans"].cuda().contiguous()
     B, A = x.shape[0], x.shape[1]
     out = torch.empty_like(x)
     L = ops._lib.init()
-    ops.check(L.pd_augment(ops.ptr(x), 1.0, ops.ptr(mask), ops.ptr(g["rot_u"].cuda().contiguous()),
-                           ops.ptr(g["trans"].cuda().contiguous()), None, 1.0, 0.0, None, 0, 0, ops.ptr(out), B, A,
-                           ops.stream()), "augment")
+    ops.check(L.pd_augment(ops.ptr(x), 1.0, ops.ptr(mask), ops.ptr(rot_u), ops.ptr(trans), None, 1.0, 0.0, None, 0, 0,
+                           ops.ptr(out), B, A, ops.stream()), "augment")
     print(f"augment: max |diff| {float((out.cpu() - g['y']).abs().max()):.2e} at |y| max {float(g['y'].abs().max()):.1f}")
     torch.testing.assert_close(out.cpu(), g["y"], atol=1e-4, rtol=1e-5)
 
