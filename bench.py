@@ -147,6 +147,9 @@ class LaunchTimer:
         def attn_hook(a, launch):
             v = L.pd_attention_variant(C.byref(a))          # 4 / 8 waves per block, or 4 + 100 * key chunks
             name = "attn_kernel<%d, %s>" % (v % 100, "true" if v > 100 else "false")
+            if v >= 1000:       # bf16 matrix pipe, split operands (csrc/attn_split.hip)
+                name = "attn_split_kernel<%d>" % (v % 100)
+            self.split[name] = v >= 1000
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); launch(); e1.record()
             c = a.nheads * 32                    # q, o: nq rows; k, v: nk rows; the bias tile set is read once per launch

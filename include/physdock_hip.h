@@ -104,6 +104,9 @@ typedef struct pd_attn_args {
     float scale;             /* 1/sqrt(32) */
     int bias_nk;             /* key count the bias buffer was laid out for (pd_gemm PD_OUT_BIASFRAG's T2, i.e. the PADDED
                                 count when nk is the real one); 0 -> nk                                                  */
+    int fp32_mfma;           /* 1: keep both contractions on v_mfma_f32_32x32x2_f32 (csrc/attention.hip); 0 (default): launches
+                                that fill the chip run on the bf16 matrix pipe with 3-way split operands at fp32 accuracy
+                                (csrc/attn_split.hip)                                                                      */
     float* ws;               /* optional scratch (16-byte aligned) for key-split launches, see below; may be NULL       */
     long long ws_bytes;
     int nsplit;              /* set by the launcher                                                                      */
@@ -112,7 +115,7 @@ typedef struct pd_attn_args {
  * up to 8 key chunks when ws holds nsplit * nbatch * nq * nheads * 34 floats; a second kernel merges the chunks. */
 int pd_attention(const pd_attn_args* args, void* stream);
 /* waves per block (4 or 8 = template argument of attn_kernel) pd_attention picks for these arguments; 4 + 100 * nsplit for
- * a key-split launch (profiling) */
+ * a key-split launch; 1000 + waves for attn_split_kernel<waves> (profiling) */
 int pd_attention_variant(const pd_attn_args* args);
 
 /* ---- pair-representation / pooling kernels (pair.hip) ----------------------------------

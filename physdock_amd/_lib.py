@@ -66,7 +66,7 @@ class AttnArgs(C.Structure):
         ("nq", C.c_int), ("nk", C.c_int), ("nbatch", C.c_int), ("nheads", C.c_int),
         ("q_bs", C.c_longlong), ("q_ss", C.c_longlong), ("k_bs", C.c_longlong), ("k_ss", C.c_longlong),
         ("v_bs", C.c_longlong), ("v_ss", C.c_longlong), ("o_bs", C.c_longlong), ("o_ss", C.c_longlong),
-        ("bias", _fp), ("scale", C.c_float), ("bias_nk", C.c_int),
+        ("bias", _fp), ("scale", C.c_float), ("bias_nk", C.c_int), ("fp32_mfma", C.c_int),
         ("ws", _fp), ("ws_bytes", C.c_longlong), ("nsplit", C.c_int),
     ]
 

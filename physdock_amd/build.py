@@ -30,7 +30,7 @@ def needs_build():
 #: multi-tile 32x64 / 64x64 wave layouts, gone with any perturbation of the schedule, and gone in every shape / 6 x
 #: repetition of tools/diag_split3.py without the packed ops (NOTES.md).  Scalar f32 VALU is also what the CDNA guide
 #: recommends beside MFMAs.  tests/test_gemm_split_gpu.py::test_split_multi_tile_stress guards it.
-EXTRA_FLAGS = {"gemm_split.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"gemm_split.hip": ["-fno-slp-vectorize"], "attn_split.hip": ["-fno-slp-vectorize"]}
 
 
 def build(force=False, verbose=True):

@@ -274,9 +274,13 @@ static int attn_nsplit(const pd_attn_args* a) {
     return s < 2 ? 1 : (int)s;
 }
 
+// attn_split.hip: the same kernel on the bf16 matrix pipe (3 x bf16 split operands)
+extern "C" int pd_attention_split_try(const pd_attn_args* a, void* stream, int init_only);
+
 // waves per block pd_attention uses for these arguments (= template argument of attn_kernel; for profiling)
 PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
     if (!a) return PD_ERR_ARG;
+    if (!a->fp32_mfma && attn_nsplit(a) <= 1) return 1000 + (a->nq > 128 ? 8 : 4);
 #ifdef PD_LAB
     static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
 #else
@@ -297,6 +301,7 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O | (uintptr_t)a->bias) & 15)
         return PD_ERR_UNSUPPORTED;
     const int variant = pd_attention_variant(a);
+    if (variant >= 1000) return pd_attention_split_try(a, stream, 0);
     if (variant > 100) {
         if (((uintptr_t)a->ws & 15) != 0) return PD_ERR_UNSUPPORTED;
         pd_attn_args s = *a;
@@ -323,6 +328,8 @@ extern "C" __attribute__((visibility("default"))) int pd_lab_set_attn_trace(void
 #endif
 
 // resident blocks per CU the runtime computes for the kernel (diagnostic, tools/attn_trace.py)
+PD_EXPORT int pd_attention_init(void) { return pd_attention_split_try(nullptr, nullptr, 1); }
+
 PD_EXPORT int pd_attention_occupancy(void) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (attn_kernel<4, false>), 256, 0) != hipSuccess) return PD_ERR_LAUNCH;

@@ -542,8 +542,11 @@ static int persistent_try(const pd_gemm_args* args, int pro, int tile, void* str
     return pd_gemm_stream_try(args, pro, tile, stream, init_only);
 }
 
+extern "C" int pd_attention_init(void);
+
 PD_EXPORT int pd_init(void) {
     int rc = pd_gemm_stream_try(nullptr, 0, 0, nullptr, 1);
+    { const int r = pd_attention_init(); if (r != PD_OK) rc = r; }
     { const int r = pd_gemm_split_try(nullptr, 0, 0, nullptr, 1); if (r != PD_OK) rc = r; }
     for (int cfg = 0; cfg < 4; ++cfg)
         for (int lay = 0; lay < 3; ++lay)

@@ -84,6 +84,9 @@ def lab_set_trace(kind, buf):
 #: fp32-MFMA kernels everywhere (A/B comparisons in the tests and the bench)
 SPLIT_GEMM = True
 
+#: the same switch for the attention kernel (csrc/attn_split.hip vs csrc/attention.hip)
+SPLIT_ATTN = True
+
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None
 ATTN_HOOK = None
@@ -127,6 +130,7 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
     a.bias = P(bias)
     a.scale = scale
     a.bias_nk = bias_nk
+    a.fp32_mfma = 0 if SPLIT_ATTN else 1
     if ws is not None:
         a.ws, a.ws_bytes = ptr(ws), ws.numel() * 4
     if ATTN_HOOK is not None:

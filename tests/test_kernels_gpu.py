@@ -305,7 +305,10 @@ def ref_attention(q, k, v, bias):
                                                 (5, 1, 24, 24, True), (2, 8, 40, 8, False), (1, 16, 256, 256, True),
                                                 (2, 4, 70, 333, True), (3, 2, 2048, 2048, True),
                                                 (64, 4, 1000, 1000, True), (32, 8, 1024, 520, False)])     # 8-wave blocks
-def test_attention(ops, B, H, nq, nk, use_bias):
+@pytest.mark.parametrize("split", [False, True], ids=["fp32mfma", "bf16x6"])
+def test_attention(ops, B, H, nq, nk, use_bias, split, monkeypatch):
+    """both attention kernels: csrc/attention.hip (fp32 MFMA) and csrc/attn_split.hip (bf16 pipe, split operands)"""
+    monkeypatch.setattr(ops, "SPLIT_ATTN", split)
     C = H * 32
     q = torch.randn(B, nq, C, generator=g(1)); k = torch.randn(B, nk, C, generator=g(2))
     v = torch.randn(B, nk, C, generator=g(3))

@@ -46,11 +46,15 @@ def main():
         f = lambda: ops.attention(q.data_ptr(), q.data_ptr() + 4 * C, q.data_ptr() + 8 * C, o, nq=n, nk=n, nbatch=nb,
                                   nheads=H, q_strides=st, k_strides=st, v_strides=st, o_strides=(n * C, C), bias=bias)
         t = timeit(f)
+        ops.SPLIT_ATTN = False
+        t32 = timeit(f)
+        ops.SPLIT_ATTN = True
         fl = 4.0 * nb * H * n * n * 32
         f0 = lambda: ops.attention(q.data_ptr(), q.data_ptr() + 4 * C, q.data_ptr() + 8 * C, o, nq=n, nk=n, nbatch=nb,
                                    nheads=H, q_strides=st, k_strides=st, v_strides=st, o_strides=(n * C, C), bias=None)
         t0 = timeit(f0)
-        print(f"attn {tag:12s} nb={nb:4d} H={H:2d} n={n:5d}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF   (no bias: {t0*1e6:9.1f} us {fl/t0/1e12:7.1f} TF)")
+        print(f"attn {tag:12s} nb={nb:4d} H={H:2d} n={n:5d}: bf16x6 {t*1e6:9.1f} us {fl/t/1e12:7.1f} TF | fp32 MFMA {t32*1e6:9.1f} us {fl/t32/1e12:7.1f} TF"
+              f"   (bf16x6 no bias: {t0*1e6:9.1f} us {fl/t0/1e12:7.1f} TF)")
 
 
 if __name__ == "__main__":
