@@ -280,7 +280,10 @@ extern "C" int pd_attention_split_try(const pd_attn_args* a, void* stream, int i
 // waves per block pd_attention uses for these arguments (= template argument of attn_kernel; for profiling)
 PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
     if (!a) return PD_ERR_ARG;
-    if (!a->fp32_mfma && attn_nsplit(a) <= 1) return 1000 + (a->nq > 128 ? 8 : 4);
+    // the bf16 split-operand kernel pays off when the launch fills the chip (>= one 32-query wave per SIMD); smaller launches
+    // are latency-bound and stay on the fp32-MFMA kernel (with its key-split option)
+    if (!a->fp32_mfma && attn_nsplit(a) <= 1 && (long long)a->nbatch * a->nheads * ((a->nq + 31) / 32) >= 1024)
+        return 1000 + (a->nq > 128 ? 8 : 4);
 #ifdef PD_LAB
     static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
 #else

@@ -317,6 +317,9 @@ extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, vo
     if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
     if (((uintptr_t)p.W3 & 15) != 0) return PD_ERR_UNSUPPORTED;
     if (p.M % tbm != 0 || p.N % tbn != 0) return PD_ERR_UNSUPPORTED;
+    // Launches that do not fill the chip are latency-bound (two block barriers per 32-k slice here, one in gemm_stream.hip):
+    // measured at 1-4 samples the fp32 kernel is faster on every DiT shape, from ~256 tiles on the split kernel wins.
+    if ((long long)(p.M / tbm) * (p.N / tbn) < 256) return PD_ERR_UNSUPPORTED;
     if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
     if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;

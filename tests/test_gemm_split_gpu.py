@@ -70,9 +70,9 @@ def test_split_adaln_headnorm_rowgroup_gate(split_ops):
     _run_split(split_ops, lambda ops: tk.test_gemm_stream_adaln_shapes(ops))
 
 
-@pytest.mark.parametrize("M,N,K", [(64 * 20, 64 * 5, 512), (128 * 6, 64 * 3, 96)])
+@pytest.mark.parametrize("M,N,K", [(64 * 40, 64 * 8, 512), (64 * 64, 64 * 5, 96)])
 def test_split_small_tiles(split_ops, M, N, K):
-    """problems that do not fill the chip with 128 x 128 tiles take the 64 x 64 split tile"""
+    """problems that do not fill the chip with 128 x 128 tiles (but have >= 256 tiles of 64 x 64) take the 64 x 64 split tile"""
     ops, seen = split_ops
     gen = torch.Generator().manual_seed(3)
     A = torch.randn(M, K, generator=gen); W = torch.randn(N, K, generator=gen) / math.sqrt(K)
