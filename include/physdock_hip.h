@@ -173,6 +173,12 @@ int pd_pairwise_rmsd(const float* x, const int* idx, const float* ref, float* D,
 int pd_euler(const float* x_hat, const float* x_den, const float* x_proj, const float* w, float t_hat, float eta, float dt,
              float* x_next, int B, int A, void* stream);
 int pd_timestep_embed(const float* tau, float* emb, int n, void* stream);
+/* chirality accept / reject of B poses without leaving the device (replaces the per-pose RDKit rebuild + R/S comparison of
+ * redocking.py:264-281,303-317): centres[nc][4] = (centre atom, three neighbour atoms), indices into the A atoms of a pose;
+ * sign of the signed volume (n1-c).((n2-c)x(n3-c)) vs ref_sign[nc] (+1 / -1); accept[b] = 1 iff every centre matches.
+ * sign_out [B][nc] (optional) returns the signs themselves (used once, on the reference coordinates, to make ref_sign).   */
+int pd_chirality(const float* x, const int* centres, const int* ref_sign, int* accept, int* sign_out, int B, int A,
+                 int n_centres, void* stream);
 /* ligand rows of a pose batch, for the relaxation branch (model.py:252-257):
  * pd_ligand_gather : lig[b,l,:] = x[b, lig_idx[l], :]                      (`x_denoised[:, is_ligand_atom]`)
  * pd_ligand_scatter: dst = src with dst[b,a,:] = lig[b, atom_slot[a], :] where atom_slot[a] >= 0

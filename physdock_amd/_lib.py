@@ -144,6 +144,7 @@ def _declare(L):
     sig("pd_timestep_embed", p, p, i, p)
     sig("pd_mmff_energy_grad", p, p, p, p, i, p)
     sig("pd_mmff_relax", p, p, p, p, p, ll, i, i, i, p)
+    sig("pd_chirality", p, p, p, p, p, i, i, i, p)
     sig("pd_ligand_gather", p, p, p, i, i, i, p)
     sig("pd_ligand_scatter", p, p, p, p, i, i, i, p)
 

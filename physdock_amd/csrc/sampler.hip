@@ -394,6 +394,32 @@ __global__ __launch_bounds__(256) void ligand_scatter_kernel(float* __restrict__
     dst[t] = l >= 0 ? lig[(b * L + l) * 3 + k] : src[t];
 }
 
+// ------------------------------------------------------------------ chirality accept / reject (redocking.py:264-281,303-317)
+// The reference rebuilds every predicted ligand with RDKit and compares the R/S labels of its stereocentres with those of
+// the reference coordinates.  For one molecule the label of a centre flips exactly when its geometric handedness flips, so
+// the test is the sign of the signed volume (n1 - c) . ((n2 - c) x (n3 - c)) of each centre c with three fixed neighbours:
+// accept[b] = all centres of pose b have the reference sign (a flat centre, volume 0, is a mismatch).
+__global__ __launch_bounds__(64) void chirality_kernel(const float* __restrict__ x, const int* __restrict__ centres,
+                                                      const int* __restrict__ ref_sign, int* __restrict__ accept,
+                                                      int* __restrict__ sign_out, int A, int nc) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* xb = x + (long long)b * A * 3;
+    bool ok = true;
+    for (int c = lane; c < nc; c += 64) {
+        const int i0 = centres[4 * c], i1 = centres[4 * c + 1], i2 = centres[4 * c + 2], i3 = centres[4 * c + 3];
+        const float cx = xb[3 * i0], cy = xb[3 * i0 + 1], cz = xb[3 * i0 + 2];
+        const float ax = xb[3 * i1] - cx, ay = xb[3 * i1 + 1] - cy, az = xb[3 * i1 + 2] - cz;
+        const float bx = xb[3 * i2] - cx, by = xb[3 * i2 + 1] - cy, bz = xb[3 * i2 + 2] - cz;
+        const float dx = xb[3 * i3] - cx, dy = xb[3 * i3 + 1] - cy, dz = xb[3 * i3 + 2] - cz;
+        const float vol = ax * (by * dz - bz * dy) + ay * (bz * dx - bx * dz) + az * (bx * dy - by * dx);
+        const int sgn = vol > 0.f ? 1 : (vol < 0.f ? -1 : 0);
+        if (sign_out) sign_out[(long long)b * nc + c] = sgn;
+        if (ref_sign && sgn != ref_sign[c]) ok = false;
+    }
+    const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
+    if (lane == 0 && accept) accept[b] = bad == 0ull ? 1 : 0;
+}
+
 // emb[n,:] = [cos(tau f_k) | sin(tau f_k)], f_k = exp(-ln(1e4) k/128)      (timestep_embeddings.py:64-81)
 __global__ void timestep_embed_kernel(const float* __restrict__ tau, float* __restrict__ emb, int n) {
     const int i = blockIdx.x, k = threadIdx.x;          // 128 threads
@@ -481,6 +507,14 @@ PD_EXPORT int pd_euler(const float* x_hat, const float* x_den, const float* x_pr
     const long long n = (long long)B * A * 3;
     hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_hat, x_den, x_proj,
                        w, t_hat, eta, dt, x_next, A, n);
+    return pd_check_launch();
+}
+
+PD_EXPORT int pd_chirality(const float* x, const int* centres, const int* ref_sign, int* accept, int* sign_out, int B, int A,
+                           int n_centres, void* stream) {
+    if (!x || !centres || B <= 0 || A <= 0 || n_centres < 0 || (!accept && !sign_out) || (accept && !ref_sign)) return PD_ERR_ARG;
+    hipLaunchKernelGGL(chirality_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, centres, ref_sign, accept, sign_out, A,
+                       n_centres);
     return pd_check_launch();
 }
 

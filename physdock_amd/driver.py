@@ -5,9 +5,10 @@ What the reference does per system, and what is kept here:
   * rounds (redocking.py:181-183): round 0 samples freely; further rounds only with physics correction, each with
     the re-sampled MSA of that round (`batch_msa_feat[round]`, :188) and the template-projection branch of the
     sampler switched on (`align_ref_pos = round > 0`, `use_ref_mol_poses`, :283-299);
-  * accept / reject (:303-317): the reference rebuilds the ligand with RDKit and compares chiral centres.  RDKit is
-    not part of this build, so the test is an injected callable `accept_fn(x_pose_cpu [A,3]) -> bool` (default:
-    accept); rejected poses go to a bounded deque (maxlen = max_samples, :164);
+  * accept / reject (:303-317): the reference rebuilds the ligand with RDKit and compares chiral centres.  Here:
+    `chirality=` (chirality.ChiralityReference: signed volumes of the stereocentres on the device, kernel pd_chirality)
+    and / or an injected callable `accept_fn(x_pose_cpu [A,3]) -> bool`; default: accept.  Rejected poses go to a
+    bounded deque (maxlen = max_samples, :164);
   * the adaptive threshold of the physics branch (:318-322): x1.15 after a round with any accepted pose, otherwise
     x0.7 with floor 1;
   * template pool for the next round (:323-335, and :293): accepted predicted ligands + the reference conformers
@@ -86,7 +87,7 @@ def _mol_num_atoms(ref_mol) -> Optional[int]:
 
 
 def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses: Optional[torch.Tensor] = None,
-           accept_fn: Optional[Callable[[torch.Tensor], bool]] = None, physics_correction: bool = False,
+           accept_fn: Optional[Callable[[torch.Tensor], bool]] = None, chirality=None, physics_correction: bool = False,
            max_samples: int = 5, max_rounds: int = 10, num_samples_per_round: int = 5, steps: int = 40,
            mmff_gamma_0_factor_start: float = 6.0, karras_noise_schedule_power: float = 1000, use_pocket: bool = True,
            align_weights: Optional[torch.Tensor] = None, ranking: bool = True, seed: Optional[int] = None,
@@ -131,10 +132,17 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
         call.update(kw)
         with torch.no_grad():
             x_pred = model.sample_diffusion(batch, **call)
-        x_cpu = x_pred.cpu()
+        # accept / reject (redocking.py:303-317): on the device when a ChiralityReference is given (one kernel, one [B]
+        # mask to the host), else through the injected per-pose callable (which needs the poses on the host)
+        dev_ok = chirality.accept(x_pred).tolist() if (physics_correction and chirality is not None) else None
+        x_cpu = x_pred.cpu() if (physics_correction and accept_fn is not None) else x_pred
         flags = []
-        for x, xc in zip(x_pred, x_cpu):
-            ok = bool(accept_fn(xc)) if (physics_correction and accept_fn is not None) else True
+        for b, (x, xc) in enumerate(zip(x_pred, x_cpu)):
+            ok = True
+            if dev_ok is not None:
+                ok = bool(dev_ok[b])
+            if ok and physics_correction and accept_fn is not None:
+                ok = bool(accept_fn(xc))
             flags.append(ok)
             if ok:
                 ligand_templates.append(x[is_lig])

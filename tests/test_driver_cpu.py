@@ -88,3 +88,21 @@ def test_next_gamma_factor():
     assert driver.next_gamma_factor(6.0, True) == pytest.approx(6.9)
     assert driver.next_gamma_factor(6.0, False) == pytest.approx(4.2)
     assert driver.next_gamma_factor(1.1, False) == 1.0
+
+
+def test_ranking_representatives_match_the_reference_procedure_fixture():
+    """G10: K-means(5, random_state=0) + medoids + global medoid first, as redocking.py:392-418 computes them with
+    scikit-learn on a committed distance matrix (tools/make_golden.py main_g10) - not a comparison of the product's
+    function with itself"""
+    import numpy as np
+    from conftest import load_golden
+    from physdock_amd.ranking import get_representatives
+    g = load_golden("g10_ranking")
+    D = g["dist"].numpy()
+    assert get_representatives(D, 5) == g["reps5"].tolist()
+    assert get_representatives(D, 1)[0] == g["medoid"]
+    ids = get_representatives(D, 5)
+    first = get_representatives(D, 1)[0]
+    ids = [first] + [i for i in ids if i != first] if first in ids else [first] + ids[:4]
+    assert ids == g["order"].tolist()
+    assert np.allclose([g["rmsds"][i] for i in ids], g["top_rmsds"].numpy())

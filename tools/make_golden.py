@@ -78,7 +78,7 @@ def main():
     import warnings
     warnings.filterwarnings("ignore")
     ap_ = argparse.ArgumentParser()
-    ap_.add_argument("--sets", default="g1-7,g8,g9")
+    ap_.add_argument("--sets", default="g1-7,g8,g9,g10")
     sets = set(ap_.parse_args().sets.split(","))
     install_shims()
     os.makedirs(OUT, exist_ok=True)
@@ -107,6 +107,8 @@ def main():
         main_g8(RefPhysDock, mlc, ref_model_module)
     if "g9" in sets:
         main_g9(RefPhysDock, RefConfig, ref_model_module)
+    if "g10" in sets:
+        main_g10()
 
 
 class Recorder:
@@ -223,6 +225,41 @@ def main_g9(RefPhysDock, RefConfig, ref_model_module):
         nz = split_draws(r.log, B, steps, A)
         print(f"  reference medium/{tag}: T={batch['target_feat'].shape[0]} A={A} B={B} steps={steps}: {time.time() - t0:.0f} s")
         npz(f"g9_medium_{tag}", x_pred=x_pred, steps=steps, **extra, **{"noise_" + k: v for k, v in nz.items()})
+
+
+def main_g10():
+    """G10: the ranking step of redocking.py:357-423 on synthetic aligned ligand poses.  redocking.py itself cannot be
+    imported here (RDKit / OpenMM), so its numpy + scikit-learn statements are executed on arrays instead of SDF files:
+    ligand RMSD to the ground truth (:382), pairwise RMSD matrix (:390), KMeans(n_clusters, random_state=0) on the rows of
+    that matrix with the in-cluster medoid as representative (:392-408), global medoid first (:410-418)."""
+    from sklearn.cluster import KMeans
+    rng = np.random.default_rng(7)
+    n, L = 24, 14
+    gt = rng.normal(0, 2.0, size=(L, 3))
+    centres = [gt + rng.normal(0, s, size=(L, 3)) for s in (0.3, 1.2, 2.0, 3.5, 5.0, 0.8)]
+    preds = np.stack([centres[i % 6] + rng.normal(0, 0.25, size=(L, 3)) for i in range(n)])
+    rmsds = [np.sqrt(np.mean(np.linalg.norm(p_ - gt, axis=-1) ** 2, axis=0)) for p_ in preds]
+    dist = np.sqrt(np.mean(np.linalg.norm(preds[:, None] - preds[None], axis=-1) ** 2, axis=-1))
+
+    def get_representatives(distance_matrix, num_clusters=5):
+        km = KMeans(n_clusters=num_clusters, random_state=0)
+        km.fit(np.array([distance_matrix[i] for i in range(len(distance_matrix))]))
+        reps = []
+        for c in range(num_clusters):
+            idx = np.where(km.labels_ == c)[0]
+            avg = np.mean(distance_matrix[idx, :], axis=0)
+            reps.append(int(idx[np.argmin(avg[idx])]))
+        return reps, km.labels_
+    ids, labels5 = get_representatives(dist, 5)
+    ids_1 = get_representatives(dist, 1)[0][0]
+    reps5 = list(ids)
+    if ids_1 in ids:
+        ids.remove(ids_1)
+        ids = [ids_1] + ids
+    else:
+        ids = [ids_1] + ids[:4]
+    npz("g10_ranking", gt=gt, preds=preds, rmsds=np.array(rmsds), dist=dist, labels5=labels5, reps5=np.array(reps5),
+        medoid=ids_1, order=np.array(ids), top_rmsds=np.array([rmsds[i] for i in ids]))
 
 
 def main_g1_g7(RefPhysDock, RefConfig, rp, rt, rdc, rtu, mlc):
