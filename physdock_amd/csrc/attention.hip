@@ -331,7 +331,7 @@ extern "C" __attribute__((visibility("default"))) int pd_lab_set_attn_trace(void
 #endif
 
 // resident blocks per CU the runtime computes for the kernel (diagnostic, tools/attn_trace.py)
-PD_EXPORT int pd_attention_init(void) { return pd_attention_split_try(nullptr, nullptr, 1); }
+extern "C" int pd_attention_init(void) { return pd_attention_split_try(nullptr, nullptr, 1); }
 
 PD_EXPORT int pd_attention_occupancy(void) {
     int n = 0;
