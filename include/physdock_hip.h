@@ -91,6 +91,16 @@ int pd_rowstats(const float* x, float* stats, int M, int C, int ldx, int kmajor,
 int pd_rownorm(const float* x, float* y, const float* res, const float* w, const float* b,
                int M, int C, int mode, float eps, int act, void* stream);
 
+/* ---- pd_pair_bias: attention pair bias in one streaming pass (pairbias.hip) -------------------
+ * frag = fragment layout of [ (norm(x) . Wf^T + c2 + maskadd ? 0 : maskval) * out_scale ] for x [T1*T2, C] (C = 16 or 128),
+ * Wf [H][C] = projection weights with the norm gain folded in (Wf[h][k] = w[k] W[h][k]), c2 [H] = projection of the norm
+ * shift (NULL: 0), H in {4, 8, 16} for C = 128 and {4, 24} for C = 16; mode 0 RMS / 1 LayerNorm.  Replaces linear_z(norm_z(z))
+ * of attentions.py:38-41,82-85,200-203,246,254 (= pd_rowstats + pd_gemm PD_OUT_BIASFRAG) with one read of x; stats_out
+ * (optional, [T1*T2][2]) receives the (mean, rstd) pairs for the projection GEMM that follows.  T2 % 4 == 0.              */
+int pd_pair_bias(const float* x, const float* Wf, const float* c2, float* stats_out, const float* maskadd, float maskval,
+                 float out_scale, float* frag, int T1, int T2, int C, int H, int frag_transpose, int mode, float eps,
+                 void* stream);
+
 /* ---- pd_attention: O = softmax(Q K^T * scale + bias) V, head width 32 ------------------
  * replaces F.scaled_dot_product_attention at attentions.py:48,92,130,211,259.
  * Q/K/V/O element (b, i, h, d) at ptr[b*bs + i*ss + h*32 + d].  bias is in the fragment

@@ -117,6 +117,7 @@ def _declare(L):
     sig("pd_gemm_variant", C.POINTER(GemmArgs))
     sig("pd_rowstats", p, p, i, i, i, i, i, f, p)
     sig("pd_rownorm", p, p, p, p, p, i, i, i, f, i, p)
+    sig("pd_pair_bias", p, p, p, p, p, f, f, p, i, i, i, i, i, i, f, p)
     sig("pd_attention", C.POINTER(AttnArgs), p)
     sig("pd_attention_variant", C.POINTER(AttnArgs))
     sig("pd_graph_begin", p)

@@ -92,14 +92,19 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ shared blocks
-    def pair_bias(self, prefix, z, T1, T2, C, mask, norm_w, out, transpose=False, norm="norm_z", st=None):
-        """bias[h, q, k] = (W_z . RMSNorm(z))[h] + maskbias -> fragment layout (x log2 e)"""
+    def pair_bias(self, prefix, z, T1, T2, C, mask, norm_w, out, transpose=False, norm="norm_z", st_out=None):
+        """bias[h, q, k] = (W_z . RMSNorm(z))[h] + maskbias -> fragment layout (x log2 e).  One streaming pass over z
+        (pd_pair_bias) that also leaves the row statistics in `st_out` for the projection GEMM that shares the norm;
+        shapes the kernel does not cover go through rowstats + GEMM."""
         P = self.P
         W, _, H, K, ldw = P.linear(prefix + ".linear_z")
-        if st is None:
-            st = self.stats(z, T1 * T2, C, RMS, self.eps, "stats_pb")
+        if ops.pair_bias(z, P.bias_w(prefix, norm), out, T1, T2, C, H, stats_out=st_out, maskadd=mask, maskval=-self.inf,
+                         out_scale=LOG2E, transpose=transpose, mode=RMS, eps=self.eps):
+            return H
+        st = st_out if st_out is not None else self.ws.get(f"stats_pb@{self.lane}", T1 * T2, 2)
+        ops.rowstats(z, st, T1 * T2, C, mode=RMS, eps=self.eps)
         self.gemm(z, W, out, T1 * T2, H, C, ldw=ldw, stats=st, pro_w=norm_w, out_mode=OUT_BIASFRAG, T1=T1, T2=T2,
-                 frag_transpose=transpose, maskadd=mask, maskval=-self.inf, out_scale=LOG2E)
+                  frag_transpose=transpose, maskadd=mask, maskval=-self.inf, out_scale=LOG2E)
         return H
 
     def attention_pair_bias(self, prefix, s, nbatch, N, C, bias, norm_name="norm_s", nk=None):
@@ -159,13 +164,14 @@ class Engine:
         P = self.P
         M = T * T
         H = C // 32
-        st = self.stats(z, M, C, RMS, self.eps)
         nw = P[prefix + ".norm.weight"]
+        # bias first: its streaming pass over z also produces the row statistics of the shared norm
+        st = self.ws.get(f"stats@{self.lane}", M, 2)
+        bias = self.ws.get("tri_bias", ops.bias_frag_numel(H, T, T), zero=True)
+        self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, norm="norm", st_out=st)
         W, b = P.qkvg(prefix)
         qkvg = self.ws.get("qkvg", M, 4 * C)
         self.gemm(z, W, qkvg, M, 4 * C, C, stats=st, pro_w=nw, bias=b)
-        bias = self.ws.get("tri_bias", ops.bias_frag_numel(H, T, T), zero=True)
-        self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, st=st)
         o = self.ws.get("attn_o", M, C)
         if not transpose:
             st4, sto = (T * 4 * C, 4 * C), (T * C, C)
@@ -349,10 +355,12 @@ class Engine:
         L = ops._lib.init()
         # --- hoisted biases
         Wa, ba_, na = P.dit_bias("atom")                  # [2*nb_atom*H, Cap] with LN affine folded
-        st = self.stats(ap, A * A, Cap, LN, 1e-5, "stats_pb")
         fa = ws.get("dit_atom_bias", ops.bias_frag_numel(na, A, A), zero=True)
-        self.gemm(ap, Wa, fa, A * A, na, Cap, stats=st, bias=ba_, out_mode=OUT_BIASFRAG, T1=A, T2=A,
-                 maskadd=batch["ap_mask"], maskval=-self.inf, out_scale=LOG2E)
+        if not (Wa.shape[1] == Cap and ops.pair_bias(ap, Wa, fa, A, A, Cap, na, c2=ba_, maskadd=batch["ap_mask"],
+                                                      maskval=-self.inf, out_scale=LOG2E, mode=LN, eps=1e-5)):
+            st = self.stats(ap, A * A, Cap, LN, 1e-5, "stats_pb")
+            self.gemm(ap, Wa, fa, A * A, na, Cap, stats=st, bias=ba_, out_mode=OUT_BIASFRAG, T1=A, T2=A,
+                      maskadd=batch["ap_mask"], maskval=-self.inf, out_scale=LOG2E)
         Wt, bt_, nt = P.dit_bias("token")
         st = self.stats(z, T * T, Cz, LN, 1e-5, "stats_pb")
         ft = ws.get("dit_token_bias", ops.bias_frag_numel(nt, T, T), zero=True)

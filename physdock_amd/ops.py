@@ -103,6 +103,21 @@ def rownorm(x, y, M, Cdim, *, res=None, w=None, b=None, mode=RMS, eps=1e-8, act=
           "pd_rownorm")
 
 
+#: (C, H) combinations pd_pair_bias is instantiated for
+PAIR_BIAS_SHAPES = {(128, 4), (128, 8), (128, 16), (16, 4), (16, 24)}
+
+
+def pair_bias(x, Wf, frag, T1, T2, Cdim, H, *, c2=None, stats_out=None, maskadd=None, maskval=0.0, out_scale=1.0,
+              transpose=False, mode=RMS, eps=1e-8):
+    """fragment-layout attention bias of x [T1*T2, C] in one streaming pass (see pd_pair_bias); returns False when the shape
+    is not covered (the caller then uses rowstats + gemm)"""
+    if (Cdim, H) not in PAIR_BIAS_SHAPES or T2 % 4 != 0:
+        return False
+    check(_lib.init().pd_pair_bias(ptr(x), ptr(Wf), ptr(c2), ptr(stats_out), ptr(maskadd), maskval, out_scale, ptr(frag), T1, T2,
+                                   Cdim, H, int(transpose), mode, eps, stream()), "pd_pair_bias")
+    return True
+
+
 def attn_split_ws_numel(nbatch, nq, nk, nheads):
     """floats of scratch that let pd_attention split the key range of a launch too small to fill the chip (0: no split)"""
     blocks = nbatch * nheads * ((nq + 127) // 128)

@@ -114,6 +114,11 @@ class PackedWeights:
             return (torch.cat([Wa, Wb], 0).contiguous(), torch.cat([ba, bb]).contiguous())
         return self._c(("triqk", prefix), mk)
 
+    def bias_w(self, prefix, norm_name):
+        """linear_z weights of an attention with the gain of the norm in front folded in: Wf[h][k] = w[k] W[h][k]"""
+        return self._c(("biasw", prefix, norm_name), lambda: (
+            self.p[prefix + ".linear_z.weight"] * self.p[f"{prefix}.{norm_name}.weight"][None, :]).contiguous())
+
     def relpos_T(self):
         name = "diffusion_conditioning.token_embedder.rel_pos_embedder.linear.weight"
         return self._c(("relposT",), lambda: self.p[name].t().contiguous())

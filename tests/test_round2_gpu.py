@@ -307,3 +307,38 @@ def test_driver_uses_the_device_chirality_mask(small):
     assert not (flipped.accept(x) & mask).any()
     out2 = driver.redock(model, dbatch, chirality=ChiralityReference(centres + centres, [1, -1], "cuda"), **kw)   # unsatisfiable
     assert [r["accepted"] for r in out2["rounds"]] == [0, 0] and out2["gamma_factor"] == pytest.approx(max(max(6.0 * 0.7, 1.0) * 0.7, 1.0))
+
+
+# ------------------------------------------------------------------ pd_pair_bias: one-pass stats + projection + fragment store
+@pytest.mark.parametrize("C,H,T1,T2,transpose,mode", [(128, 4, 96, 96, False, 0), (128, 4, 96, 96, True, 0), (128, 8, 40, 72, False, 0),
+                                                      (128, 16, 70, 68, False, 0), (16, 4, 200, 200, False, 0),
+                                                      (16, 24, 130, 132, False, 1), (128, 4, 260, 260, True, 0)])
+def test_pair_bias_kernel(C, H, T1, T2, transpose, mode):
+    """attentions.py:38-41,200-203,246,254: bias = linear_z(norm(z)) + mask, against torch; the by-product statistics
+    against pd_rowstats' definition"""
+    import torch.nn.functional as F
+    from physdock_amd import ops
+    gen = torch.Generator().manual_seed(C + H + T1)
+    x = torch.randn(T1 * T2, C, generator=gen) * torch.exp(0.5 * torch.randn(T1 * T2, 1, generator=gen)) + 0.2
+    w = 1 + 0.1 * torch.randn(C, generator=gen); b = 0.1 * torch.randn(C, generator=gen) if mode else None
+    W = torch.randn(H, C, generator=gen) / C ** 0.5
+    mask = (torch.rand(T1 * T2, generator=gen) > 0.1).float()
+    eps = 1e-5 if mode else 1e-8
+    xn = F.layer_norm(x, (C,), w, b, eps) if mode else x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps) * w
+    dense = (xn @ W.T + (1 - mask)[:, None] * -1e9).reshape(T1, T2, H).permute(2, 0, 1)       # [H, i, j]
+    if transpose:
+        dense = dense.transpose(1, 2)                                                           # query = j, key = i
+    ref = ops.bias_to_frag(dense.contiguous())
+    Wf = (W * w[None]).contiguous().cuda()
+    c2 = (W @ b).contiguous().cuda() if mode else None
+    xd, md = x.cuda(), mask.cuda()
+    frag = torch.zeros(ref.numel(), device="cuda")
+    st = torch.empty(T1 * T2, 2, device="cuda")
+    assert ops.pair_bias(xd, Wf, frag, T1, T2, C, H, c2=c2, stats_out=st, maskadd=md, maskval=-1e9,
+                         out_scale=ops._lib.LOG2E, transpose=transpose, mode=mode, eps=eps)
+    live = ref.abs() < 1e8                                       # masked entries: -1e9 * log2e, compare separately
+    torch.testing.assert_close(frag.cpu()[live], ref[live], atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(frag.cpu()[~live], ref[~live], rtol=1e-6, atol=0)
+    st2 = torch.empty(T1 * T2, 2, device="cuda")
+    ops.rowstats(xd, st2, T1 * T2, C, mode=mode, eps=eps)
+    torch.testing.assert_close(st, st2, atol=1e-6, rtol=1e-5)
