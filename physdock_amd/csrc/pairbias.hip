@@ -48,33 +48,43 @@ __global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict_
     const int nqt = (nq + 31) >> 5, nkt = (nk + 31) >> 5;
     for (long long t = (long long)blockIdx.x * 4 + wave; t < ntile; t += (long long)gridDim.x * 4) {
         const long long m0 = t * 64;
-#pragma unroll 4
-        for (int q = 0; q < NI; ++q) {
-            // C = 128: half 0 takes rows 0..31 of the tile, half 1 rows 32..63 (two contiguous 512-byte reads per instruction);
-            // C = 16: 16 consecutive rows per instruction
-            const int r = LPR == 32 ? q + 32 * grp : q * RPI + grp;
-            const long long row = m0 + r;
-            const bool ok = row < M;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(x + row * C + 4 * sub);
-            float mean = 0.f, rstd;
-            if (mode == 0) {
-                const float s2 = group_sum<LPR>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-                rstd = rsqrtf(s2 / (float)C + eps);
-            } else {
-                mean = group_sum<LPR>(v[0] + v[1] + v[2] + v[3]) / (float)C;
+        constexpr int UB = NI < 8 ? NI : 8;          // rows in flight per lane: UB independent 16-byte loads before any use
+        for (int q0 = 0; q0 < NI; q0 += UB) {
+            f32x4 vv[UB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] -= mean;
-                const float s2 = group_sum<LPR>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
-                rstd = rsqrtf(s2 / (float)C + eps);
+            for (int u = 0; u < UB; ++u) {
+                const int r = LPR == 32 ? (q0 + u) + 32 * grp : (q0 + u) * RPI + grp;
+                const long long row = m0 + r;
+                vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < M) vv[u] = *reinterpret_cast<const f32x4*>(x + row * C + 4 * sub);
             }
-            const float madd = (ok && maskadd && maskadd[row] == 0.f) ? maskval : 0.f;
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const float d = group_sum<LPR>(v[0] * w[h][0] + v[1] * w[h][1] + v[2] * w[h][2] + v[3] * w[h][3]);
-                if (sub == h % LPR) tile[wave][r][h] = ((d * rstd + cb[h]) + madd) * out_scale;      // spread the LDS writes over lanes
+            for (int u = 0; u < UB; ++u) {
+                // C = 128: half 0 takes rows 0..31 of the tile, half 1 rows 32..63 (two contiguous 512-byte reads per
+                // instruction); C = 16: 16 consecutive rows per instruction
+                const int r = LPR == 32 ? (q0 + u) + 32 * grp : (q0 + u) * RPI + grp;
+                const long long row = m0 + r;
+                const bool ok = row < M;
+                f32x4 v = vv[u];
+                float mean = 0.f, rstd;
+                if (mode == 0) {
+                    const float s2 = group_sum<LPR>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+                    rstd = rsqrtf(s2 / (float)C + eps);
+                } else {
+                    mean = group_sum<LPR>(v[0] + v[1] + v[2] + v[3]) / (float)C;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] -= mean;
+                    const float s2 = group_sum<LPR>(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+                    rstd = rsqrtf(s2 / (float)C + eps);
+                }
+                const float madd = (ok && maskadd && maskadd[row] == 0.f) ? maskval : 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const float d = group_sum<LPR>(v[0] * w[h][0] + v[1] * w[h][1] + v[2] * w[h][2] + v[3] * w[h][3]);
+                    if (sub == h % LPR) tile[wave][r][h] = ((d * rstd + cb[h]) + madd) * out_scale;   // spread the LDS writes over lanes
+                }
+                if (ok && stats && sub == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
             }
-            if (ok && stats && sub == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);          // this wave's LDS writes have landed (the tile is private to the wave)
         asm volatile("" ::: "memory");

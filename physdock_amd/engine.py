@@ -99,7 +99,7 @@ class Engine:
         P = self.P
         W, _, H, K, ldw = P.linear(prefix + ".linear_z")
         if ops.pair_bias(z, P.bias_w(prefix, norm), out, T1, T2, C, H, stats_out=st_out, maskadd=mask, maskval=-self.inf,
-                         out_scale=LOG2E, transpose=transpose, mode=RMS, eps=self.eps):
+                         out_scale=LOG2E, transpose=transpose, mode=RMS, eps=self.eps, only_if_faster=True):
             return H
         st = st_out if st_out is not None else self.ws.get(f"stats_pb@{self.lane}", T1 * T2, 2)
         ops.rowstats(z, st, T1 * T2, C, mode=RMS, eps=self.eps)
@@ -357,7 +357,8 @@ class Engine:
         Wa, ba_, na = P.dit_bias("atom")                  # [2*nb_atom*H, Cap] with LN affine folded
         fa = ws.get("dit_atom_bias", ops.bias_frag_numel(na, A, A), zero=True)
         if not (Wa.shape[1] == Cap and ops.pair_bias(ap, Wa, fa, A, A, Cap, na, c2=ba_, maskadd=batch["ap_mask"],
-                                                      maskval=-self.inf, out_scale=LOG2E, mode=LN, eps=1e-5)):
+                                                      maskval=-self.inf, out_scale=LOG2E, mode=LN, eps=1e-5,
+                                                      only_if_faster=True)):
             st = self.stats(ap, A * A, Cap, LN, 1e-5, "stats_pb")
             self.gemm(ap, Wa, fa, A * A, na, Cap, stats=st, bias=ba_, out_mode=OUT_BIASFRAG, T1=A, T2=A,
                       maskadd=batch["ap_mask"], maskval=-self.inf, out_scale=LOG2E)

@@ -103,15 +103,18 @@ def rownorm(x, y, M, Cdim, *, res=None, w=None, b=None, mode=RMS, eps=1e-8, act=
           "pd_rownorm")
 
 
-#: (C, H) combinations pd_pair_bias is instantiated for
+#: (C, H) combinations pd_pair_bias is instantiated for, and the ones where it beats rowstats + GEMM on MI355X
+#: (tools/kbench.py --pair-bias: z H=4 21 vs 26 us; ap H=4 98 vs 547 us, H=24 330 vs 640 us; z H=16 44 vs 28 us - the 32-lane
+#: DPP reduction per head is the cost, so the wide-head z biases stay on the GEMM)
 PAIR_BIAS_SHAPES = {(128, 4), (128, 8), (128, 16), (16, 4), (16, 24)}
+PAIR_BIAS_FASTER = {(128, 4), (16, 4), (16, 24)}
 
 
 def pair_bias(x, Wf, frag, T1, T2, Cdim, H, *, c2=None, stats_out=None, maskadd=None, maskval=0.0, out_scale=1.0,
-              transpose=False, mode=RMS, eps=1e-8):
+              transpose=False, mode=RMS, eps=1e-8, only_if_faster=False):
     """fragment-layout attention bias of x [T1*T2, C] in one streaming pass (see pd_pair_bias); returns False when the shape
-    is not covered (the caller then uses rowstats + gemm)"""
-    if (Cdim, H) not in PAIR_BIAS_SHAPES or T2 % 4 != 0:
+    is not covered - or, with only_if_faster, not a win - (the caller then uses rowstats + gemm)"""
+    if (Cdim, H) not in (PAIR_BIAS_FASTER if only_if_faster else PAIR_BIAS_SHAPES) or T2 % 4 != 0:
         return False
     check(_lib.init().pd_pair_bias(ptr(x), ptr(Wf), ptr(c2), ptr(stats_out), ptr(maskadd), maskval, out_scale, ptr(frag), T1, T2,
                                    Cdim, H, int(transpose), mode, eps, stream()), "pd_pair_bias")

@@ -57,5 +57,25 @@ def main():
               f"   (bf16x6 no bias: {t0*1e6:9.1f} us {fl/t0/1e12:7.1f} TF)")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--pair-bias" not in sys.argv:
     main()
+
+
+def bench_pair_bias():
+    import torch
+    from physdock_amd import ops
+    for (C, H, T, tag) in [(128, 4, 256, "z tri"), (128, 16, 256, "z single"), (16, 4, 2048, "ap trunk"), (16, 24, 2048, "ap dit")]:
+        M = T * T
+        x = torch.randn(M, C, device="cuda"); Wf = torch.randn(H, C, device="cuda"); mask = torch.ones(M, device="cuda")
+        frag = torch.zeros(ops.bias_frag_numel(H, T, T), device="cuda"); st = torch.empty(M, 2, device="cuda")
+        t = timeit(lambda: ops.pair_bias(x, Wf, frag, T, T, C, H, stats_out=st, maskadd=mask, maskval=-1e9))
+        Wp = torch.zeros(H, (C + 3) // 4 * 4, device="cuda"); Wp[:, :C] = Wf
+        def old():
+            ops.rowstats(x, st, M, C)
+            ops.gemm(x, Wp, frag, M, H, C, stats=st, out_mode=ops.OUT_BIASFRAG, T1=T, T2=T, maskadd=mask, maskval=-1e9)
+        t0 = timeit(old)
+        print(f"pair_bias {tag:9s} C={C:3d} H={H:2d} M={M}: {t*1e6:8.1f} us ({M*C*4/t/1e12:5.2f} TB/s read) | rowstats + gemm {t0*1e6:8.1f} us")
+
+
+if __name__ == "__main__" and "--pair-bias" in sys.argv:
+    bench_pair_bias()
