@@ -519,6 +519,7 @@ int dispatch(int op, int cfg, bool akm, bool wkm, bool vec, int pro, const pd_ge
     PD_CASE(3, 64, 64, 2, 2, false, false, true, 1)
     PD_CASE(3, 64, 64, 2, 2, false, false, true, 2)
     PD_CASE(3, 64, 64, 2, 2, false, false, false, 0)
+    PD_CASE(3, 64, 64, 2, 2, true, true, true, 0)        // k-major x k-major on small tiles: the column-variant triangle einsum
 #undef PD_CASE
     return PD_ERR_UNSUPPORTED;
 }
@@ -586,7 +587,8 @@ static int select_variant(pd_gemm_args& p, int& cfg, bool& akm, bool& wkm, bool&
     if (wkm && !akm) return PD_ERR_UNSUPPORTED;
     if (!vec && p.glu) return PD_ERR_UNSUPPORTED;
     const long long blocks128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
-    if (akm || wkm || p.glu) cfg = 0;
+    if (akm && wkm && !p.glu && pro == 0 && blocks128 < 192) cfg = 3;     // 32 batches of 256^3: 128 blocks of 128x128 leave half the chip idle
+    else if (akm || wkm || p.glu) cfg = 0;
     else if (!vec) cfg = 3;
     else if (p.N <= 32) cfg = 2;
     else if (blocks128 < 192) cfg = 3;
