@@ -138,6 +138,10 @@ int pd_attention_variant(const pd_attn_args* args);
  * pd_axpby          : out = a*sa + b*(sb_ptr ? sb_ptr[0]*sb : sb)
  * pd_template_mask  : z_mask * templ_feat[...,D-1] * same_chain        (diffusion_conditioning.py:41-42)
  * Index tensors keep the loader's dtypes: int64 (uid, a2t, residue_index) / int32 (asym, sym, entity). */
+/* pd_atom_pair_ffn  : ap += W2 . (silu(W1 ap) * (W3 ap)) in one pass, c_ap = 16 / hidden = 128 only (other shapes:
+ *                      PD_ERR_UNSUPPORTED, use two pd_gemm)         (diffusion_conditioning.py:125-126, feed_forward.py:26-31) */
+int pd_atom_pair_ffn(float* ap, const float* W1, const float* W3, const float* W2, long long rows, int c_ap, int hidden,
+                     void* stream);
 int pd_atom_pair_init(const float* pos, const long long* uid, const float* cl, const float* cm, const float* Wp,
                       const float* Wd, const float* Wv, float* ap, int A, int c_ap, void* stream);
 int pd_pair_gather_add(float* ap, const float* zt, const long long* a2t, int A, int T, int c_ap, void* stream);

@@ -126,6 +126,7 @@ def _declare(L):
     sig("pd_graph_destroy", p)
     ull = C.c_ulonglong
     sig("pd_atom_pair_init", p, p, p, p, p, p, p, p, i, i, p)
+    sig("pd_atom_pair_ffn", p, p, p, p, ll, i, i, p)
     sig("pd_pair_gather_add", p, p, p, i, i, i, p)
     sig("pd_pair_init_z", p, p, p, p, p, p, p, p, p, p, p, i, i, p)
     sig("pd_segment_pool", p, p, p, p, i, i, i, i, p)

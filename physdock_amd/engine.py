@@ -221,15 +221,21 @@ class Engine:
             ops.ptr(batch["ref_pos"]), ops.ptr(batch["ref_space_uid"]), ops.ptr(cl), ops.ptr(cm),
             ops.ptr(P[ae + ".linear_p.weight"]), ops.ptr(P[ae + ".linear_d.weight"]), ops.ptr(P[ae + ".linear_v.weight"]),
             ops.ptr(ap), A, Cap, ops.stream()), "pd_atom_pair_init")
-        # ap += FFN(ap) (no norm), chunked over rows so the hidden tile stays cache-sized
+        # ap += FFN(ap) (no norm): one fused pass for the model's shapes (c_ap = 16 -> 128 -> 16); otherwise two GEMMs,
+        # chunked over rows so that the hidden tile stays cache-sized
         W13, hidden = P.glu(ae + ".ffn")
-        W2, _, _, _, ldw2 = P.linear(ae + ".ffn.w2")
-        chunk = min(A * A, 1 << 20)
-        h = ws.get("ap_ffn_h", chunk, hidden)
-        for r0 in range(0, A * A, chunk):
-            rows = min(chunk, A * A - r0)
-            self.gemm(off(ap, r0 * Cap), W13, h, rows, 2 * hidden, Cap, glu=1)
-            self.gemm(h, W2, off(ap, r0 * Cap), rows, Cap, hidden, ldw=ldw2, res=off(ap, r0 * Cap), ldres=Cap)
+        rc = ops._lib.init().pd_atom_pair_ffn(ops.ptr(ap), ops.ptr(P[ae + ".ffn.w1.weight"]), ops.ptr(P[ae + ".ffn.w3.weight"]),
+                                              ops.ptr(P[ae + ".ffn.w2.weight"]), A * A, Cap, hidden, ops.stream())
+        if rc == -3:         # PD_ERR_UNSUPPORTED: shapes outside the fused kernel
+            W2, _, _, _, ldw2 = P.linear(ae + ".ffn.w2")
+            chunk = min(A * A, 1 << 20)
+            h = ws.get("ap_ffn_h", chunk, hidden)
+            for r0 in range(0, A * A, chunk):
+                rows = min(chunk, A * A - r0)
+                self.gemm(off(ap, r0 * Cap), W13, h, rows, 2 * hidden, Cap, glu=1)
+                self.gemm(h, W2, off(ap, r0 * Cap), rows, Cap, hidden, ldw=ldw2, res=off(ap, r0 * Cap), ldres=Cap)
+        else:
+            ops.check(rc, "pd_atom_pair_ffn")
         Ha = Ca // 32
         abias = ws.get("atom_bias", ops.bias_frag_numel(Ha, A, A), zero=True)
         for b in range(dc.no_blocks_atom):

@@ -342,3 +342,20 @@ def test_pair_bias_kernel(C, H, T1, T2, transpose, mode):
     st2 = torch.empty(T1 * T2, 2, device="cuda")
     ops.rowstats(xd, st2, T1 * T2, C, mode=mode, eps=eps)
     torch.testing.assert_close(st, st2, atol=1e-6, rtol=1e-5)
+
+
+def test_atom_pair_ffn_fused_kernel():
+    """ap += W2 (silu(W1 ap) * (W3 ap)) (diffusion_conditioning.py:125-126) in one pass vs torch"""
+    import torch.nn.functional as F
+    from physdock_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    R = 32 * 1000 + 13                                    # ragged row count
+    ap = torch.randn(R, 16, generator=gen)
+    W1 = torch.randn(128, 16, generator=gen) / 4; W3 = torch.randn(128, 16, generator=gen) / 4
+    W2 = torch.randn(16, 128, generator=gen) / 11
+    ref = ap + (F.silu(ap @ W1.T) * (ap @ W3.T)) @ W2.T
+    apd, w1, w3, w2 = ap.cuda(), W1.cuda(), W3.cuda(), W2.cuda()
+    ops.check(ops._lib.init().pd_atom_pair_ffn(ops.ptr(apd), ops.ptr(w1), ops.ptr(w3), ops.ptr(w2), R, 16, 128, ops.stream()),
+              "pd_atom_pair_ffn")
+    torch.testing.assert_close(apd.cpu(), ref, atol=2e-5, rtol=1e-4)
+    assert ops._lib.init().pd_atom_pair_ffn(ops.ptr(apd), ops.ptr(w1), ops.ptr(w3), ops.ptr(w2), R, 8, 128, ops.stream()) == -3
