@@ -274,7 +274,7 @@ int dispatch_split(int op, int pro, int epi, int tile, const pd_gemm_args* p, hi
 #define PD_SCASE(P, E, C, TL) if (pro == P && epi == E && tile == C) return run_split<P, E, TL>(op, p, s);
     PD_SCASE(0, EPI_PLAIN, 128, S128) PD_SCASE(1, EPI_PLAIN, 128, S128)
     PD_SCASE(1, EPI_HN, 128, S128) PD_SCASE(2, EPI_HN, 128, S128)
-    PD_SCASE(1, EPI_GLU, 128, S128G) PD_SCASE(2, EPI_GLU, 128, S128G)
+    PD_SCASE(1, EPI_GLU, 128, S128G) PD_SCASE(2, EPI_GLU, 128, S128G) PD_SCASE(1, EPI_GLUT, 128, S128G)
     PD_SCASE(0, EPI_GATERES, 128, S128) PD_SCASE(0, EPI_TGATERES, 128, S128)
     PD_SCASE(0, EPI_PLAIN, 64, S64) PD_SCASE(1, EPI_PLAIN, 64, S64)
     PD_SCASE(1, EPI_HN, 64, S64) PD_SCASE(2, EPI_HN, 64, S64)
@@ -297,7 +297,7 @@ extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, vo
         int rc = PD_OK;
         for (int T : {128, 64, 12864})
             for (int P = 0; P < 3; ++P)
-                for (int E = 0; E < 5; ++E) {
+                for (int E = 0; E < 6; ++E) {
                     const int r = dispatch_split(1, P, E, T, nullptr, nullptr);
                     if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
                 }
@@ -314,15 +314,18 @@ extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, vo
 #endif
     if (tile != 128 && tile != 64 && tile != 12864) return PD_ERR_UNSUPPORTED;
     const int tbm = tile == 64 ? 64 : 128, tbn = tile == 128 ? 128 : 64;
-    if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
+    const bool glut = p.out_mode == PD_OUT_TRANSPOSED && p.glu && !p.hn_w && !p.mul && !p.res && !p.act && !p.rowscale_acc &&
+                      !p.maskadd && p.out_scale == 1.f && p.vecY && (!p.rowscale || ((uintptr_t)p.rowscale & 15) == 0) && tile == 128;
+    if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || (p.out_mode != PD_OUT_ROWMAJOR && !glut)) return PD_ERR_UNSUPPORTED;
     if (((uintptr_t)p.W3 & 15) != 0) return PD_ERR_UNSUPPORTED;
     if (p.M % tbm != 0 || p.N % tbn != 0) return PD_ERR_UNSUPPORTED;
     // Launches that do not fill the chip are latency-bound (two block barriers per 32-k slice here, one in gemm_stream.hip):
     // measured at 1-4 samples the fp32 kernel is faster on every DiT shape, from ~256 tiles on the split kernel wins.
     if ((long long)(p.M / tbm) * (p.N / tbn) < 256) return PD_ERR_UNSUPPORTED;
-    if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
+    if (p.rowscale_acc || (p.rowscale && !glut) || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
-    if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
+    if (glut) epi = EPI_GLUT;
+    else if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
     else if (p.hn_w) epi = (p.mul || p.res || p.act) ? -1 : EPI_HN;
     else if (p.res) {
         epi = (p.mul && p.mul_rows_per_group <= 0) ? EPI_TGATERES : EPI_GATERES;

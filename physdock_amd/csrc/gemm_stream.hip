@@ -261,7 +261,7 @@ static int dispatch_stream(int op, int pro, int epi, int tile, const pd_gemm_arg
 #define PD_SCASE(P, E, C, TL) if (pro == P && epi == E && tile == C) return run_stream<P, E, TL>(op, p, s);
     PD_SCASE(0, EPI_PLAIN, 128, T128) PD_SCASE(1, EPI_PLAIN, 128, T128)
     PD_SCASE(1, EPI_HN, 128, T128) PD_SCASE(2, EPI_HN, 128, T128)
-    PD_SCASE(1, EPI_GLU, 128, T128) PD_SCASE(2, EPI_GLU, 128, T128)
+    PD_SCASE(1, EPI_GLU, 128, T128) PD_SCASE(2, EPI_GLU, 128, T128) PD_SCASE(1, EPI_GLUT, 128, T128)
     PD_SCASE(0, EPI_GATERES, 128, T128) PD_SCASE(0, EPI_TGATERES, 128, T128)
     // smaller tiles for problems that do not fill the chip with 128 x 128 ones (few samples, trunk side tracks)
     PD_SCASE(0, EPI_PLAIN, 64, T64) PD_SCASE(1, EPI_PLAIN, 64, T64)
@@ -280,7 +280,7 @@ extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, v
         int rc = PD_OK;
         for (int T : {128, 64, 12864})
             for (int P = 0; P < 3; ++P)
-                for (int E = 0; E < 5; ++E) {
+                for (int E = 0; E < 6; ++E) {
                     const int r = dispatch_stream(1, P, E, T, nullptr, nullptr);
                     if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
                 }
@@ -290,11 +290,14 @@ extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, v
     if (tile != 128 && tile != 64 && tile != 12864) return PD_ERR_UNSUPPORTED;
     int tbm, tbn;
     tile_dims(tile, tbm, tbn);
-    if (p.a_kmajor || p.w_kmajor || !p.vecA || !p.vecW || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
+    const bool glut = p.out_mode == PD_OUT_TRANSPOSED && p.glu && !p.hn_w && !p.mul && !p.res && !p.act && !p.rowscale_acc &&
+                      !p.maskadd && p.out_scale == 1.f && p.vecY && (!p.rowscale || ((uintptr_t)p.rowscale & 15) == 0) && tile == 128;
+    if (p.a_kmajor || p.w_kmajor || !p.vecA || !p.vecW || p.batch != 1 || (p.out_mode != PD_OUT_ROWMAJOR && !glut)) return PD_ERR_UNSUPPORTED;
     if (p.M % tbm != 0 || p.N % tbn != 0) return PD_ERR_UNSUPPORTED;        // full tiles only
-    if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
+    if (p.rowscale_acc || (p.rowscale && !glut) || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
-    if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
+    if (glut) epi = EPI_GLUT;
+    else if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
     else if (p.hn_w) epi = (p.mul || p.res || p.act) ? -1 : EPI_HN;
     else if (p.res) {
         epi = (p.mul && p.mul_rows_per_group <= 0) ? EPI_TGATERES : EPI_GATERES;

@@ -20,7 +20,9 @@ namespace {
 //   GLU     : Y = silu(a + ba) * (b + bb)  |  (a + ba) * sigmoid(b + bb)   on packed column pairs
 //   GATERES : Y = (acc + bias) * gate[row group] + res          (gate optional; res may alias Y)
 //   TGATERES: Y = (acc + bias) * gate[row, col] + res           (gate tensor, e.g. the sigmoid gate of an attention)
-enum { EPI_PLAIN = 0, EPI_HN = 1, EPI_GLU = 2, EPI_GATERES = 3, EPI_TGATERES = 4 };
+//   GLUT    : GLU as above, times rowscale[row], stored TRANSPOSED  Y[col][row]   (the channel-major q | k operands of the
+//             triangle multiplication, attentions.py:161-162: four consecutive rows of one column = one 16-byte store)
+enum { EPI_PLAIN = 0, EPI_HN = 1, EPI_GLU = 2, EPI_GATERES = 3, EPI_TGATERES = 4, EPI_GLUT = 5 };
 
 // Epilogue of one block tile straight from the accumulator fragments: lane = column, register r = row
 // (r&3)+8(r>>2)+4*half.  Tiles are always full (the launcher peels ragged rows off to gemm.hip).  Addresses are
@@ -28,13 +30,28 @@ enum { EPI_PLAIN = 0, EPI_HN = 1, EPI_GLU = 2, EPI_GATERES = 3, EPI_TGATERES = 4
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&acc)[TM][TN], const float (&c0)[TN],
                                          const float (&c1)[TN], int bm0, int bn0, int wm, int wn, int l31, int hh) {
-    static_assert(EPI != EPI_GLU || TN == 2, "a GLU pair needs both column fragments in one wave");
+    static_assert((EPI != EPI_GLU && EPI != EPI_GLUT) || TN == 2, "a GLU pair needs both column fragments in one wave");
     const int ldy = p.ldy, ldres = p.ldres, ldmul = p.ldmul;
     const int yoff = hh * 4 * ldy + l31;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mb = bm0 + wm * (32 * TM) + i * 32;
-        if constexpr (EPI == EPI_GLU) {
+        if constexpr (EPI == EPI_GLUT) {
+            // output column n = packed column pair index; rows of register group g: mb + 8 g + 4 hh + (0..3)
+            float* __restrict__ Yo = p.Y + (long long)(((bn0 + wn * (32 * TN)) >> 1) + l31) * ldy + mb + 4 * hh;
+            const float* __restrict__ rs = p.rowscale + mb + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sc = p.rowscale ? *reinterpret_cast<const f32x4*>(rs + 8 * g) : f32x4{1.f, 1.f, 1.f, 1.f};
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = acc[i][0][4 * g + e] + c0[0], b = acc[i][TN - 1][4 * g + e] + c0[TN - 1];
+                    o[e] = (p.glu == 1 ? pd_silu(a) * b : a * pd_sigmoid(b)) * sc[e];
+                }
+                *reinterpret_cast<f32x4*>(Yo + 8 * g) = o;
+            }
+        } else if constexpr (EPI == EPI_GLU) {
             float* __restrict__ Yo = p.Y + (long long)mb * ldy + ((bn0 + wn * (32 * TN)) >> 1);
             if (p.glu == 1) {
 #pragma unroll

@@ -68,12 +68,14 @@ __global__ __launch_bounds__(256) void pair_init_z_kernel(const float* __restric
     for (int i = threadIdx.x; i < 42 * CZ; i += blockDim.x) sW[i] = WT[66 * CZ + i];
     __syncthreads();
     const int i = blockIdx.x;
+    const int jchunk = (T + gridDim.y - 1) / gridDim.y;      // the keys of a row are split over blockIdx.y (more blocks than CUs)
+    const int jend = (blockIdx.y + 1) * jchunk < T ? (blockIdx.y + 1) * jchunk : T;
     const int ai = asym[i], si_ = sym[i], ei = ent[i];
     const long long ri = res[i];
     for (int c = threadIdx.x; c < CZ; c += blockDim.x) {
         const float base = si[(long long)i * CZ + c];
         const float wbc = wb[c];
-        for (int j = 0; j < T; ++j) {
+        for (int j = blockIdx.y * jchunk; j < jend; ++j) {
             const bool chain_same = ai == asym[j], ent_same = ei == ent[j];
             long long dr = ri - res[j] + 32;
             dr = dr < 0 ? 0 : (dr > 64 ? 64 : dr);
@@ -200,7 +202,7 @@ PD_EXPORT int pd_pair_init_z(const float* si, const float* sj, const float* WT, 
                              const float* bonds, float* z, int T, int CZ, void* stream) {
     if (!si || !sj || !WT || !z || T <= 0) return PD_ERR_ARG;
     const int threads = CZ < 256 ? ((CZ + 63) / 64) * 64 : 256;
-    hipLaunchKernelGGL(pair_init_z_kernel, dim3(T), dim3(threads), 42 * CZ * sizeof(float), (hipStream_t)stream, si, sj,
+    hipLaunchKernelGGL(pair_init_z_kernel, dim3(T, T >= 64 ? 16 : 1), dim3(threads), 42 * CZ * sizeof(float), (hipStream_t)stream, si, sj,
                        WT, wb, asym, sym, ent, res, rel_tok_feat, bonds, z, T, CZ);
     return pd_check_launch();
 }

@@ -64,7 +64,8 @@ class Engine:
         contractions (raw addresses, k-major / batched operands) stay on the fp32 MFMA."""
         w3 = None
         if isinstance(W, torch.Tensor) and W.dim() == 2 and W.shape[0] == N and K % 4 == 0 and kw.get("batch", 1) == 1 \
-                and not kw.get("a_kmajor") and not kw.get("w_kmajor") and kw.get("out_mode", 0) == 0 and N % 64 == 0:
+                and not kw.get("a_kmajor") and not kw.get("w_kmajor") and N % 64 == 0 \
+                and (kw.get("out_mode", 0) == 0 or (kw.get("out_mode") == OUT_TRANSPOSED and kw.get("glu"))):
             w3 = self.P.w3(W, K)
         ops.gemm(A, W, Y, M, N, K, W3=w3, **kw)
 

@@ -145,3 +145,35 @@ def test_split_multi_tile_stress():
             ops.gemm(A, W, Y1, M, N, K, W3=W3, **kw)
             bad = int(((Y0 - Y1).abs() > 1e-4 * (1 + Y0.abs())).sum())
             assert bad == 0, (M, N, K, glu, pro, rep, bad)
+
+
+@pytest.mark.parametrize("use_split", [False, True], ids=["fp32mfma", "bf16x6"])
+def test_transposed_glu_epilogue(use_split):
+    """the channel-major q | k operands of the triangle multiplication (attentions.py:161-162): norm prologue, sigmoid-gated
+    pair, mask as a row scale, TRANSPOSED store - on the persistent kernels (EPI_GLUT), both matrix pipes"""
+    import torch.nn.functional as F
+    from physdock_amd import ops
+    from physdock_amd.packing import pack_glu, split3_bf16
+    gen = torch.Generator().manual_seed(9)
+    M, K, Hd = 128 * 72, 128, 64
+    x = torch.randn(M, K, generator=gen) + 0.1
+    Wa = torch.randn(Hd, K, generator=gen) / 11; Wb = torch.randn(Hd, K, generator=gen) / 11
+    ba = torch.randn(Hd, generator=gen); bb = torch.randn(Hd, generator=gen)
+    w = 1 + 0.1 * torch.randn(K, generator=gen)
+    mask = (torch.rand(M, generator=gen) > 0.2).float()
+    Wp, bp = pack_glu(Wa, Wb, ba, bb)
+    xd, Wd, bd, wd, md = x.cuda(), Wp.cuda(), bp.cuda(), w.cuda(), mask.cuda()
+    st = torch.empty(M, 2, device="cuda")
+    ops.rowstats(xd, st, M, K, mode=ops.RMS, eps=1e-8)
+    Y = torch.empty(Hd, M, device="cuda")
+    seen = []
+    ops.GEMM_HOOK = lambda a, launch: (seen.append(ops._lib.init().pd_gemm_variant(C.byref(a))), launch())
+    try:
+        ops.gemm(xd, Wd, Y, M, 2 * Hd, K, stats=st, pro_w=wd, bias=bd, glu=2, rowscale=md, out_mode=ops.OUT_TRANSPOSED, ldy=M,
+                 W3=split3_bf16(Wd) if use_split else None)
+    finally:
+        ops.GEMM_HOOK = None
+    assert seen[0] % 10000 >= 5000 and (seen[0] // 10000) % 10 == 5 and (seen[0] >= 1000000) == use_split, seen
+    xn = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-8) * w
+    ref = ((xn @ Wa.T + ba) * torch.sigmoid(xn @ Wb.T + bb) * mask[:, None]).T
+    torch.testing.assert_close(Y.cpu(), ref, atol=2e-5, rtol=1e-4)
