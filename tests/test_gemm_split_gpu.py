@@ -55,8 +55,8 @@ def _run_split(split_ops, fn):
     assert main and all(v >= 1000000 for v in main), seen       # every full-tile launch went to gemm_split_kernel
 
 
-@pytest.mark.parametrize("M,N,K", [(128 * 40, 128 * 26, 100), (128 * 33, 128 * 32, 300), (128 * 70 + 37, 128 * 3, 72),
-                                   (128 * 200 + 1, 128, 128)])
+@pytest.mark.parametrize("M,N,K", [(128 * 40, 128 * 26, 100), (128 * 33, 128 * 32, 300), (128 * 90 + 37, 128 * 3, 72),
+                                   (128 * 260 + 1, 128, 128)])       # >= 256 tiles each: below that pd_gemm keeps the fp32 kernel
 def test_split_bias_act_res_gate(split_ops, M, N, K):
     _run_split(split_ops, lambda ops: tk.test_gemm_stream_bias_act_res(ops, M, N, K))
 
@@ -155,7 +155,7 @@ def test_transposed_glu_epilogue(use_split):
     from physdock_amd import ops
     from physdock_amd.packing import pack_glu, split3_bf16
     gen = torch.Generator().manual_seed(9)
-    M, K, Hd = 128 * 72, 128, 64
+    M, K, Hd = 128 * 400, 128, 64          # >= 384 row blocks: the 128 x 128 GLU tile (as the trunk's T = 256 pair tensor)
     x = torch.randn(M, K, generator=gen) + 0.1
     Wa = torch.randn(Hd, K, generator=gen) / 11; Wb = torch.randn(Hd, K, generator=gen) / 11
     ba = torch.randn(Hd, generator=gen); bb = torch.randn(Hd, generator=gen)
