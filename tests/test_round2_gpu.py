@@ -270,6 +270,7 @@ def test_chirality_kernel_on_hand_checkable_tetrahedra():
     bonds = [(0, 1), (0, 2), (0, 3), (0, 4), (5, 6), (5, 7), (5, 8), (5, 9), (4, 5)]
     centres = centres_from_bonds(10, bonds)
     assert centres == [(0, 1, 2, 3), (5, 4, 6, 7)]          # atoms with four neighbours; first three neighbours by index
+    centres = [(0, 1, 2, 3), (5, 6, 7, 8)]                  # for the handedness cases: each centre with neighbours of its own group
     cr = ChiralityReference.from_coordinates(ref.cuda(), centres)
     vol = lambda x, c: float(np.dot(x[c[1]] - x[c[0]], np.cross(x[c[2]] - x[c[0]], x[c[3]] - x[c[0]])))
     assert cr.signs.cpu().tolist() == [int(np.sign(vol(ref.numpy(), c))) for c in centres]
