@@ -14,25 +14,39 @@ def _worker(rank, world, port, num_sample, results):
     from physdock_amd.parallel import gather_poses, sample_diffusion_parallel, shard_range
 
     class FakeModel:     # stands in for the GPU sampler: pose b is filled with its GLOBAL sample id
-        def sample_diffusion(self, batch, num_sample, sample_offset=0, **kw):
+        def sample_diffusion(self, batch, num_sample, sample_offset=0, noise=None, **kw):
+            assert num_sample > 0, "a rank without samples must not call the sampler"
             ids = torch.arange(sample_offset, sample_offset + num_sample, dtype=torch.float32)
-            return ids[:, None, None].expand(num_sample, 5, 3).contiguous()
+            x = ids[:, None, None].expand(num_sample, 5, 3).contiguous()
+            if noise is not None:       # parity mode: the rank must have been handed ITS block of the caller's draws
+                assert noise["init"].shape[0] == num_sample and noise["rot_u"].shape[2] == num_sample
+                assert noise["trans"].shape[1] == num_sample and noise["diffuse"].shape[1] == num_sample
+                x = x + 1000.0 * noise["init"][:, :1, :1]
+            return x
 
     lo, hi = shard_range(num_sample, rank, world)
     x = FakeModel().sample_diffusion(None, hi - lo, sample_offset=lo)
     full = gather_poses(x, num_sample)
     full2 = sample_diffusion_parallel(FakeModel(), None, num_sample)
+    # more ranks than samples: rank 1 holds an empty block and still takes part in the gather
+    one = sample_diffusion_parallel(FakeModel(), {"x_gt": torch.zeros(5, 3)}, 1)
+    # sharded parity noise: sample b carries init[b] = b, so the gathered poses are (1001 b) if every rank sliced correctly
+    nz = {"init": torch.arange(num_sample, dtype=torch.float32)[:, None, None].expand(num_sample, 5, 3).contiguous(),
+          "rot_u": torch.zeros(3, 4, num_sample), "trans": torch.zeros(3, num_sample, 3), "diffuse": torch.zeros(2, num_sample, 5, 3)}
+    full3 = sample_diffusion_parallel(FakeModel(), None, num_sample, noise=nz)
     from physdock_amd.parallel import map_systems
     systems = list(range(11))
     res = map_systems(lambda s: {"system": s, "rank": rank, "score": s * s}, systems)
     res_c = map_systems(lambda s: (s, rank), systems, costs=[1, 9, 1, 1, 1, 1, 1, 1, 1, 1, 5])
     if rank == 0:
         ok = torch.equal(full[:, 0, 0], torch.arange(num_sample, dtype=torch.float32)) and torch.equal(full, full2)
+        ok = ok and one.shape == (1, 5, 3) and float(one[0, 0, 0]) == 0.0
+        ok = ok and torch.equal(full3[:, 0, 0], 1001.0 * torch.arange(num_sample, dtype=torch.float32))
         ok = ok and [r["system"] for r in res] == systems and [r["rank"] for r in res] == [i % world for i in systems]
         ok = ok and [r[0] for r in res_c] == systems and res_c[1][1] != res_c[10][1]       # the two heavy systems are split
         results.put(bool(ok))
     else:
-        assert full is None and full2 is None and res is None and res_c is None
+        assert full is None and full2 is None and one is None and full3 is None and res is None and res_c is None
     dist.barrier()
     dist.destroy_process_group()
 
