@@ -153,6 +153,11 @@ int pd_segment_pool(const float* u, const int* tok_start, const float* add, floa
 int pd_unpool_add(float* ba, const float* us, const long long* a2t, int B, int A, int T, int C, void* stream);
 int pd_gather_rows_add(float* y, const float* x, const long long* idx, int R, int C, void* stream);
 int pd_axpby(float* out, const float* a, float sa, const float* b, const float* sb_ptr, float sb, long long n, void* stream);
+/* pd_template_feat  : templ_feat [T,T,no_bins+1] = [distogram bins of the pseudo-beta distance | mask] * mask, mask = z_mask *
+ *                      protein_i * protein_j (feature_loader.py:944-968 inference branch; tensor_utils.py:689-703); lower =
+ *                      the no_bins fp32 bin edges linspace(3.25, 50.75, no_bins)^2 computed by the host (slice) */
+int pd_template_feat(const float* x, const long long* pseudo_beta_atom, const float* z_mask, const float* is_protein,
+                     const float* lower, float* out, int T, int no_bins, void* stream);
 int pd_template_mask(const float* z_mask, const float* templ_feat, const int* asym, float* out, int T, int D, void* stream);
 
 /* ---- per-step sampler kernels (sampler.hip) ------------------------------------------------

@@ -172,7 +172,40 @@ __global__ __launch_bounds__(256) void template_mask_kernel(const float* __restr
     out[idx] = z_mask[idx] * templ[idx * D + (D - 1)] * (asym[i] == asym[j] ? 1.f : 0.f);
 }
 
+// templ_feat[i,j,:] = [ 39-bin distogram of the pseudo-beta distance | mask ], mask = z_mask * protein_i * protein_j
+// (feature_loader.py:944-968 get_template_feat, inference branch; utils/tensor_utils.py:689-703 dgram_from_positions:
+// bin b is set when lower[b] < d^2 < upper[b], both strict, lower = linspace(3.25, 50.75, 39)^2 supplied by the host so that
+// the boundaries are the reference's own fp32 values; d^2 = (dx^2 + dy^2) + dz^2 without fused multiply-adds)
+__global__ __launch_bounds__(256) void template_feat_kernel(const float* __restrict__ x, const long long* __restrict__ pb,
+                                                           const float* __restrict__ z_mask, const float* __restrict__ is_prot,
+                                                           const float* __restrict__ lower, float* __restrict__ out, int T,
+                                                           int NB, float inf) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)T * T) return;
+    const int i = (int)(idx / T), j = (int)(idx - (long long)i * T);
+    const long long ai = pb[i], aj = pb[j];
+    const float dx = x[3 * ai] - x[3 * aj], dy = x[3 * ai + 1] - x[3 * aj + 1], dz = x[3 * ai + 2] - x[3 * aj + 2];
+    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    const float m = z_mask[idx] * (is_prot[i] * is_prot[j]);
+    float* o = out + idx * (NB + 1);
+    for (int b = 0; b < NB; ++b) {
+        const float up = b + 1 < NB ? lower[b + 1] : inf;
+        const float bit = (d2 > lower[b] && d2 < up) ? 1.f : 0.f;
+        o[b] = bit * m;
+    }
+    o[NB] = m;
+}
+
 }  // namespace
+
+PD_EXPORT int pd_template_feat(const float* x, const long long* pseudo_beta_atom, const float* z_mask, const float* is_protein,
+                               const float* lower, float* out, int T, int no_bins, void* stream) {
+    if (!x || !pseudo_beta_atom || !z_mask || !is_protein || !lower || !out || T <= 0 || no_bins <= 0) return PD_ERR_ARG;
+    const long long n = (long long)T * T;
+    hipLaunchKernelGGL(template_feat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       pseudo_beta_atom, z_mask, is_protein, lower, out, T, no_bins, 1e8f);
+    return pd_check_launch();
+}
 
 PD_EXPORT int pd_atom_pair_init(const float* pos, const long long* uid, const float* cl, const float* cm,
                                 const float* Wp, const float* Wd, const float* Wv, float* ap, int A, int c_ap, void* stream) {

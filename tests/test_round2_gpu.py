@@ -360,3 +360,15 @@ def test_atom_pair_ffn_fused_kernel():
               "pd_atom_pair_ffn")
     torch.testing.assert_close(apd.cpu(), ref, atol=2e-5, rtol=1e-4)
     assert ops._lib.init().pd_atom_pair_ffn(ops.ptr(apd), ops.ptr(w1), ops.ptr(w3), ops.ptr(w2), R, 8, 128, ops.stream()) == -3
+
+
+# ------------------------------------------------------------------ 8f row 3, first slice: template features on the device
+def test_template_feat_kernel_vs_reference_fixture():
+    """get_template_feat (feature_loader.py:944-968) around the reference's dgram_from_positions: 0/1 features, bit-exact"""
+    from physdock_amd.features import pair_masks, template_feat
+    g = load_golden("g11_template_feat")
+    t = pair_masks({"s_mask": g["s_mask"].cuda(), "a_mask": torch.ones(5, device="cuda")})
+    tf = template_feat(g["x_gt"].cuda(), g["token_id_to_pseudo_beta_atom_id"].cuda(), t["z_mask"], g["is_protein"].cuda())
+    assert tf.shape == g["templ_feat"].shape
+    assert torch.equal(tf.cpu(), g["templ_feat"])
+    assert float(tf[..., :39].sum(-1).max()) == 1.0 and float(tf.sum()) > 100          # one bin per live pair; not trivially empty

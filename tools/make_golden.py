@@ -78,7 +78,7 @@ def main():
     import warnings
     warnings.filterwarnings("ignore")
     ap_ = argparse.ArgumentParser()
-    ap_.add_argument("--sets", default="g1-7,g8,g9,g10")
+    ap_.add_argument("--sets", default="g1-7,g8,g9,g10,g11")
     sets = set(ap_.parse_args().sets.split(","))
     install_shims()
     os.makedirs(OUT, exist_ok=True)
@@ -109,6 +109,8 @@ def main():
         main_g9(RefPhysDock, RefConfig, ref_model_module)
     if "g10" in sets:
         main_g10()
+    if "g11" in sets:
+        main_g11(rtu)
 
 
 class Recorder:
@@ -260,6 +262,28 @@ def main_g10():
         ids = [ids_1] + ids[:4]
     npz("g10_ranking", gt=gt, preds=preds, rmsds=np.array(rmsds), dist=dist, labels5=labels5, reps5=np.array(reps5),
         medoid=ids_1, order=np.array(ids), top_rmsds=np.array([rmsds[i] for i in ids]))
+
+
+def main_g11(rtu):
+    """G11: template feature block of FeatureLoader.get_template_feat (feature_loader.py:944-968, inference branch).  The
+    loader class itself cannot be imported (RDKit, CCD metadata); its statements are executed here around the reference's
+    own `dgram_from_positions` (utils/tensor_utils.py:689-703), which IS imported."""
+    g = torch.Generator().manual_seed(17)
+    T, A = 40, 180
+    x_gt = torch.cumsum(3.8 * torch.nn.functional.normalize(torch.randn(A, 3, generator=g), dim=-1), 0)   # chain-like, distances up to ~60 A
+    pb = torch.sort(torch.randperm(A, generator=g)[:T]).values
+    s_mask = (torch.rand(T, generator=g) > 0.1).float()
+    z_mask = s_mask[None] * s_mask[:, None]
+    is_protein = (torch.arange(T) < 33).float()
+    x_pb = x_gt[pb]
+    protein2d = is_protein[None] * is_protein[:, None]
+    dgram = rtu.dgram_from_positions(x_pb, no_bins=39)
+    dgram = dgram * protein2d[..., None] * z_mask[..., None]
+    mask = z_mask * protein2d
+    dgram = dgram * mask[..., None]
+    templ_feat = torch.cat([dgram, mask[..., None]], dim=-1).float()
+    npz("g11_template_feat", x_gt=x_gt, token_id_to_pseudo_beta_atom_id=pb, s_mask=s_mask, is_protein=is_protein,
+        templ_feat=templ_feat)
 
 
 def main_g1_g7(RefPhysDock, RefConfig, rp, rt, rdc, rtu, mlc):
