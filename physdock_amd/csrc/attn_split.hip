@@ -24,6 +24,8 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KT = 64;        // keys per LDS tile
 constexpr int KP = 40;        // bf16 per K row (80 bytes)
@@ -70,12 +72,12 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
                 v0 = *reinterpret_cast<const f32x4*>(qp + 16 * s);
                 v1 = *reinterpret_cast<const f32x4*>(qp + 16 * s + 4);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 a, bq, c;
-                split1(v0[e] * qs, a, bq, c); qh[s][e] = a; qm[s][e] = bq; ql[s][e] = c;
-                split1(v1[e] * qs, a, bq, c); qh[s][4 + e] = a; qm[s][4 + e] = bq; ql[s][4 + e] = c;
-            }
+            u32x4 fh, fm, fl;
+            { const pd_parts t_ = pd_split2(v0[0] * qs, v0[1] * qs); fh[0] = t_.h; fm[0] = t_.m; fl[0] = t_.l; }
+            { const pd_parts t_ = pd_split2(v0[2] * qs, v0[3] * qs); fh[1] = t_.h; fm[1] = t_.m; fl[1] = t_.l; }
+            { const pd_parts t_ = pd_split2(v1[0] * qs, v1[1] * qs); fh[2] = t_.h; fm[2] = t_.m; fl[2] = t_.l; }
+            { const pd_parts t_ = pd_split2(v1[2] * qs, v1[3] * qs); fh[3] = t_.h; fm[3] = t_.m; fl[3] = t_.l; }
+            qh[s] = __builtin_bit_cast(bf16x8, fh); qm[s] = __builtin_bit_cast(bf16x8, fm); ql[s] = __builtin_bit_cast(bf16x8, fl);
         }
     }
 
@@ -112,23 +114,24 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             const int kr = srow + RPP * i;                         // key row inside the tile
-            bf16x4 kh, km, kl;
-            __bf16 vh[4], vm[4], vl[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 a, bq, c;
-                split1(rk[i][e], a, bq, c); kh[e] = a; km[e] = bq; kl[e] = c;
-                split1(rv[i][e], vh[e], vm[e], vl[e]);
-            }
+            u32x2 kh, km, kl, vh, vm, vl;                          // packed pairs: (e0, e1), (e2, e3)
+            { const pd_parts t_ = pd_split2(rk[i][0], rk[i][1]); kh[0] = t_.h; km[0] = t_.m; kl[0] = t_.l; }
+            { const pd_parts t_ = pd_split2(rk[i][2], rk[i][3]); kh[1] = t_.h; km[1] = t_.m; kl[1] = t_.l; }
+            { const pd_parts t_ = pd_split2(rv[i][0], rv[i][1]); vh[0] = t_.h; vm[0] = t_.m; vl[0] = t_.l; }
+            { const pd_parts t_ = pd_split2(rv[i][2], rv[i][3]); vh[1] = t_.h; vm[1] = t_.m; vl[1] = t_.l; }
             const int ko = kr * KP + 4 * sc;
-            *reinterpret_cast<bf16x4*>(sK + ko) = kh;
-            *reinterpret_cast<bf16x4*>(sK + K_PART + ko) = km;
-            *reinterpret_cast<bf16x4*>(sK + 2 * K_PART + ko) = kl;
+            *reinterpret_cast<u32x2*>(sK + ko) = kh;
+            *reinterpret_cast<u32x2*>(sK + K_PART + ko) = km;
+            *reinterpret_cast<u32x2*>(sK + 2 * K_PART + ko) = kl;
             const int vo = (kr & 32) + vpos(kr & 31);              // column of this key in the transposed tile
+            unsigned short* sV16 = reinterpret_cast<unsigned short*>(sV);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e) {                          // transposed scatter: dim 4 sc + e, column vo
                 const int ro = (4 * sc + e) * VP + vo;
-                sV[ro] = vh[e]; sV[V_PART + ro] = vm[e]; sV[2 * V_PART + ro] = vl[e];
+                const int sh = 16 * (e & 1);
+                sV16[ro] = (unsigned short)(vh[e >> 1] >> sh);
+                sV16[V_PART + ro] = (unsigned short)(vm[e >> 1] >> sh);
+                sV16[2 * V_PART + ro] = (unsigned short)(vl[e >> 1] >> sh);
             }
         }
     };
@@ -188,15 +191,15 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         // computed while the matrix pipe works on the first, and only one set of P fragments is live
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            bf16x8 ph, pm, pl;
+            u32x4 fh, fm, fl;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float pr = __builtin_amdgcn_exp2f(s[8 * st + e] - m_new);
-                psum += pr;
-                __bf16 a, bq, c;
-                split1(pr, a, bq, c);
-                ph[e] = a; pm[e] = bq; pl[e] = c;
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[8 * st + 2 * e2] - m_new);
+                const float p1 = __builtin_amdgcn_exp2f(s[8 * st + 2 * e2 + 1] - m_new);
+                psum += p0 + p1;
+                { const pd_parts t_ = pd_split2(p0, p1); fh[e2] = t_.h; fm[e2] = t_.m; fl[e2] = t_.l; }
             }
+            const bf16x8 ph = __builtin_bit_cast(bf16x8, fh), pm = __builtin_bit_cast(bf16x8, fm), pl = __builtin_bit_cast(bf16x8, fl);
             const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vbase + 16 * st);
             const bf16x8 vm = *reinterpret_cast<const bf16x8*>(vbase + V_PART + 16 * st);
             const bf16x8 vl = *reinterpret_cast<const bf16x8*>(vbase + 2 * V_PART + 16 * st);

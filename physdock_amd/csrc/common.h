@@ -75,6 +75,27 @@ __device__ __forceinline__ float pd_half_sum32(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);      // the other 16-lane row of the half
 }
 
+// Error-free 3-way bf16 split of TWO floats at a time: a = h + m + l per value, each part's pair packed in one dword
+// (low half = first value) - the form v_cvt_pk_bf16_f32 produces and the bf16 MFMA fragments consume.  Working on pairs
+// keeps it at 11 VALU operations per two values (3 packed conversions, 4 re-expansions, 4 subtractions).
+typedef float pd_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pd_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pd_cvt_pk_bf16(float a, float b) {
+    const pd_f32x2 v = {a, b};
+    const pd_bf16x2 r = __builtin_convertvector(v, pd_bf16x2);
+    return __builtin_bit_cast(unsigned, r);
+}
+struct pd_parts { unsigned h, m, l; };
+__device__ __forceinline__ pd_parts pd_split2(float a, float b) {
+    pd_parts r;
+    r.h = pd_cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(r.h << 16), rb = b - __uint_as_float(r.h & 0xffff0000u);
+    r.m = pd_cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(r.m << 16), sb = rb - __uint_as_float(r.m & 0xffff0000u);
+    r.l = pd_cvt_pk_bf16(sa, sb);
+    return r;
+}
+
 __device__ __forceinline__ int pd_frag_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 __device__ __forceinline__ float wave_sum(float v) {
