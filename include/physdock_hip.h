@@ -159,6 +159,15 @@ int pd_axpby(float* out, const float* a, float sa, const float* b, const float* 
 int pd_template_feat(const float* x, const long long* pseudo_beta_atom, const float* z_mask, const float* is_protein,
                      const float* lower, float* out, int T, int no_bins, void* stream);
 int pd_template_mask(const float* z_mask, const float* templ_feat, const int* asym, float* out, int T, int D, void* stream);
+/* ConfidenceModule entry / exit passes (confidence.hip; reference models/layers/confidence_module.py:56-88):
+ * pd_confidence_pair_init: out[i,j,:] = z[i,j,:] + si[i,:] + sj[j,:] + WdT[bin(|xc_i - xc_j|), :], xc = x[centre[.]], bin =
+ *                          nearest of linspace(3.375, 24.375, 13) (first on ties), WdT = linear_d.weight^T [13][C]   (:68-72)
+ * pd_pair_symmetrize     : out[i,j,:] = z[i,j,:] + z[j,i,:] (out != z)                                             (:75)
+ * pd_atom_dist_embed     : ap[i,j,:] = |x_i - x_j| w + b, Linear(1, c_ap)                                           (:80)     */
+int pd_confidence_pair_init(const float* z, const float* si, const float* sj, const float* WdT, const float* x,
+                            const long long* centre, float* out, int T, int C, void* stream);
+int pd_pair_symmetrize(const float* z, float* out, int T, int C, void* stream);
+int pd_atom_dist_embed(const float* x, const float* w, const float* b, float* ap, int A, int C, void* stream);
 
 /* ---- per-step sampler kernels (sampler.hip) ------------------------------------------------
  * pd_augment       : centre_random_augmentation + noise injection      (tensor_utils.py:576-586, model.py:70-85)

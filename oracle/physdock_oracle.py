@@ -338,6 +338,31 @@ def af3_dit(P, batch, x_hat, t_hat, a, ap, s, z, sigma_data=16.0, inf=1e9, eps=1
 
 
 # --------------------------------------------------------------------------- sampler
+def confidence_module(P, batch, s, z, x_pred, inf=1e9, eps=1e-8, name="confidence_module"):
+    """layers/confidence_module.py:56-88 -> p_pae [T,T,c_pae], p_pde [T,T,c_pde], p_plddt [A,c_plddt]."""
+    ctr = batch["token_id_to_centre_atom_id"]
+    a2t = batch["atom_id_to_token_id"]
+    xc = x_pred[0, ctr, :]
+    z = z + linear(P, name + ".linear_s_i", s)[..., None, :] + linear(P, name + ".linear_s_j", s)[..., None, :, :]
+    d = torch.norm(xc[..., None, :] - xc[..., None, :, :], dim=-1, keepdim=True)
+    v_bins = torch.linspace(3.375, 24.375, 13).type(z.dtype)
+    b = torch.argmin(torch.abs(d[..., None] - v_bins), dim=-1)              # utils/tensor_utils.py:673-686
+    onehot = torch.zeros(d.shape[:-1] + (13,), dtype=z.dtype).scatter_(-1, b, 1)
+    z = z + linear(P, name + ".linear_d", onehot)
+    for blk in range(_nblocks(P, name + ".pairformer.blocks")):
+        s, z = pairformer_block(P, f"{name}.pairformer.blocks.{blk}", s, z, batch["z_mask"], inf, eps)
+    z = z + z.transpose(-2, -3)
+    p_pae = linear(P, name + ".linear_pae", z)
+    p_pde = linear(P, name + ".linear_pde", z)
+    a = linear(P, name + ".linear_s_a", s)[a2t]
+    ap = linear(P, name + ".linear_z_a", torch.norm(x_pred[0][None] - x_pred[0][:, None], dim=-1)[..., None])
+    a1 = a
+    for blk in range(_nblocks(P, name + ".atom_transformer.blocks")):
+        a1 = atom_block(P, f"{name}.atom_transformer.blocks.{blk}", a1, ap, batch["ap_mask"], inf, eps)
+    a = a + a1
+    return p_pae, p_pde, linear(P, name + ".linear_plddt", a)
+
+
 def karras_noise_schedule(num_steps=200, sigma_data=16, s_max=160, s_min=4 * 10e-4, p=7):
     """models/model.py:117-129, same torch fp32 op order (p=1000 amplifies rounding)."""
     idx = torch.arange(num_steps, dtype=torch.float32)

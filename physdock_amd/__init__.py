@@ -11,5 +11,6 @@ raises if `physdock_amd/libphysdock_hip.so` has not been built (python -m physdo
 from .configs import PhysDockConfig, small_config  # noqa: F401
 from .import_weights import import_state_dict, import_unicore_ckpt  # noqa: F401
 from .model import PhysDock, weighted_rigid_align  # noqa: F401
+from .confidence import ConfidenceModule  # noqa: F401  (reference layers/confidence_module.py)
 from .params import param_shapes, seeded_state_dict  # noqa: F401
 from .driver import redock  # noqa: F401  (multi-round caller of the sampler, reference redocking.py:156-342)

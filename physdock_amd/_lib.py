@@ -135,6 +135,9 @@ def _declare(L):
     sig("pd_axpby", p, p, f, p, p, f, ll, p)
     sig("pd_template_mask", p, p, p, p, i, i, p)
     sig("pd_template_feat", p, p, p, p, p, p, i, i, p)
+    sig("pd_confidence_pair_init", p, p, p, p, p, p, p, i, i, p)
+    sig("pd_pair_symmetrize", p, p, i, i, p)
+    sig("pd_atom_dist_embed", p, p, p, p, i, i, p)
     sig("pd_augment", p, f, p, p, p, p, f, f, p, i, i, p, i, i, p)
     sig("pd_init_noise", p, p, i, f, i, i, p)
     sig("pd_precond", p, f, p, p, p, p, p, i, i, i, p)

@@ -101,6 +101,12 @@ def PhysDockConfig(
                 "no_blocks_dit": dims["no_blocks_dit"],
                 "sigma_data": sigma_data,
             },
+            "confidence_module": {
+                "c_a": dims["c_a"], "c_ap": dims["c_ap"], "c_s": dims["c_s"], "c_z": dims["c_z"],
+                "inf": inf, "eps": eps,
+                "no_blocks_heads": dims.get("no_blocks_heads", nb_heads),
+                "no_blocks_atom": dims["no_blocks_atom"],
+            },
         },
     }
     return ConfigDict(cfg)

@@ -192,6 +192,27 @@ class Engine:
         self.triangle_attention(prefix + ".triangle_col_attention", z, T, C, maskT, True)
         self.transition(prefix + ".pair_transition", z, T * T, C)
 
+    def atom_transformer(self, prefix, a, ap, A, Ca, Cap, ap_mask, no_blocks):
+        """AtomTransformer (layers/transformers.py:25-36): a is updated in place through the blocks' residuals"""
+        P = self.P
+        abias = self.ws.get("atom_bias", ops.bias_frag_numel(Ca // 32, A, A), zero=True)
+        for b in range(no_blocks):
+            blk = f"{prefix}.blocks.{b}"
+            self.pair_bias(blk + ".attention", ap, A, A, Cap, ap_mask, P[blk + ".attention.norm_z.weight"], abias)
+            self.attention_pair_bias(blk + ".attention", a, 1, A, Ca, abias, nk=self.Ar)
+            self.transition(blk + ".transition", a, A, Ca)
+
+    def pairformer(self, prefix, s, z, T, Cs, Cz, z_mask, z_maskT, no_blocks):
+        """Pairformer (layers/transformers.py:124-146): s and z are updated in place"""
+        P = self.P
+        sbias = self.ws.get("single_bias", ops.bias_frag_numel(Cs // 32, T, T), zero=True)
+        for b in range(no_blocks):
+            blk = f"{prefix}.blocks.{b}"
+            self.triangle_block(blk, z, T, Cz, z_mask, z_maskT)
+            self.pair_bias(blk + ".attention", z, T, T, Cz, z_mask, P[blk + ".attention.norm_z.weight"], sbias)
+            self.attention_pair_bias(blk + ".attention", s, 1, T, Cs, sbias, nk=self.Tr)
+            self.transition(blk + ".transition", s, T, Cs)
+
     # ------------------------------------------------------------------ conditioning trunk
     def conditioning(self, batch):
         """DiffusionConditioning.forward (diffusion_conditioning.py:232-238) -> a, ap, s, z (workspace tensors)"""
@@ -237,13 +258,7 @@ class Engine:
                 self.gemm(h, W2, off(ap, r0 * Cap), rows, Cap, hidden, ldw=ldw2, res=off(ap, r0 * Cap), ldres=Cap)
         else:
             ops.check(rc, "pd_atom_pair_ffn")
-        Ha = Ca // 32
-        abias = ws.get("atom_bias", ops.bias_frag_numel(Ha, A, A), zero=True)
-        for b in range(dc.no_blocks_atom):
-            blk = f"{ae}.atom_transformer.blocks.{b}"
-            self.pair_bias(blk + ".attention", ap, A, A, Cap, ap_mask, P[blk + ".attention.norm_z.weight"], abias)
-            self.attention_pair_bias(blk + ".attention", a, 1, A, Ca, abias, nk=self.Ar)
-            self.transition(blk + ".transition", a, A, Ca)
+        self.atom_transformer(ae + ".atom_transformer", a, ap, A, Ca, Cap, ap_mask, dc.no_blocks_atom)
 
         # ---------------- TokenEmbedder (:178-202)
         te = pre + ".token_embedder"
@@ -302,14 +317,7 @@ class Engine:
         self.lin(m, te + ".linear_m", T, out=s2)                  # m[0] = first T rows
         self.lin(s, te + ".linear_s", T, out=s2, res=s2)
         s = s2
-        Hs = Cs // 32
-        sbias = ws.get("single_bias", ops.bias_frag_numel(Hs, T, T), zero=True)
-        for b in range(dc.no_blocks_pairformer):
-            blk = f"{te}.pairformer.blocks.{b}"
-            self.triangle_block(blk, z, T, Cz, z_mask, z_maskT)
-            self.pair_bias(blk + ".attention", z, T, T, Cz, z_mask, P[blk + ".attention.norm_z.weight"], sbias)
-            self.attention_pair_bias(blk + ".attention", s, 1, T, Cs, sbias, nk=self.Tr)
-            self.transition(blk + ".transition", s, T, Cs)
+        self.pairformer(te + ".pairformer", s, z, T, Cs, Cz, z_mask, z_maskT, dc.no_blocks_pairformer)
 
         # ---------------- tail (:236-237)
         st = self.stats(s, T, Cs, RMS, eps)
@@ -319,6 +327,51 @@ class Engine:
         zt = self.lin(z, pre + ".linear_z", T * T, stats=st, pro_w=P[pre + ".norm_z.weight"])
         ops.check(L.pd_pair_gather_add(ops.ptr(ap), ops.ptr(zt), ops.ptr(a2t), A, T, Cap, ops.stream()), "pair_gather_add")
         return a, ap, s, z
+
+    # ------------------------------------------------------------------ confidence head
+    def confidence(self, batch, s_in, z_in, x_pred, dims, pre="confidence_module"):
+        """ConfidenceModule.forward (layers/confidence_module.py:56-88) -> p_pae [T,T,c_pae], p_pde [T,T,c_pde],
+        p_plddt [A,c_plddt] (fresh tensors).  s_in [T,c_s], z_in [T*T,c_z] and x_pred [A,3] (the first predicted pose) are
+        read only; `dims` carries c_a c_ap c_s c_z no_blocks_heads no_blocks_atom."""
+        P, ws = self.P, self.ws
+        Ca, Cap, Cs, Cz = dims["c_a"], dims["c_ap"], dims["c_s"], dims["c_z"]
+        T, A = s_in.shape[0], x_pred.shape[0]
+        self.Ar, self.Tr = batch.get("_A_real", A), batch.get("_T_real", T)
+        z_mask = batch["z_mask"]
+        z_maskT = z_mask.t().contiguous()
+        L = ops._lib.init()
+        sp = ops.stream()
+        # z = z + linear_s_i(s)[:, None] + linear_s_j(s)[None, :] + linear_d(one_hot(d))                     (:68-72)
+        si = self.lin(s_in, pre + ".linear_s_i", T)
+        sj = self.lin(s_in, pre + ".linear_s_j", T)
+        z = ws.get("conf_z", T * T, Cz)
+        WdT = P._c(("conf_WdT", pre), lambda: P[pre + ".linear_d.weight"].t().contiguous())
+        ops.check(L.pd_confidence_pair_init(ops.ptr(z_in), ops.ptr(si), ops.ptr(sj), ops.ptr(WdT), ops.ptr(x_pred),
+                                            ops.ptr(batch["token_id_to_centre_atom_id"]), ops.ptr(z), T, Cz, sp), "confidence_pair_init")
+        s = ws.get("conf_s", T, Cs)
+        s.copy_(s_in)
+        self.pairformer(pre + ".pairformer", s, z, T, Cs, Cz, z_mask, z_maskT, dims["no_blocks_heads"])      # (:74)
+        zs = ws.get("conf_zs", T * T, Cz)
+        ops.check(L.pd_pair_symmetrize(ops.ptr(z), ops.ptr(zs), T, Cz, sp), "pair_symmetrize")               # (:75)
+        n_pae = P[pre + ".linear_pae.weight"].shape[0]
+        n_pde = P[pre + ".linear_pde.weight"].shape[0]
+        p_pae = self.lin(zs, pre + ".linear_pae", T * T, out=torch.empty(T * T, n_pae, device=self.device))  # (:76-77)
+        p_pde = self.lin(zs, pre + ".linear_pde", T * T, out=torch.empty(T * T, n_pde, device=self.device))
+        # a = linear_s_a(s)[atom_id_to_token_id];  ap = linear_z_a(|x_i - x_j|)                              (:79-80)
+        ta = self.lin(s, pre + ".linear_s_a", T)
+        a0 = ws.get("conf_a0", A, Ca)
+        a0.zero_()
+        ops.check(L.pd_gather_rows_add(ops.ptr(a0), ops.ptr(ta), ops.ptr(batch["atom_id_to_token_id"]), A, Ca, sp), "gather_rows_add")
+        ap = ws.get("conf_ap", A * A, Cap)
+        ops.check(L.pd_atom_dist_embed(ops.ptr(x_pred), ops.ptr(P[pre + ".linear_z_a.weight"]), ops.ptr(P[pre + ".linear_z_a.bias"]),
+                                       ops.ptr(ap), A, Cap, sp), "atom_dist_embed")
+        a = ws.get("conf_a", A, Ca)
+        a.copy_(a0)
+        self.atom_transformer(pre + ".atom_transformer", a, ap, A, Ca, Cap, batch["ap_mask"], dims["no_blocks_atom"])
+        ops.check(L.pd_axpby(ops.ptr(a), ops.ptr(a0), 1.0, ops.ptr(a), None, 1.0, A * Ca, sp), "axpby")      # a + AT(a) (:82-84)
+        n_pl = P[pre + ".linear_plddt.weight"].shape[0]
+        p_plddt = self.lin(a, pre + ".linear_plddt", A, out=torch.empty(A, n_pl, device=self.device))         # (:86)
+        return p_pae.reshape(T, T, n_pae), p_pde.reshape(T, T, n_pde), p_plddt
 
     def msa_column_attention(self, prefix, m, S, T, C):
         """m += MSAColumnAttention(m): attention along the MSA-row axis, no bias (attentions.py:117-136)"""

@@ -191,6 +191,32 @@ def param_shapes(config) -> "OrderedDict[str, tuple]":
     return d
 
 
+def confidence_param_shapes(c_a, c_ap, c_s, c_z, no_blocks_heads, no_blocks_atom=3, c_pae=64, c_pde=64, c_plddt=50,
+                            **_unused) -> "OrderedDict[str, tuple]":
+    """state dict of the reference's ConfidenceModule (layers/confidence_module.py:28-54; the module is built from the
+    `model.confidence_module` block of the config, configs.py:141-150, but is not attached to the released model,
+    model.py:68).  Pinned by tests/golden/param_names_confidence.json."""
+    d: "OrderedDict[str, tuple]" = OrderedDict()
+    _lin(d, "linear_s_i", c_s, c_z)
+    _lin(d, "linear_s_j", c_s, c_z)
+    _lin(d, "linear_d", 13, c_z, False)
+    for b in range(no_blocks_heads):
+        q = f"pairformer.blocks.{b}"
+        _triangle_block(d, q, c_z)
+        _attn_pair_bias(d, q + ".attention", c_s, c_z)
+        _transition(d, q + ".transition", c_s)
+    _lin(d, "linear_pae", c_z, c_pae)
+    _lin(d, "linear_pde", c_z, c_pde)
+    _lin(d, "linear_s_a", c_s, c_a)
+    _lin(d, "linear_z_a", 1, c_ap)
+    for b in range(no_blocks_atom):
+        q = f"atom_transformer.blocks.{b}"
+        _attn_pair_bias(d, q + ".attention", c_a, c_ap)
+        _transition(d, q + ".transition", c_a)
+    _lin(d, "linear_plddt", c_a, c_plddt)
+    return d
+
+
 def seeded_state_dict(shapes, seed: int = 0, dtype=torch.float32):
     """Deterministic non-degenerate weights for parity tests.
 

@@ -185,3 +185,18 @@ def toy_relax_fn(ref_mol, ligand_pos, mmff_iters=5):
     tgt = tgt - tgt.mean(0, keepdim=True)
     centre = ligand_pos.mean(1, keepdim=True)
     return ligand_pos + (0.02 * mmff_iters) * (tgt[None] + centre - ligand_pos)
+
+
+def confidence_inputs(batch, c_s, c_z, seed=5, n_pose=2):
+    """Inputs of ConfidenceModule.forward (reference confidence_module.py:56-66) for a synthetic batch: the centre atom of
+    every token (its first atom), trunk-like s / z activations and `n_pose` predicted poses around x_gt.  Seeded on the CPU
+    generator so that tools/make_golden.py (reference side) and the tests (HIP / oracle side) build identical tensors."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    T, A = batch["target_feat"].shape[0], batch["ref_pos"].shape[0]
+    chunk = batch["token_id_to_chunk_sizes"].long()
+    centre = torch.cumsum(chunk, 0) - chunk
+    s = torch.randn(T, c_s, generator=g)
+    z = torch.randn(T, T, c_z, generator=g)
+    x_pred = batch["x_gt"].float()[None] + 0.5 * torch.randn(n_pose, A, 3, generator=g)
+    return {"token_id_to_centre_atom_id": centre, "s": s, "z": z, "x_pred": x_pred}

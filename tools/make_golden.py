@@ -78,7 +78,7 @@ def main():
     import warnings
     warnings.filterwarnings("ignore")
     ap_ = argparse.ArgumentParser()
-    ap_.add_argument("--sets", default="g1-7,g8,g9,g10,g11")
+    ap_.add_argument("--sets", default="g1-7,g8,g9,g10,g11,g12")
     sets = set(ap_.parse_args().sets.split(","))
     install_shims()
     os.makedirs(OUT, exist_ok=True)
@@ -111,6 +111,8 @@ def main():
         main_g10()
     if "g11" in sets:
         main_g11(rtu)
+    if "g12" in sets:
+        main_g12(RefConfig)
 
 
 class Recorder:
@@ -284,6 +286,45 @@ def main_g11(rtu):
     templ_feat = torch.cat([dgram, mask[..., None]], dim=-1).float()
     npz("g11_template_feat", x_gt=x_gt, token_id_to_pseudo_beta_atom_id=pb, s_mask=s_mask, is_protein=is_protein,
         templ_feat=templ_feat)
+
+
+def main_g12(RefConfig):
+    """G12: the reference's ConfidenceModule (layers/confidence_module.py:13-88; built but unused in the released model) on
+    seeded weights: parameter-name contract, a small case and a ragged small case with full outputs, and the medium
+    configuration at the benchmark crop (T 256 / A 2048) with strided output samples (the full pae/pde logits are 2 x 16 MB)."""
+    from PhysDock.models.layers.confidence_module import ConfidenceModule as RefConfidence
+    from physdock_amd.configs import PhysDockConfig, small_config
+    from physdock_amd.params import confidence_param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import make_batch, small_batch, cfg1_batch, confidence_inputs
+
+    ref_cm = dict(RefConfig(model_name="medium").model.confidence_module)
+    mine_cm = dict(PhysDockConfig(model_name="medium").model.confidence_module)
+    assert ref_cm == mine_cm, (ref_cm, mine_cm)
+    with torch.device("meta"):
+        m = RefConfidence(**ref_cm)
+    names = {k: list(v.shape) for k, v in m.state_dict().items()}
+    mine = {k: list(v) for k, v in confidence_param_shapes(**mine_cm).items()}
+    assert names == mine, (set(names) ^ set(mine))
+    with open(os.path.join(OUT, "param_names_confidence.json"), "w") as f:
+        json.dump({"config": ref_cm, "names": names}, f)
+    print(f"  confidence param names: {len(names)} tensors - match")
+
+    def run(tag, cm, batch, stride):
+        mod = RefConfidence(**cm)
+        mod.load_state_dict(seeded_state_dict(confidence_param_shapes(**cm), seed=3), strict=True)
+        mod.eval()
+        inp = confidence_inputs(batch, cm["c_s"], cm["c_z"])
+        b = dict(batch)
+        b["token_id_to_centre_atom_id"] = inp["token_id_to_centre_atom_id"]
+        with torch.no_grad():
+            pae, pde, plddt = mod(b, inp["s"], inp["z"], inp["x_pred"])
+        npz(tag, p_pae=pae[::stride, ::stride], p_pde=pde[::stride, ::stride], p_plddt=plddt, stride=np.int64(stride),
+            pae_sum=pae.double().sum(), pde_sum=pde.double().sum())
+
+    small = dict(small_config().model.confidence_module)
+    run("g12_confidence_small", small, small_batch(seed=0), 1)
+    run("g12_confidence_ragged", small, make_batch(17, 5, 6, 8, seed=4), 1)
+    run("g12_confidence_cfg1", mine_cm, cfg1_batch(seed=0), 8)
 
 
 def main_g1_g7(RefPhysDock, RefConfig, rp, rt, rdc, rtu, mlc):
