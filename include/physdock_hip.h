@@ -169,6 +169,30 @@ int pd_confidence_pair_init(const float* z, const float* si, const float* sj, co
 int pd_pair_symmetrize(const float* z, float* out, int T, int C, void* stream);
 int pd_atom_dist_embed(const float* x, const float* w, const float* b, float* ap, int A, int C, void* stream);
 
+/* ---- feature tensorisation + PDB writer (features.hip) ------------------------
+ * The steps either side of the sampler: FeatureLoader.transform (feature_loader.py:970-998) and
+ * FeatureLoader.write_pdb_block (:1230-1283).  Raw per-system arrays in, model feature tensors out; poses in, PDB bytes out.
+ * pd_target_feat    : [one_hot(restype, n_class) | profile | deletion_mean] -> [T, n_class + n_profile + 1]      (:805-809)
+ * pd_msa_feat       : rows inds[] of (msa, deletion_matrix) -> [n_rows_out, T, n_class + 2] =
+ *                     [one_hot | clamp(del,0,1) | atan(del/3) * two_over_pi]; two_over_pi = the host's fp32 2/(2 acos 0) (:813-826)
+ * pd_outer_mask     : out[i,j] = m[i] m[j]  (z_mask, ap_mask)                                                     (:982-983)
+ * pd_chain_contacts : per chain pair p = (pairs[2p], pairs[2p+1]) (atoms chain_start[c] .. chain_start[c+1]): closest atom pair
+ *                     under |xa-xb| + (1 - mask_a mask_b) 1000, first in (a,b) order on ties; below `threshold` the two atoms'
+ *                     tokens are set to 1 in between[T,T] (symmetric; caller zeroes it); min_out / arg_out [n_pairs] optional  (:882-900)
+ * pd_pdb_format     : out[b, n, 0:81] = tmpl[n, 0:81] with columns 31-54 replaced by x[b, atom[n], 0:3] as "%8.3f" (Python
+ *                     float formatting of the fp32 value, ties to even, "-0.000" kept); *overflow counts values that do not fit
+ *                     the field (printed as '*')                                                                  (:1259-1270) */
+int pd_target_feat(const long long* restype, const float* profile, const float* deletion_mean, float* out, int T, int n_class,
+                   int n_profile, void* stream);
+int pd_msa_feat(const long long* msa, const float* deletion_matrix, const long long* inds, float two_over_pi, float* out,
+                int n_rows_out, int T, int n_class, void* stream);
+int pd_outer_mask(const float* m, float* out, int N, void* stream);
+int pd_chain_contacts(const float* x, const float* a_mask, const int* chain_start, const int* pairs, int n_pairs,
+                      const long long* a2t, float threshold, float* between, int T, float* min_out, long long* arg_out,
+                      void* stream);
+int pd_pdb_format(const float* x, const unsigned char* tmpl, const int* atom, unsigned char* out, int* overflow, int B, int A,
+                  int N, void* stream);
+
 /* ---- per-step sampler kernels (sampler.hip) ------------------------------------------------
  * pd_augment       : centre_random_augmentation + noise injection      (tensor_utils.py:576-586, model.py:70-85)
  *                    parity mode: rot_u[4][B], trans[B][3], noise[B][A][3]; perf mode: Philox(seed, sample0+b, step)

@@ -138,6 +138,11 @@ def _declare(L):
     sig("pd_confidence_pair_init", p, p, p, p, p, p, p, i, i, p)
     sig("pd_pair_symmetrize", p, p, i, i, p)
     sig("pd_atom_dist_embed", p, p, p, p, i, i, p)
+    sig("pd_target_feat", p, p, p, p, i, i, i, p)
+    sig("pd_msa_feat", p, p, p, f, p, i, i, i, p)
+    sig("pd_outer_mask", p, p, i, p)
+    sig("pd_chain_contacts", p, p, p, p, i, p, f, p, i, p, p, p)
+    sig("pd_pdb_format", p, p, p, p, p, i, i, i, p)
     sig("pd_augment", p, f, p, p, p, p, f, f, p, i, i, p, i, i, p)
     sig("pd_init_noise", p, p, i, f, i, i, p)
     sig("pd_precond", p, f, p, p, p, p, p, i, i, i, p)
@@ -158,7 +163,7 @@ def _declare(L):
 def ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.float64, torch.int32, torch.int64), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8), (t.device, t.dtype)
     return t.data_ptr()
 
 

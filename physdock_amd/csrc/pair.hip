@@ -155,12 +155,16 @@ __global__ __launch_bounds__(256) void gather_rows_add_kernel(float* __restrict_
 // out = a*sa [+ b*sb]  (elementwise, float4) - used for z += template embedding * t_mask etc.
 __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ out, const float* __restrict__ a, float sa,
                                                    const float* __restrict__ b, const float* __restrict__ sb_ptr, float sb,
-                                                   long long n4) {
+                                                   long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 v = reinterpret_cast<const f32x4*>(a)[i] * sa;
-    if (b) v += reinterpret_cast<const f32x4*>(b)[i] * (sb_ptr ? sb_ptr[0] * sb : sb);
-    reinterpret_cast<f32x4*>(out)[i] = v;
+    const float sbv = sb_ptr ? sb_ptr[0] * sb : sb;
+    if (4 * i + 3 < n) {
+        f32x4 v = reinterpret_cast<const f32x4*>(a)[i] * sa;
+        if (b) v += reinterpret_cast<const f32x4*>(b)[i] * sbv;
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    } else {
+        for (long long k = 4 * i; k < n; ++k) out[k] = a[k] * sa + (b ? b[k] * sbv : 0.f);      // tail of an n that is not a multiple of 4
+    }
 }
 
 // mask2d[i,j] = z_mask[i,j] * templ_feat[i,j,39] * [asym_i == asym_j]     (diffusion_conditioning.py:41-42)
@@ -267,9 +271,9 @@ PD_EXPORT int pd_gather_rows_add(float* y, const float* x, const long long* idx,
 
 PD_EXPORT int pd_axpby(float* out, const float* a, float sa, const float* b, const float* sb_ptr, float sb, long long n,
                        void* stream) {
-    if (!out || !a || n % 4) return PD_ERR_ARG;
-    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, a, sa, b,
-                       sb_ptr, sb, n / 4);
+    if (!out || !a || n <= 0) return PD_ERR_ARG;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, a, sa, b,
+                       sb_ptr, sb, n);
     return pd_check_launch();
 }
 

@@ -200,3 +200,105 @@ def confidence_inputs(batch, c_s, c_z, seed=5, n_pose=2):
     z = torch.randn(T, T, c_z, generator=g)
     x_pred = batch["x_gt"].float()[None] + 0.5 * torch.randn(n_pose, A, 3, generator=g)
     return {"token_id_to_centre_atom_id": centre, "s": s, "z": z, "x_pred": x_pred}
+
+
+def raw_features(seed=0, n_res=(14, 9), n_lig=(7, 5), n_msa=24, atoms_per_res=5):
+    """Synthetic *raw* (pre-`FeatureLoader.transform`, reference feature_loader.py:970-998) features of a small complex:
+    two protein chains and two ligand chains (one token per ligand atom), numpy arrays in the loader's layout.  Built so that
+    the inter-chain token-bond search (feature_loader.py:853-911) meets every case: ligand 0 has an atom 1.9 A from a protein
+    atom (bond), ligand 1 sits 2.1 A from ligand 0 (ligand-ligand bond) and far from the proteins, the two protein chains
+    touch at 1.5 A (protein-protein pairs are skipped), and the closest protein-ligand atom pair of all is masked out."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    chunks, asym, is_prot, is_lig = [], [], [], []
+    for c, n in enumerate(n_res):
+        chunks += [atoms_per_res] * n
+        asym += [c] * n
+        is_prot += [1.0] * n
+        is_lig += [0.0] * n
+    for c, n in enumerate(n_lig):
+        chunks += [1] * n
+        asym += [len(n_res) + c] * n
+        is_prot += [0.0] * n
+        is_lig += [1.0] * n
+    chunks = np.asarray(chunks, dtype=np.int64)
+    T, A = len(chunks), int(chunks.sum())
+    a2t = np.repeat(np.arange(T), chunks)
+    asym = np.asarray(asym, dtype=np.int32)
+    atom_asym = asym[a2t]
+    x = np.zeros((A, 3), dtype=np.float32)
+    origin = {0: (0, 0, 0), 1: (40, 0, 0), 2: (0, 30, 0), 3: (0, 30, 25)}
+    for c in range(len(n_res) + len(n_lig)):
+        m = atom_asym == c
+        walk = np.cumsum(rng.normal(0, 1.6, size=(int(m.sum()), 3)), axis=0)
+        x[m] = (walk - walk.mean(0) + np.asarray(origin.get(c, (20 * c, 50, 0)), dtype=np.float64)).astype(np.float32)
+    first = {c: int(np.argmax(atom_asym == c)) for c in range(len(n_res) + len(n_lig))}
+    p0, p1, l0, l1 = first[0], first[1], first[2], first[3]
+    x[l0 + 2] = x[p0 + 7] + np.float32([1.9, 0, 0])           # protein 0 - ligand 0 contact -> token bond
+    x[l1 + 1] = x[l0 + 4] + np.float32([0, 2.1, 0])           # ligand 0 - ligand 1 contact -> token bond
+    x[p1 + 3] = x[p0 + 11] + np.float32([0, 0, 1.5])          # protein - protein contact: never searched
+    x[l0 + 5] = x[p1 + 9] + np.float32([0.4, 0, 0])           # would be the closest pair (protein 1 - ligand 0) ...
+    a_mask = np.ones(A, dtype=np.float32)
+    a_mask[p1 + 9] = 0.0                                      # ... but the protein atom is unresolved; next best is > 2.4 A
+    s_mask = np.ones(T, dtype=np.float32)
+    s_mask[3] = 0.0
+    restype = np.where(np.asarray(is_prot) > 0, rng.integers(0, 20, T), 20 + rng.integers(0, 12, T)).astype(np.int64)
+    profile = rng.random((T, 32)).astype(np.float32)
+    profile /= profile.sum(-1, keepdims=True)
+    msa = rng.integers(0, 32, (n_msa, T)).astype(np.int64)
+    msa[0] = restype
+    deletion = np.where(rng.random((n_msa, T)) < 0.15, rng.integers(1, 9, (n_msa, T)), 0).astype(np.float32)
+    tb = np.zeros((T, T), dtype=np.float32)
+    lig_tok = np.nonzero(np.asarray(is_lig) > 0)[0]
+    for i, j in zip(lig_tok[:-1], lig_tok[1:]):
+        if asym[i] == asym[j]:
+            tb[i, j] = tb[j, i] = 1.0                         # within-conformer bonds already present before the search
+    is_short = np.zeros(T, dtype=np.float32)
+    is_short[lig_tok[-2:]] = 1.0                              # last ligand chain's tail flagged as short polymer
+    pb = (np.cumsum(chunks) - chunks + np.minimum(1, chunks - 1)).astype(np.int64)
+    return {
+        "restype": restype, "profile": profile, "deletion_mean": deletion.mean(0).astype(np.float32), "msa": msa,
+        "deletion_matrix": deletion, "asym_id": asym, "atom_id_to_token_id": a2t.astype(np.int64),
+        "is_ligand": np.asarray(is_lig, dtype=np.float32), "is_protein": np.asarray(is_prot, dtype=np.float32),
+        "is_short_poly": is_short, "x_gt": x, "a_mask": a_mask, "s_mask": s_mask, "token_bonds": tb,
+        "token_id_to_pseudo_beta_atom_id": pb, "token_id_to_chunk_sizes": chunks,
+        "residue_index": np.concatenate([np.arange(n) for n in n_res] + [np.zeros(n, dtype=np.int64) for n in n_lig]).astype(np.int64),
+    }
+
+
+def pdb_meta(raw, seed=0):
+    """`infer_meta_data` of FeatureLoader.write_pdb_block (reference feature_loader.py:1230-1283) for `raw_features`: one
+    conformer per protein residue and one per ligand chain, atom names of 2-4 characters, two-letter elements."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    chunks, asym = raw["token_id_to_chunk_sizes"], raw["asym_id"]
+    is_lig = raw["is_ligand"] > 0
+    res3 = ["ALA", "GLY", "SER", "LEU", "LYS", "ASP", "PHE", "HIS"]
+    ccds, conf_chunks, chain_class, res_index, conf_asym = [], [], [], [], []
+    meta = {}
+    t = 0
+    T = len(chunks)
+    while t < T:
+        if not is_lig[t]:
+            ccd = res3[int(rng.integers(0, len(res3)))]
+            n = int(chunks[t])
+            ccds.append(ccd); conf_chunks.append(n); chain_class.append("protein")
+            res_index.append(int(raw["residue_index"][t])); conf_asym.append(int(asym[t]))
+            if ccd not in meta:
+                names = ["N", "CA", "C", "O", "CB", "CG", "HD11", "OXT", "CD", "CE", "NZ", "OG", "SD", "HE21"]
+                meta[ccd] = {"ref_atom_name_chars": names, "ref_element": [6, 5, 5, 7, 5, 5, 0, 7, 5, 5, 6, 7, 15, 0]}
+            t += 1
+        else:
+            c = asym[t]
+            n = int((asym == c).sum())
+            ccd = f"L{int(c):02d}X" if c % 2 else "7Z4"     # a 4-character id (only its last three are printed) and a 3-character one
+            ccds.append(ccd); conf_chunks.append(n); chain_class.append("ligand")
+            res_index.append(0); conf_asym.append(int(c))
+            meta[ccd] = {"ref_atom_name_chars": [f"C{i + 1}" if i % 3 else f"CL{i + 1}" for i in range(n)],
+                         "ref_element": [5 if i % 3 else 16 for i in range(n)]}
+            t += n
+    inner = np.concatenate([np.arange(n) if cls == "ligand" else rng.permutation(max(n, 8))[:n]
+                            for n, cls in zip(conf_chunks, chain_class)]).astype(np.int64)
+    return {"ccds": ccds, "atom_id_to_conformer_atom_id": inner, "conformer_id_to_chunk_sizes": np.asarray(conf_chunks),
+            "CHAIN_CLASS": chain_class, "CONF_META_DATA": meta, "residue_index": np.asarray(res_index),
+            "asym_id": np.asarray(conf_asym)}

@@ -21,7 +21,10 @@ def load_golden(name):
     out = {}
     for k in z.files:
         v = z[k]
-        out[k] = torch.from_numpy(v) if v.ndim > 0 else v.item()
+        if v.dtype.kind in "US":
+            out[k] = v.tolist()                 # lists of names stay Python strings
+        else:
+            out[k] = torch.from_numpy(v) if v.ndim > 0 else v.item()
     return out
 
 

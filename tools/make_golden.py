@@ -78,7 +78,7 @@ def main():
     import warnings
     warnings.filterwarnings("ignore")
     ap_ = argparse.ArgumentParser()
-    ap_.add_argument("--sets", default="g1-7,g8,g9,g10,g11,g12")
+    ap_.add_argument("--sets", default="g1-7,g8,g9,g10,g11,g12,g13")
     sets = set(ap_.parse_args().sets.split(","))
     install_shims()
     os.makedirs(OUT, exist_ok=True)
@@ -113,6 +113,8 @@ def main():
         main_g11(rtu)
     if "g12" in sets:
         main_g12(RefConfig)
+    if "g13" in sets:
+        main_g13()
 
 
 class Recorder:
@@ -286,6 +288,88 @@ def main_g11(rtu):
     templ_feat = torch.cat([dgram, mask[..., None]], dim=-1).float()
     npz("g11_template_feat", x_gt=x_gt, token_id_to_pseudo_beta_atom_id=pb, s_mask=s_mask, is_protein=is_protein,
         templ_feat=templ_feat)
+
+
+def install_permissive_rdkit():
+    """G13 only: `PhysDock/data/feature_loader.py` imports RDKit helpers at module level (feature_loader.py:18 ->
+    data/tools/rdkit.py:4).  The methods captured below (transform / make_feats / _make_token_bonds / get_template_feat /
+    write_pdb_block) are pure torch / string code that never calls them, so every `rdkit.*` sub-module is replaced by an empty
+    module whose attributes are inert placeholders - enough for the imports to succeed, useless for anything else."""
+    import importlib.abc
+    import importlib.machinery
+    import types
+
+    class Inert:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return Inert()
+        def __getattr__(self, k): return Inert()
+
+    class StubModule(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return Inert()
+
+    class Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path, target=None):
+            if name.startswith("rdkit."):
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+        def create_module(self, spec):
+            m = StubModule(spec.name)
+            m.__path__ = []
+            return m
+
+        def exec_module(self, m): pass
+
+    sys.meta_path.insert(0, Finder())
+    for k in sorted((k for k in sys.modules if k.startswith("rdkit.")), key=len, reverse=True):
+        parent, _, leaf = k.rpartition(".")
+        if parent in sys.modules and hasattr(sys.modules[parent], leaf):
+            delattr(sys.modules[parent], leaf)
+        del sys.modules[k]
+
+
+def main_g13():
+    """G13: the tensorisation step `FeatureLoader.transform` (feature_loader.py:970-998: make_feats :803-851,
+    _make_token_bonds :853-911, masks, get_template_feat :944-968, type correction) and the PDB writer
+    `FeatureLoader.write_pdb_block` (:1230-1283), run as the reference's own bound methods on an instance created without
+    __init__ (the constructor needs the CCD metadata pickle); inputs from physdock_amd.synthetic.raw_features / pdb_meta."""
+    install_permissive_rdkit()
+    import PhysDock.data.feature_loader as fl
+    from physdock_amd.synthetic import raw_features, pdb_meta
+    loader = object.__new__(fl.FeatureLoader)
+    loader.num_recycles = None
+    loader.max_msa_clusters = 16
+    loader.token_bond_threshold = 2.4
+    loader.inference_mode = True
+    for seed in (0, 1):
+        raw = raw_features(seed)
+        torch.manual_seed(100 + seed)
+        out = loader.transform({k: v.copy() for k, v in raw.items()})
+        torch.manual_seed(100 + seed)
+        inds = [0] + torch.randperm(raw["msa"].shape[0])[:loader.max_msa_clusters - 1].tolist()
+        keys = ["target_feat", "msa_feat", "token_bonds", "z_mask", "ap_mask", "is_dna", "is_rna", "templ_feat", "t_mask",
+                "is_protein", "is_ligand"]
+        assert "msa" not in out and "is_short_poly" not in out
+        npz(f"g13_transform_{seed}", msa_inds=np.asarray(inds), out_keys=np.asarray(sorted(out.keys())),
+            **{k: out[k] for k in keys})
+        print("   token bonds added:", int((out["token_bonds"].numpy() - raw["token_bonds"]).sum()) // 2)
+    raw = raw_features(0)
+    meta = pdb_meta(raw)
+    g = torch.Generator().manual_seed(9)
+    A = raw["x_gt"].shape[0]
+    x = torch.from_numpy(raw["x_gt"]).clone()[None].repeat(3, 1, 1)
+    x[1] = x[1] * 7.3 - 250.0                                            # wide range incl. values below -100
+    x[2] = torch.randn(A, 3, generator=g) * 1e-3                         # values that round to 0.000 / -0.000 / +-0.001
+    x[2, :6, 0] = torch.tensor([0.0625, -0.0625, 0.0005, -0.0005, 2.5e-4, -1e-4])   # ties and negative zero
+    x[2, 6, :] = torch.tensor([9999.9994, -999.9994, 1234.5675])         # field-width limits
+    texts = {}
+    for tag, kw in (("all", {}), ("receptor", {"receptor_only": True}), ("ligand", {"ligand_only": True})):
+        for b in range(3):
+            texts[f"{tag}_{b}"] = np.frombuffer(loader.write_pdb_block(x[b], meta, **kw).encode("ascii"), dtype=np.uint8)
+    npz("g13_pdb_block", x_pred=x, **texts)
+    print(loader.write_pdb_block(x[2], meta, ligand_only=True)[:400])
 
 
 def main_g12(RefConfig):
