@@ -91,11 +91,13 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
            max_samples: int = 5, max_rounds: int = 10, num_samples_per_round: int = 5, steps: int = 40,
            mmff_gamma_0_factor_start: float = 6.0, karras_noise_schedule_power: float = 1000, use_pocket: bool = True,
            align_weights: Optional[torch.Tensor] = None, ranking: bool = True, seed: Optional[int] = None,
-           sampler_kwargs: Optional[dict] = None) -> dict:
+           sampler_kwargs: Optional[dict] = None, infer_meta_data=None) -> dict:
     """One system through the reference's round loop (defaults = redocking.py:33-59).  `batch` holds device tensors
     as for `model.sample_diffusion`; with physics correction it may hold `batch_msa_feat [rounds,S,T,34]`.
     Returns dict(poses [n,A,3] in the ground-truth frame, accepted (count before the top-up), rounds (per-round log),
-    gamma_factor, ranking (ranking.rank_poses output or None))."""
+    gamma_factor, ranking (ranking.rank_poses output or None)); with `infer_meta_data` (the loader's per-system naming
+    tables) also `pdb_blocks` / `receptor_pdb_blocks`: the `write_pdb_block` text of every kept pose (redocking.py:342-345),
+    formatted on the device for the whole batch (pdbio.py)."""
     if physics_correction and ref_mol_poses is None:
         raise ValueError("physics correction needs reference conformers (ref_mol_poses [C,L,3]); the reference generates "
                          "them with RDKit ETKDG (redocking.py:231-243), which this build does not include")
@@ -168,4 +170,8 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
     if ranking:
         from .ranking import rank_poses
         out["ranking"] = rank_poses(poses, x_gt, w, is_lig)
+    if infer_meta_data is not None:
+        from .pdbio import PdbTemplate
+        out["pdb_blocks"] = PdbTemplate(infer_meta_data).blocks(aligned)
+        out["receptor_pdb_blocks"] = PdbTemplate(infer_meta_data, receptor_only=True).blocks(aligned)
     return out

@@ -111,3 +111,25 @@ def test_pdb_number_formatting_matches_python():
     for a, line in enumerate(lines):
         want = "".join(f"{float(v):>8.3f}" for v in x[0, a])
         assert line[30:54] == want, (a, x[0, a].tolist(), line[30:54], want)
+
+
+def test_driver_emits_pdb_blocks_of_the_aligned_poses(small_model_inputs):
+    """redock(..., infer_meta_data=) returns the system / receptor PDB text of every kept pose (redocking.py:341-345),
+    equal to the per-pose Python writer applied to the poses it returns"""
+    from physdock_amd import PhysDock, driver
+    from physdock_amd.synthetic import pdb_meta
+    cfg, P, batch = small_model_inputs
+    model = PhysDock(cfg)
+    model.load_state_dict(P, strict=True)
+    model = model.cuda().eval()
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    meta = pdb_meta({k: batch[k].numpy() for k in ("token_id_to_chunk_sizes", "asym_id", "is_ligand", "residue_index")})
+    out = driver.redock(model, dbatch, max_samples=3, num_samples_per_round=3, steps=10, seed=1, ranking=False, infer_meta_data=meta,
+                        karras_noise_schedule_power=7)
+    poses = out["poses"].cpu()
+    assert float(poses.abs().max()) < 999.0            # the synthetic run stays inside the PDB coordinate field
+    assert len(out["pdb_blocks"]) == 3 and len(out["receptor_pdb_blocks"]) == 3
+    for b in range(3):
+        assert out["pdb_blocks"][b] == forc.write_pdb_block(poses[b], meta)
+        assert out["receptor_pdb_blocks"][b] == forc.write_pdb_block(poses[b], meta, receptor_only=True)
+        assert "HETATM" in out["pdb_blocks"][b] and "HETATM" not in out["receptor_pdb_blocks"][b]
