@@ -30,7 +30,8 @@ enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFR
 typedef struct pd_gemm_args {
     const float* A;          /* [M,K] row-major (lda) or, if a_kmajor, [K,M] */
     const float* W;          /* [N,K] row-major (ldw) or, if w_kmajor, [K,N] */
-    const void* W3;          /* optional: W pre-split into three bf16 parts, [3][N][Kp] with Kp = 32*ceil(K/32), zero padded
+    const void* W3;          /* optional: W pre-split into three bf16 parts, fragment-major [3][ceil(N/32)][Kp/16][64][8] with Kp =
+                                32*ceil(K/32), zero padded: element (n,k) at lane 32*(k%16/8) + n%32, slot k%8 (packing.split3_bf16)
                                 (w = hi + mid + lo exactly).  When given and the problem is one of the full-tile row-major
                                 shapes, the contraction runs as six bf16 MFMAs per block with fp32 accumulation
                                 (csrc/gemm_split.hip: at least the accuracy of the fp32 MFMA, 2.67x its peak rate); W must

@@ -28,21 +28,31 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KS = 16;               // k per LDS stage = one v_mfma_f32_32x32x16_bf16 step
 constexpr int PITCH = 24;            // bf16 per LDS row (48 bytes)
+constexpr int PITCH2 = 40;           // DW tiles: 32 k per row, 80 bytes apart (20 r mod 64 hits 16 distinct 4-bank groups: conflict-free b128 reads)
 
 // Block tile BM x BN computed by NWAVES waves laid out WM x WN.  The hot 128 x 128 tile runs on EIGHT waves (64 x 32 per
 // wave; 32 x 64 for GLU epilogues, where a wave must own both columns of a pair): with two blocks per CU that is four
 // waves per SIMD at <= 128 VGPRs, so the matrix pipe always has a wave with MFMAs to issue while others stage operands -
 // the six short bf16 MFMAs per block leave 2.67 x less matrix time per staged byte than the fp32 kernel has to hide it in.
-template <int BM_, int BN_, int WM_, int NWAVES_>
+// DW ("direct W"): the pre-split weight fragments do not pass through LDS at all.  packing.split3_bf16 stores them
+// FRAGMENT-MAJOR - the 64 lanes' 16-byte operands of one (32-row block, 16-k step) are one contiguous 1 KB block - so a
+// wave fetches its B operand with one fully coalesced global_load_dwordx4 per part, one k-step ahead of its use.  LDS then
+// carries only the A tile (which needs the norm prologue and the split, done once for the four waves that share it): per
+// block and k-step 12 KB of stores + 48 KB of reads instead of 24 + 72, the LDS port being what bounded the loop.
+template <int BM_, int BN_, int WM_, int NWAVES_, bool DW_ = false>
 struct STile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = NWAVES_ / WM_, NT = 64 * NWAVES_;
     static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-    static constexpr int STAGE = 3 * (BM + BN) * PITCH;                 // bf16 elements per stage
+    static constexpr bool DW = DW_;
+    // DW: a stage is a whole 32-k slice of A (rows PITCH2 apart) -> one block barrier per slice instead of two
+    static constexpr int STAGE = DW ? 3 * BM * PITCH2 : 3 * (BM + BN) * PITCH;      // bf16 elements per stage
     static constexpr int LDS_BYTES = 2 * STAGE * 2;
-    static constexpr int BLOCKS_PER_CU = LDS_BYTES > 60000 ? 2 : LDS_BYTES > 40000 ? 3 : 4;
+    static constexpr int BLOCKS_PER_CU = NWAVES_ == 8 ? 2 : LDS_BYTES > 60000 ? 2 : LDS_BYTES > 40000 ? 3 : 4;
+    static constexpr int WAVES_PER_SIMD = NWAVES_ * BLOCKS_PER_CU / 4;
     static constexpr int GRID = 256 * BLOCKS_PER_CU;
 };
 
@@ -56,18 +66,16 @@ __device__ __forceinline__ void lds_barrier() {
 
 // a = h + m + l with bf16 parts (round-to-nearest-even conversions; the residuals are exact in fp32)
 __device__ __forceinline__ void split4(const f32x4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 hh = (__bf16)v[e];
-        const float r1 = v[e] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        const float r2 = r1 - (float)mm;
-        h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
-    }
+    const pd_parts p0 = pd_split2(v[0], v[1]), p1 = pd_split2(v[2], v[3]);       // two values per packed conversion
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    h = __builtin_bit_cast(bf16x4, (u32x2){p0.h, p1.h});
+    m = __builtin_bit_cast(bf16x4, (u32x2){p0.m, p1.m});
+    l = __builtin_bit_cast(bf16x4, (u32x2){p0.l, p1.l});
 }
 
 template <int PRO, int EPI, class TL>
-__global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(const pd_gemm_args p) {
+__global__ __launch_bounds__(TL::NT) __attribute__((amdgpu_waves_per_eu(TL::WAVES_PER_SIMD, TL::WAVES_PER_SIMD)))
+void gemm_split_kernel(const pd_gemm_args p) {
     constexpr int BM = TL::BM, BN = TL::BN, TM = TL::TM, TN = TL::TN;
     constexpr int XSLOTS = TL::GRID / 8;
     constexpr int SNT = TL::NT;
@@ -81,10 +89,15 @@ __global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(c
     const int l31 = lane & 31, hh = lane >> 5;
     const int nMb = p.M / BM, nNb = p.N / BN;
     const int ntiles = nMb * nNb;
+    constexpr bool DW = TL::DW;
     const int nk = (p.K + 31) / 32;
-    const int Kp = nk * 32;                       // row pitch of the pre-split weight parts
-    const __bf16* __restrict__ W3 = reinterpret_cast<const __bf16*>(p.W3);
-    const long long wpart = (long long)p.N * Kp;
+    const int nks = 2 * nk;                       // 16-k steps per (zero padded) weight row
+    // pre-split weights, fragment-major: [3 parts][N / 32 row blocks][nks k-steps][64 lanes][8 bf16], lane = 32 * (k / 8 & 1) + n % 32
+    const bf16x8* __restrict__ W3 = reinterpret_cast<const bf16x8*>(p.W3);
+    const long long wpart = (long long)((p.N + 31) / 32) * nks * 64;          // in 16-byte units
+    auto w3_chunk = [&](int part, int n, int kchunk) {                          // kchunk = k / 8
+        return W3 + part * wpart + ((long long)(n >> 5) * nks + (kchunk >> 1)) * 64 + (kchunk & 1) * 32 + (n & 31);
+    };
 
     // stage s: [3 parts][BM rows][PITCH] for A, then [3][BN][PITCH] for W
     auto sA = [&](int s, int part) { return lds + s * TL::STAGE + part * BM * PITCH; };
@@ -96,6 +109,9 @@ __global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(c
     bf16x8 rw[3][NW];                            // [part][i]: NW == 2 -> chunk w_q + 2 i (half i); NW == 1 -> chunk w_q (half w_q >> 1)
 
     auto gload = [&](int bm0, int bn0, int k0) {
+#if defined(PD_ABL) && (PD_ABL == 1 || PD_ABL == 5)
+        if (k0 != 0) return;                      // ablation: no A traffic inside a tile
+#endif
         const int r = bm0 + a_row;                // full tiles only: always < M
         const float* ap = p.A + (long long)r * p.lda + k0;
 #pragma unroll
@@ -106,12 +122,26 @@ __global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(c
                 kc = k0 + kc < p.K ? kc : 0;      // clamped address; zeroed in `stage` (K % 4 == 0 is required)
                 ra[h][i] = *reinterpret_cast<const f32x4*>(ap + kc);
             }
-        const __bf16* wp = W3 + (long long)(bn0 + w_row) * Kp + k0;
+        if constexpr (!DW) {
 #pragma unroll
-        for (int part = 0; part < 3; ++part)
+            for (int part = 0; part < 3; ++part)
 #pragma unroll
-            for (int i = 0; i < NW; ++i)
-                rw[part][i] = *reinterpret_cast<const bf16x8*>(wp + part * wpart + 8 * (NW == 2 ? w_q + 2 * i : w_q));
+                for (int i = 0; i < NW; ++i)
+                    rw[part][i] = *w3_chunk(part, bn0 + w_row, (k0 >> 3) + (NW == 2 ? w_q + 2 * i : w_q));
+        }
+    };
+    // DW: this wave's B fragments of 16-k step `ks` of column block bn0, straight into MFMA operand registers
+    bf16x8 wf[2][TN][3];
+    auto wfrag = [&](int buf, int bn0, int ks) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#if defined(PD_ABL) && (PD_ABL == 2 || PD_ABL == 5)
+            ks = 0;                               // ablation: B operands always the same (L1-resident) block
+#endif
+            const bf16x8* base = W3 + ((long long)((bn0 + wn * (32 * TN) + j * 32) >> 5) * nks + ks) * 64 + lane;
+#pragma unroll
+            for (int part = 0; part < 3; ++part) wf[buf][j][part] = base[part * wpart];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -131,6 +161,7 @@ __global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(c
     int bm0, bn0;
     coords(tile, bm0, bn0);
     gload(bm0, bn0, 0);
+    if constexpr (DW) { wfrag(0, bn0, 0); wfrag(1, bn0, 1); }
 
     for (; tile < t_end; tile += t_step) {
         const int n0 = bn0 + wn * (32 * TN) + l31;
@@ -182,7 +213,7 @@ __global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(c
                 *reinterpret_cast<bf16x4*>(sA(h, 1) + o) = pm;
                 *reinterpret_cast<bf16x4*>(sA(h, 2) + o) = pl;
             }
-            if (NW == 2 || (w_q >> 1) == h) {
+            if (!DW && (NW == 2 || (w_q >> 1) == h)) {
                 const int i = NW == 2 ? h : 0;
                 const int c = NW == 2 ? w_q : (w_q & 1);          // 16-byte chunk inside the half
 #pragma unroll
@@ -199,8 +230,10 @@ __global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(c
                 for (int i = 0; i < TM; ++i)
                     fa[i][part] = *reinterpret_cast<const bf16x8*>(sA(s, part) + (wm * (32 * TM) + i * 32 + l31) * PITCH + 8 * hh);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fw[j][part] = *reinterpret_cast<const bf16x8*>(sW(s, part) + (wn * (32 * TN) + j * 32 + l31) * PITCH + 8 * hh);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (DW) fw[j][part] = wf[s][j][part];
+                    else fw[j][part] = *reinterpret_cast<const bf16x8*>(sW(s, part) + (wn * (32 * TN) + j * 32 + l31) * PITCH + 8 * hh);
+                }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -216,6 +249,65 @@ __global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(c
                     acc[i][j] = c;
                 }
         };
+        // ---- DW variants: the whole 32-k slice in ra goes to LDS stage s; fragments of k-step ks come from there and from wf[ks]
+        auto stage2 = [&](int s, int k0) {
+            __bf16* base = lds + s * TL::STAGE + a_row * PITCH2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < CPH_A; ++i) {
+                    const int c = a_q + TPR_A * i;
+                    const int kc = k0 + 16 * h + 4 * c;
+                    f32x4 v = ra[h][i];
+                    if constexpr (PRO != 0) {
+                        const int kl = kc < p.K ? kc : 0;
+                        const f32x4 pw = *reinterpret_cast<const f32x4*>(p.pro_w + grp_off + kl);
+                        const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pro_b + grp_off + kl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (v[e] - st_mean) * st_rstd * pw[e] + pb[e];
+                    }
+                    if (p.pro_act == PD_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    } else if (p.pro_act == PD_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = pd_silu(v[e]);
+                    }
+                    if (kc >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    bf16x4 ph, pm, pl;
+#if defined(PD_ABL) && (PD_ABL == 3 || PD_ABL == 5)
+                    ph = pm = pl = __builtin_bit_cast(bf16x4, f32x2{ra[h][i][0], ra[h][i][1]});      // ablation: no prologue / split VALU
+#else
+                    split4(v, ph, pm, pl);
+#endif
+                    const int o = 16 * h + 4 * c;
+                    *reinterpret_cast<bf16x4*>(base + o) = ph;
+                    *reinterpret_cast<bf16x4*>(base + BM * PITCH2 + o) = pm;
+                    *reinterpret_cast<bf16x4*>(base + 2 * BM * PITCH2 + o) = pl;
+                }
+        };
+        auto mma2 = [&](int s, int ks) {
+            bf16x8 fa[TM][3];
+            const __bf16* base = lds + s * TL::STAGE + (wm * (32 * TM) + l31) * PITCH2 + 16 * ks + 8 * hh;
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i][part] = *reinterpret_cast<const bf16x8*>(base + part * BM * PITCH2 + i * 32 * PITCH2);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], wf[ks][j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], wf[ks][j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], wf[ks][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], wf[ks][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], wf[ks][j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], wf[ks][j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        };
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -225,6 +317,26 @@ __global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(c
 
         // slice 0 of this tile is in ra / rw (requested before the previous tile's epilogue)
         lds_barrier();                            // every wave has finished the previous tile's last stage
+        if constexpr (DW) {
+            stage2(0, 0);
+            lds_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int st = kt & 1;
+                const bool more = kt + 1 < nk;
+                if (more) gload(bm0, bn0, (kt + 1) * 32);
+                mma2(st, 0);
+                if (more) wfrag(0, bn0, 2 * kt + 2);          // every B buffer is re-requested right after its last use:
+                mma2(st, 1);                                  // a full k-step (+ the staging and the barrier) ahead
+                if (more) {
+                    wfrag(1, bn0, 2 * kt + 3);
+                    // the other stage was last read in the previous iteration, which every wave left through its barrier
+                    stage2(st ^ 1, (kt + 1) * 32);
+#if !defined(PD_ABL) || (PD_ABL != 4 && PD_ABL != 5)
+                    lds_barrier();
+#endif
+                }
+            }
+        } else {
         stage(0, 0);
         stage(1, 0);
         lds_barrier();
@@ -243,10 +355,12 @@ __global__ __launch_bounds__(TL::NT, TL::BLOCKS_PER_CU) void gemm_split_kernel(c
                 stage(1, (kt + 1) * 32);          // (visible to the next mma(1) through the barrier after the next mma(0))
             }
         }
+        }
         const int cur_bm0 = bm0, cur_bn0 = bn0;
         if (tile + t_step < t_end) {
             coords(tile + t_step, bm0, bn0);
             gload(bm0, bn0, 0);
+            if constexpr (DW) { wfrag(0, bn0, 0); wfrag(1, bn0, 1); }
         }
         epilogue<EPI, TM, TN>(p, acc, c0, c1, cur_bm0, cur_bn0, wm, wn, l31, hh);
     }
@@ -264,8 +378,8 @@ int run_split(int op, const pd_gemm_args* p, hipStream_t s) {
     return pd_check_launch();
 }
 
-using S128 = STile<128, 128, 2, 8>;        // 2 x 4 waves of 64 x 32
-using S128G = STile<128, 128, 4, 8>;       // 4 x 2 waves of 32 x 64 (GLU)
+using S128 = STile<128, 128, 2, 8, true>;  // 2 x 4 waves of 64 x 32
+using S128G = STile<128, 128, 4, 8, false>; // 4 x 2 waves of 32 x 64 (GLU): two B fragments per wave do not fit the register budget directly
 using S128W4 = STile<128, 128, 2, 4>;      // 2 x 2 waves of 64 x 64
 using S64 = STile<64, 64, 2, 4>;
 using S12864 = STile<128, 64, 4, 4>;
@@ -317,7 +431,7 @@ extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, vo
     const bool glut = p.out_mode == PD_OUT_TRANSPOSED && p.glu && !p.hn_w && !p.mul && !p.res && !p.act && !p.rowscale_acc &&
                       !p.maskadd && p.out_scale == 1.f && p.vecY && (!p.rowscale || ((uintptr_t)p.rowscale & 15) == 0) && tile == 128;
     if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || (p.out_mode != PD_OUT_ROWMAJOR && !glut)) return PD_ERR_UNSUPPORTED;
-    if (((uintptr_t)p.W3 & 15) != 0) return PD_ERR_UNSUPPORTED;
+    if (((uintptr_t)p.W3 & 15) != 0 || p.N % 32 != 0) return PD_ERR_UNSUPPORTED;
     if (p.M % tbm != 0 || p.N % tbn != 0) return PD_ERR_UNSUPPORTED;
     // Launches that do not fill the chip are latency-bound (two block barriers per 32-k slice here, one in gemm_stream.hip):
     // measured at 1-4 samples the fp32 kernel is faster on every DiT shape, from ~256 tiles on the split kernel wins.

@@ -31,9 +31,9 @@ def pad_k(W):
     return out
 
 
-def split3_bf16(W):
+def split3_rows(W):
     """[N,K] fp32 -> [3][N][Kp] bf16 with W = hi + mid + lo exactly (round-to-nearest-even splits; the residuals are exact
-    in fp32), Kp = K rounded up to a multiple of 32, zero padded: the B operand of csrc/gemm_split.hip."""
+    in fp32), Kp = K rounded up to a multiple of 32, zero padded."""
     N, K = W.shape
     Kp = (K + 31) // 32 * 32
     out = torch.zeros(3, N, Kp, dtype=torch.bfloat16, device=W.device)
@@ -42,7 +42,21 @@ def split3_bf16(W):
         h = r.to(torch.bfloat16)
         out[part, :, :K] = h
         r = r - h.float()
-    return out.contiguous()
+    return out
+
+
+def split3_bf16(W):
+    """The B operand of csrc/gemm_split.hip: the three bf16 parts of W [N,K] (split3_rows), stored FRAGMENT-MAJOR:
+    [3][ceil(N/32)][Kp/16][64][8], element (n, k) of a part at lane 32 * ((k % 16) // 8) + n % 32, slot k % 8 of the
+    (n // 32, k // 16) block - i.e. every 1 KB block is exactly one wave's v_mfma_f32_32x32x16_bf16 B operand (row n % 32
+    = lane & 31, eight consecutive k at 8 * (lane >> 5)), so the kernel fetches it with one coalesced 16-byte load per lane."""
+    rows = split3_rows(W)
+    _, N, Kp = rows.shape
+    Np = (N + 31) // 32 * 32
+    if Np != N:
+        rows = torch.cat([rows, torch.zeros(3, Np - N, Kp, dtype=rows.dtype, device=rows.device)], 1)
+    v = rows.reshape(3, Np // 32, 32, Kp // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)
+    return v.contiguous()
 
 
 class PackedWeights:

@@ -110,12 +110,19 @@ def test_split_accuracy_is_at_least_fp32_mfma(K):
 
 
 def test_split_weights_are_an_exact_decomposition():
-    from physdock_amd.packing import split3_bf16
+    from physdock_amd.packing import split3_bf16, split3_rows
     W = torch.randn(96, 77) * torch.exp(3 * torch.randn(96, 77))
-    s = split3_bf16(W)
+    s = split3_rows(W)
     assert s.shape == (3, 96, 96) and s.dtype == torch.bfloat16
     assert torch.equal(s.float().sum(0)[:, :77], W)       # hi + mid + lo reproduces every fp32 weight bit for bit
     assert float(s[:, :, 77:].abs().max()) == 0.0
+    # the kernel's operand layout: fragment-major 1 KB blocks, element (n, k) at [n // 32][k // 16][32 * (k % 16 // 8) + n % 32][k % 8]
+    f = split3_bf16(W)
+    assert f.shape == (3, 3, 6, 2, 32, 8) and f.is_contiguous()
+    for (n, k) in [(0, 0), (31, 15), (32, 16), (95, 76), (40, 9), (70, 95)]:
+        assert torch.equal(f[:, n // 32, k // 16, (k % 16) // 8, n % 32, k % 8], s[:, n, k])
+    g = split3_bf16(torch.randn(40, 20))                   # rows padded to a multiple of 32 with zeros
+    assert g.shape == (3, 2, 2, 2, 32, 8) and float(g[:, 1, :, :, 8:].abs().max()) == 0.0
 
 
 def test_split_multi_tile_stress():

@@ -30,10 +30,12 @@ def main():
                                 (4096, 4096, 4096, 0, "square 4096")]:
         A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda")
         Y = torch.empty(M, N // 2 if glu else N, device="cuda")
-        t = timeit(lambda: ops.gemm(A, W, Y, M, N, K, glu=glu))
+        # the model's SwiGLU projections always carry a norm prologue (the split kernel has no prologue-free GLU variant)
+        kw = dict(stats=torch.tensor([0.0, 1.0], device="cuda").repeat(M, 1).contiguous()) if glu else {}
+        t = timeit(lambda: ops.gemm(A, W, Y, M, N, K, glu=glu, **kw))
         from physdock_amd.packing import split3_bf16
         W3 = split3_bf16(W)
-        t6 = timeit(lambda: ops.gemm(A, W, Y, M, N, K, glu=glu, W3=W3))
+        t6 = timeit(lambda: ops.gemm(A, W, Y, M, N, K, glu=glu, W3=W3, **kw))
         print(f"gemm {tag:14s} M={M:7d} N={N:5d} K={K:5d}: fp32 MFMA {t*1e6:9.1f} us {2*M*N*K/t/1e12:7.1f} TF | "
               f"bf16x6 {t6*1e6:9.1f} us {2*M*N*K/t6/1e12:7.1f} TF")
     for (nb, H, n, tag) in [(B, 4, 2048, "dit atom"), (B, 16, 256, "dit token"), (256, 4, 256, "triangle"),
