@@ -30,6 +30,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef PD_SPLIT_MIN_TILES
+#define PD_SPLIT_MIN_TILES 256
+#endif
 constexpr int KS = 16;               // k per LDS stage = one v_mfma_f32_32x32x16_bf16 step
 constexpr int PITCH = 24;            // bf16 per LDS row (48 bytes)
 constexpr int PITCH2 = 40;           // DW tiles: 32 k per row, 80 bytes apart (20 r mod 64 hits 16 distinct 4-bank groups: conflict-free b128 reads)
@@ -435,7 +438,7 @@ extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, vo
     if (p.M % tbm != 0 || p.N % tbn != 0) return PD_ERR_UNSUPPORTED;
     // Launches that do not fill the chip are latency-bound (two block barriers per 32-k slice here, one in gemm_stream.hip):
     // measured at 1-4 samples the fp32 kernel is faster on every DiT shape, from ~256 tiles on the split kernel wins.
-    if ((long long)(p.M / tbm) * (p.N / tbn) < 256) return PD_ERR_UNSUPPORTED;
+    if ((long long)(p.M / tbm) * (p.N / tbn) < PD_SPLIT_MIN_TILES) return PD_ERR_UNSUPPORTED;
     if (p.rowscale_acc || (p.rowscale && !glut) || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
     if (glut) epi = EPI_GLUT;
