@@ -201,7 +201,8 @@ int pd_pdb_format(const float* x, const unsigned char* tmpl, const int* atom, un
  * pd_precond       : ba = Wx.(x_hat*c_in) + bx + a                      (transformers.py:218-223)
  * pd_denoise       : x_den = c_skip*x_hat + c_out*Wr.LN(ba)             (transformers.py:228-233)
  * pd_kabsch_align  : weighted_rigid_align (moves x_gt onto x_pred)      (tensor_utils.py:724-778)
- * pd_template_match: eps metric, argmin, write template into ref_pos   (model.py:231-241; redocking.py:326-335)
+ * pd_template_match: eps metric, argmin, write template into ref_pos   (model.py:231-241; redocking.py:326-335);
+ *                    with eps_out [B][Cn] given the metric runs one workgroup per (conformer, sample), same values
  * pd_pose_dist     : pairwise distances of conformers                   (model.py:186)
  * pd_euler         : d_cur mix + Euler step                             (model.py:245-281)
  * pd_timestep_embed: sinusoidal embedding                               (timestep_embeddings.py:64-81)   */

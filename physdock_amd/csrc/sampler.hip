@@ -319,6 +319,48 @@ __global__ __launch_bounds__(256) void template_match_kernel(const float* __rest
     }
 }
 
+// The same metric with one workgroup per (conformer, sample) - 40 x B blocks instead of B blocks that walk the conformers
+// one after the other (112 us per step at any B) - followed by the argmin / copy pass.  Per (b, c) the arithmetic and the
+// reduction order are those of template_match_kernel, so eps and the selection are bit-identical.
+__global__ __launch_bounds__(256) void template_eps_kernel(const float* __restrict__ x, const int* __restrict__ lig_idx,
+                                                          const float* __restrict__ ref_dist, float* __restrict__ eps_out, int A,
+                                                          int L, int Cn) {
+    extern __shared__ float sm[];     // L*3 coords
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    for (int i = threadIdx.x; i < L * 3; i += 256) sm[i] = x[((long long)b * A + lig_idx[i / 3]) * 3 + i % 3];
+    __syncthreads();
+    float acc = 0.f;
+    const float* rd = ref_dist + (long long)c * L * L;
+    for (int ij = threadIdx.x; ij < L * L; ij += 256) {
+        const int i = ij / L, j = ij % L;
+        const float dx = sm[3 * i] - sm[3 * j], dy = sm[3 * i + 1] - sm[3 * j + 1], dz = sm[3 * i + 2] - sm[3 * j + 2];
+        const float delta = fabsf(sqrtf(dx * dx + dy * dy + dz * dz) - rd[ij]);
+        acc += 0.25f * (1.f / (1.f + expf(0.5f - delta)) + 1.f / (1.f + expf(1.f - delta)) +
+                        1.f / (1.f + expf(2.f - delta)) + 1.f / (1.f + expf(4.f - delta)));
+    }
+    const float e = block_sum(acc, red) / (float)(L * L);
+    if (threadIdx.x == 0) eps_out[(long long)b * Cn + c] = e;
+}
+
+__global__ __launch_bounds__(64) void template_select_kernel(const float* __restrict__ eps, const int* __restrict__ lig_idx,
+                                                            const float* __restrict__ poses, float* __restrict__ batch_ref_pos,
+                                                            int* __restrict__ sel_out, int A, int L, int Cn) {
+    const int b = blockIdx.x;
+    float best_e = INFINITY;
+    int best_c = 0;
+    for (int c = 0; c < Cn; ++c) {                      // every lane scans the (<= a few dozen) values: first minimum wins
+        const float e = eps[(long long)b * Cn + c];
+        if (e < best_e) { best_e = e; best_c = c; }
+    }
+    if (threadIdx.x == 0 && sel_out) sel_out[b] = best_c;
+    if (batch_ref_pos) {
+        const float* ps = poses + (long long)best_c * L * 3;
+        for (int i = threadIdx.x; i < L * 3; i += 64)
+            batch_ref_pos[((long long)b * A + lig_idx[i / 3]) * 3 + i % 3] = ps[i];
+    }
+}
+
 // pairwise distance matrices of conformers: D[c,i,j] = |p_ci - p_cj|          (model.py:186)
 __global__ __launch_bounds__(256) void pose_dist_kernel(const float* __restrict__ poses, float* __restrict__ D, int L, long long n) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -481,6 +523,14 @@ PD_EXPORT int pd_template_match(const float* x, const int* lig_idx, const float*
                                 float* batch_ref_pos, float* eps_out, int* sel_out, int B, int A, int L, int Cn, void* stream) {
     if (!x || !lig_idx || !ref_dist || L <= 0 || Cn <= 0) return PD_ERR_ARG;
     if (batch_ref_pos && !poses) return PD_ERR_ARG;
+    if (eps_out) {             // scratch for eps given: conformer-parallel pass + selection pass
+        hipLaunchKernelGGL(template_eps_kernel, dim3(Cn, B), dim3(256), L * 3 * sizeof(float), (hipStream_t)stream, x, lig_idx,
+                           ref_dist, eps_out, A, L, Cn);
+        if (batch_ref_pos || sel_out)
+            hipLaunchKernelGGL(template_select_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, eps_out, lig_idx, poses,
+                               batch_ref_pos, sel_out, A, L, Cn);
+        return pd_check_launch();
+    }
     hipLaunchKernelGGL(template_match_kernel, dim3(B), dim3(256), L * 3 * sizeof(float), (hipStream_t)stream, x, lig_idx,
                        ref_dist, poses, batch_ref_pos, eps_out, sel_out, A, L, Cn);
     return pd_check_launch();

@@ -272,7 +272,7 @@ class PhysDock(nn.Module):
         lig_w.copy_(batch["a_mask"] * lig_flag)
         any_align = any(p["align"] for p in plan)
         any_mmff = any(p["mmff"] for p in plan)
-        ref_dist = poses = lig_idx = atom_slot = None
+        ref_dist = poses = lig_idx = atom_slot = tm_eps = None
         n_conf = n_lig = 0
         if (any_align and ref_mol_poses is not None) or any_mmff:
             lig_idx = torch.nonzero(lig_flag > 0).flatten().to(torch.int32)
@@ -284,6 +284,7 @@ class PhysDock(nn.Module):
                 poses = staged("poses", ref_mol_poses.to(device).float())
                 n_conf = poses.shape[0]
                 ref_dist = ws.get("ref_dist", n_conf, n_lig, n_lig)
+                tm_eps = ws.get("tm_eps", B, n_conf)          # eps[b, c] scratch: lets the matching run conformer-parallel
                 ops.check(L.pd_pose_dist(ops.ptr(poses), ops.ptr(ref_dist), n_conf, n_lig, sp), "pose_dist")
         if any_mmff:
             if n_lig == 0:
@@ -348,7 +349,7 @@ class PhysDock(nn.Module):
             if p["align"]:
                 if poses is not None:
                     ops.check(L.pd_template_match(ops.ptr(x_den), ops.ptr(lig_idx), ops.ptr(ref_dist), ops.ptr(poses),
-                                                  ops.ptr(bref), None, None, B, A, n_lig, n_conf, sp_), "template_match")
+                                                  ops.ptr(bref), ops.ptr(tm_eps), None, B, A, n_lig, n_conf, sp_), "template_match")
                 target, tstride = bref, A * 3
             elif p["mmff"]:
                 if relaxer.kind == "host":

@@ -21,3 +21,11 @@ for _ in range(3):
     eng.conditioning(pb)
 torch.cuda.synchronize()
 print(f"{cfgname}: trunk {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms")
+# host enqueue time alone (no synchronisation inside the loop): if it is close to the wall time above, the trunk is
+# bound by the ~1.6 k launches' host cost, not by the GPU
+t0 = time.perf_counter()
+for _ in range(3):
+    eng.conditioning(pb)
+t_cpu = (time.perf_counter() - t0) / 3
+torch.cuda.synchronize()
+print(f"{cfgname}: host enqueue {t_cpu * 1e3:.1f} ms per pass")
