@@ -122,32 +122,46 @@ __device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&a
     }
 }
 
-// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.
-// A persistent grid of 512 (1024 for 64x64 tiles) blocks gives every XCD 64 (128) concurrently running tiles; they are chosen as a compact patch of
-// GM row blocks x (64 / GM) column blocks inside a contiguous range of row blocks owned by that XCD, so that an A panel
-// fetched by one tile is an L2 hit for the tiles of the other column blocks (M-fastest order re-fetches A once per
-// column block: measured 8x the algorithmic read traffic for N = 2816), and W panels are shared by GM tiles.
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own 4 MB L2.
+// A persistent grid of 512 (1024 for 64x64 tiles) blocks gives every XCD 64 (128) concurrently running tiles; they are chosen
+// as a compact PATCH of gm row blocks x gn column blocks inside a contiguous range of row blocks owned by that XCD, so that
+// an A panel fetched by one tile is an L2 hit for the gn tiles beside it and a W panel for the gm tiles below it.  Traffic
+// per XCD ~ tiles x (W-panel bytes / gm + A-panel bytes / gn): a square patch (8 x 8) minimises it.  (M-fastest order
+// re-fetches A once per column block: measured 8x the algorithmic reads for N = 2816; full-width patches of 2 row blocks
+// streamed the 8.6 MB of split weights of that shape once per patch: 445 MB per launch against 134 MB algorithmic.)
 struct TileOrder {
-    int nMb, nNb, mb_lo, nmb, gm, per_group, ntiles;      // this XCD's row-block range, patch height, tiles per patch
+    int nMb, nNb, mb_lo, nmb, gm, gn, per_group, ntiles;      // this XCD's row-block range, patch height / width, tiles per row group
     __device__ __forceinline__ void init(int nMb_, int nNb_, int xcd, int nxcd, int slots) {
         nMb = nMb_; nNb = nNb_;
         mb_lo = (int)((long long)nMb * xcd / nxcd);
         nmb = (int)((long long)nMb * (xcd + 1) / nxcd) - mb_lo;
-        gm = slots / nNb;
+        int g0 = 1;
+        while ((g0 + 1) * (g0 + 1) <= slots) ++g0;            // floor(sqrt(slots))
+        gn = nNb < g0 ? nNb : g0;
+        gm = slots / gn;
         gm = gm < 1 ? 1 : gm;
-        gm = gm > nmb ? (nmb > 0 ? nmb : 1) : gm;
+        if (gm > nmb) {                                       // few row blocks: spend the slots on width instead
+            gm = nmb > 0 ? nmb : 1;
+            gn = slots / gm;
+            gn = gn > nNb ? nNb : (gn < 1 ? 1 : gn);
+        }
         per_group = gm * nNb;
         ntiles = nmb * nNb;
     }
-    // t-th tile of this XCD -> (row block, column block); only the last patch may be shorter than gm
+    // t-th tile of this XCD -> (row block, column block): row groups of gm row blocks (the last may be shorter), inside a
+    // group column chunks of gn (the last may be narrower), inside a patch row-fastest
     __device__ __forceinline__ void get(int t, int& mb, int& nb) const {
         int g = t / per_group;
         const int ngroups = (nmb + gm - 1) / gm;
         g = g < ngroups - 1 ? g : ngroups - 1;
-        const int r = t - g * per_group;
+        const int q = t - g * per_group;
         const int h = nmb - g * gm < gm ? nmb - g * gm : gm;
+        const int nchunks = (nNb + gn - 1) / gn;
+        int c = q / (h * gn);
+        c = c < nchunks - 1 ? c : nchunks - 1;
+        const int r = q - c * h * gn;
         mb = mb_lo + g * gm + r % h;
-        nb = r / h;
+        nb = c * gn + r / h;
     }
 };
 
