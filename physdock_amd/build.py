@@ -57,8 +57,9 @@ def build(force=False, verbose=True):
             cmd[1:1] = ["-DPD_GEMM_NOSTORE=1"]
         if os.environ.get("PD_ABL") and os.path.basename(src) == "gemm_split.hip":      # lab: main-loop ablations (wrong results)
             cmd[1:1] = ["-DPD_ABL=" + os.environ["PD_ABL"]]
-        if os.environ.get("PD_SPLIT_MIN_TILES") and os.path.basename(src) == "gemm_split.hip":
-            cmd[1:1] = ["-DPD_SPLIT_MIN_TILES=" + os.environ["PD_SPLIT_MIN_TILES"]]
+        for knob in ("PD_SPLIT_MIN_TILES", "PD_SPLIT_MIN_TILES_SMALL"):
+            if os.environ.get(knob) and os.path.basename(src) == "gemm_split.hip":
+                cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
         if os.environ.get("PD_NO_EXTRA_FLAGS") != "1":
             cmd[1:1] = EXTRA_FLAGS.get(os.path.basename(src), [])
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

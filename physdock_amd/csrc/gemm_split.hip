@@ -33,6 +33,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PD_SPLIT_MIN_TILES
 #define PD_SPLIT_MIN_TILES 256
 #endif
+#ifndef PD_SPLIT_MIN_TILES_SMALL
+#define PD_SPLIT_MIN_TILES_SMALL 256
+#endif
 constexpr int KS = 16;               // k per LDS stage = one v_mfma_f32_32x32x16_bf16 step
 constexpr int PITCH = 24;            // bf16 per LDS row (48 bytes)
 constexpr int PITCH2 = 40;           // DW tiles: 32 k per row, 80 bytes apart (20 r mod 64 hits 16 distinct 4-bank groups: conflict-free b128 reads)
@@ -384,8 +387,8 @@ int run_split(int op, const pd_gemm_args* p, hipStream_t s) {
 using S128 = STile<128, 128, 2, 8, true>;  // 2 x 4 waves of 64 x 32
 using S128G = STile<128, 128, 4, 8, false>; // 4 x 2 waves of 32 x 64 (GLU): two B fragments per wave do not fit the register budget directly
 using S128W4 = STile<128, 128, 2, 4>;      // 2 x 2 waves of 64 x 64
-using S64 = STile<64, 64, 2, 4>;
-using S12864 = STile<128, 64, 4, 4>;
+using S64 = STile<64, 64, 2, 4, true>;
+using S12864 = STile<128, 64, 4, 4, true>;
 
 int dispatch_split(int op, int pro, int epi, int tile, const pd_gemm_args* p, hipStream_t s) {
 #define PD_SCASE(P, E, C, TL) if (pro == P && epi == E && tile == C) return run_split<P, E, TL>(op, p, s);
@@ -438,7 +441,7 @@ extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, vo
     if (p.M % tbm != 0 || p.N % tbn != 0) return PD_ERR_UNSUPPORTED;
     // Launches that do not fill the chip are latency-bound (two block barriers per 32-k slice here, one in gemm_stream.hip):
     // measured at 1-4 samples the fp32 kernel is faster on every DiT shape, from ~256 tiles on the split kernel wins.
-    if ((long long)(p.M / tbm) * (p.N / tbn) < PD_SPLIT_MIN_TILES) return PD_ERR_UNSUPPORTED;
+    if ((long long)(p.M / tbm) * (p.N / tbn) < (tile == 128 ? PD_SPLIT_MIN_TILES : PD_SPLIT_MIN_TILES_SMALL)) return PD_ERR_UNSUPPORTED;
     if (p.rowscale_acc || (p.rowscale && !glut) || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
     if (glut) epi = EPI_GLUT;
