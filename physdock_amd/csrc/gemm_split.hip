@@ -385,7 +385,7 @@ int run_split(int op, const pd_gemm_args* p, hipStream_t s) {
 }
 
 using S128 = STile<128, 128, 2, 8, true>;  // 2 x 4 waves of 64 x 32
-using S128G = STile<128, 128, 4, 8, false>; // 4 x 2 waves of 32 x 64 (GLU): two B fragments per wave do not fit the register budget directly
+using S128G = STile<128, 128, 4, 8, false>; // 4 x 2 waves of 32 x 64 (GLU): two B fragments per wave do not fit the register budget directly (the 4-wave 64 x 64 direct layout: same GEMM rate, -2 % end to end)
 using S128W4 = STile<128, 128, 2, 4>;      // 2 x 2 waves of 64 x 64
 using S64 = STile<64, 64, 2, 4, true>;
 using S12864 = STile<128, 64, 4, 4, true>;
