@@ -133,3 +133,31 @@ def test_driver_emits_pdb_blocks_of_the_aligned_poses(small_model_inputs):
         assert out["pdb_blocks"][b] == forc.write_pdb_block(poses[b], meta)
         assert out["receptor_pdb_blocks"][b] == forc.write_pdb_block(poses[b], meta, receptor_only=True)
         assert "HETATM" in out["pdb_blocks"][b] and "HETATM" not in out["receptor_pdb_blocks"][b]
+
+
+def test_transform_and_pdb_at_the_benchmark_crop_vs_oracle():
+    """T 256 / A 2048 / 512 MSA rows: the device tensorisation against the (G13-pinned) oracle restatement, and 64 poses of
+    PDB text against the per-pose Python writer"""
+    from physdock_amd.features import transform
+    from physdock_amd.pdbio import PdbTemplate
+    from physdock_amd.synthetic import pdb_meta, raw_features
+    raw = raw_features(0, n_res=(150, 74), n_lig=(20, 12), n_msa=512, atoms_per_res=9)
+    assert raw["restype"].shape[0] == 256 and raw["x_gt"].shape[0] == 2048
+    inds = [0] + torch.randperm(512, generator=torch.Generator().manual_seed(5))[:127].tolist()
+    out = transform(raw, "cuda", msa_inds=inds)
+    ref = forc.transform(raw, inds)
+    for k in TRANSFORM_KEYS:
+        got = out[k].cpu()
+        if k == "msa_feat":
+            assert torch.equal(got[..., :33], ref[k][..., :33])
+            torch.testing.assert_close(got[..., 33], ref[k][..., 33], rtol=0, atol=1.2e-7)
+        else:
+            assert torch.equal(got, ref[k]), k
+    assert out["msa_feat"].shape == (128, 256, 34) and out["templ_feat"].shape == (256, 256, 40)
+    assert float((out["token_bonds"].cpu() - torch.from_numpy(raw["token_bonds"])).sum()) >= 4
+    meta = pdb_meta(raw)
+    x = torch.from_numpy(raw["x_gt"])[None] + 0.3 * torch.randn(64, 2048, 3, generator=torch.Generator().manual_seed(6))
+    blocks = PdbTemplate(meta, device="cuda").blocks(x.cuda())
+    assert len(blocks) == 64
+    for b in (0, 31, 63):
+        assert blocks[b] == forc.write_pdb_block(x[b], meta)
