@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 3
+#define PD_ABI_VERSION 4
 
 enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFRAG = 3 };
 
@@ -75,6 +75,12 @@ typedef struct pd_gemm_args {
     int T1, T2;                  /* OPM: T2 = tokens; BIASFRAG: rows m = (i,j), i<T1, j<T2   */
     int frag_transpose;          /* BIASFRAG: query = j, key = i                             */
     int vecA, vecW, vecY;        /* set by the launcher                                      */
+    /* optional K-split scratch (ABI 4): float workspace.  Given it, a launch whose full tiles cannot fill the chip (few
+       samples) is cut along K into `ksplit` parts per tile: a first launch stores every part's partial accumulators here, a
+       second one adds them IN FIXED ORDER (bit-reproducible, no floating-point atomics) and runs the epilogue.  NULL: never.  */
+    void* ksplit_ws;
+    long long ksplit_ws_bytes;
+    int ksplit;                  /* set by the launcher                                      */
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
 /* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling);

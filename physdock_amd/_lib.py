@@ -57,6 +57,7 @@ class GemmArgs(C.Structure):
         ("res", _fp), ("ldres", C.c_int), ("res_row_mod", C.c_int), ("sRes", C.c_longlong),
         ("out_mode", C.c_int), ("T1", C.c_int), ("T2", C.c_int), ("frag_transpose", C.c_int),
         ("vecA", C.c_int), ("vecW", C.c_int), ("vecY", C.c_int),
+        ("ksplit_ws", _fp), ("ksplit_ws_bytes", C.c_longlong), ("ksplit", C.c_int),
     ]
 
 

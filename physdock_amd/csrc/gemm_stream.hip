@@ -32,6 +32,9 @@
 
 namespace {
 
+#ifndef PD_KSPLIT_MAX_BYTES
+#define PD_KSPLIT_MAX_BYTES (12 << 20)
+#endif
 constexpr int BK = 32, LDK = BK + 4, NT = 256;
 
 // Block tile BM x BN, 4 waves laid out WM x WN, each wave TM x TN MFMA fragments of 32 x 32:
@@ -101,9 +104,31 @@ __global__ __launch_bounds__(NT, TL::BLOCKS_PER_CU) void gemm_stream_kernel(cons
     const bool grouped = gridDim.x == TL::GRID && nMb >= 8;
     TileOrder ord;
     ord.init(nMb, nNb, grouped ? blockIdx.x & 7 : 0, grouped ? 8 : 1, XSLOTS);
-    const int t_step = grouped ? XSLOTS : gridDim.x;
+    int t_step = grouped ? XSLOTS : gridDim.x;
     const int t_end = grouped ? ord.ntiles : ntiles;
     int tile = grouped ? blockIdx.x >> 3 : blockIdx.x;
+    // K-split launches (few tiles, long K): one (tile, k-part) per block, all parts of a tile on one XCD (block b -> XCD
+    // b & 7) so that the partial sums meet in that XCD's L2:  b = xcd + 8 (q ks + part),  tile = 8 q + xcd
+    // Two launches: ksplit = ks > 1: every block computes one k-part of one tile and stores its partial accumulators in the
+    // scratch; ksplit = -ks: one block per tile adds the parts IN ORDER (bit-reproducible, no atomics, the kernel boundary is
+    // the only synchronisation) and runs the epilogue.
+    const int ks = p.ksplit > 1 ? p.ksplit : (p.ksplit < -1 ? -p.ksplit : 1);
+    const bool reduce_only = p.ksplit < -1;
+    int kt_beg = 0, kt_end = nk, part = 0;
+    if (ks > 1) {
+        if (reduce_only) {
+            tile = blockIdx.x;
+            kt_end = 0;
+        } else {
+            const int rest = blockIdx.x >> 3;
+            part = rest % ks;
+            tile = (rest / ks) * 8 + (blockIdx.x & 7);
+            const int nkp = (nk + ks - 1) / ks;
+            kt_beg = part * nkp;
+            kt_end = kt_beg + nkp < nk ? kt_beg + nkp : nk;
+        }
+        t_step = 1 << 30;                                   // a single pass through the tile loop
+    }
     if (tile >= t_end) return;
     auto coords = [&](int t, int& bm0, int& bn0) {
         int mb, nb;
@@ -113,8 +138,10 @@ __global__ __launch_bounds__(NT, TL::BLOCKS_PER_CU) void gemm_stream_kernel(cons
     };
     int bm0, bn0;
     coords(tile, bm0, bn0);
-    la.load(p.A, p.lda, PD_LT(bm0), p.M, 0, p.K, tid);
-    lw.load(p.W, p.ldw, PD_LT(bn0), p.N, 0, p.K, tid);
+    if (!reduce_only) {
+        la.load(p.A, p.lda, PD_LT(bm0), p.M, kt_beg * BK, p.K, tid);
+        lw.load(p.W, p.ldw, PD_LT(bn0), p.N, kt_beg * BK, p.K, tid);
+    }
 
     for (; tile < t_end; tile += t_step) {
         // per-lane column constants of this tile (column group j = packed columns n0 + 32 j); consumed in the epilogue
@@ -183,17 +210,19 @@ __global__ __launch_bounds__(NT, TL::BLOCKS_PER_CU) void gemm_stream_kernel(cons
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         // slice 0 of this tile is already in la/lw (requested before the previous tile's epilogue)
-        transform_A(0);
-        la.mask(bm0, p.M, 0, p.K, tid);
-        lw.mask(bn0, p.N, 0, p.K, tid);
-        __syncthreads();                     // previous tile's last slice has been read by every wave
-        la.store(sA, tid);
-        lw.store(sW, tid);
-        __syncthreads();
+        if (!reduce_only) {
+            transform_A(kt_beg * BK);
+            la.mask(bm0, p.M, kt_beg * BK, p.K, tid);
+            lw.mask(bn0, p.N, kt_beg * BK, p.K, tid);
+            __syncthreads();                     // previous tile's last slice has been read by every wave
+            la.store(sA, tid);
+            lw.store(sW, tid);
+            __syncthreads();
+        }
 
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nk;
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            const int cur = (kt - kt_beg) & 1;
+            const bool more = kt + 1 < kt_end;
             if (more) {
                 la.load(p.A, p.lda, PD_LT(bm0), p.M, (kt + 1) * BK, p.K, tid);
                 lw.load(p.W, p.ldw, PD_LT(bn0), p.N, (kt + 1) * BK, p.K, tid);
@@ -232,6 +261,34 @@ __global__ __launch_bounds__(NT, TL::BLOCKS_PER_CU) void gemm_stream_kernel(cons
             lw.load(p.W, p.ldw, PD_LT(bn0), p.N, 0, p.K, tid);
         }
 
+        if (ks > 1) {
+            float* __restrict__ parts = reinterpret_cast<float*>(p.ksplit_ws) + (long long)tile * ks * (BM * BN);
+            if (!reduce_only) {
+                float* mine = parts + (long long)part * (BM * BN);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<f32x4*>(mine + (((i * TN + j) * 4 + q) * NT + tid) * 4) =
+                                f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                return;
+            }
+            for (int pp = 0; pp < ks; ++pp) {
+                const float* src = parts + (long long)pp * (BM * BN);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (((i * TN + j) * 4 + q) * NT + tid) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
+                        }
+            }
+        }
         epilogue<EPI, TM, TN>(p, acc, c0, c1, cur_bm0, cur_bn0, wm, wn, l31, hh);
     }
 }
@@ -247,6 +304,13 @@ static int run_stream(int op, const pd_gemm_args* p, hipStream_t s) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
     const long long ntiles = (long long)(p->M / TL::BM) * (p->N / TL::BN);
+    if (p->ksplit > 1) {
+        hipLaunchKernelGGL(k, dim3((unsigned)(((ntiles + 7) / 8) * 8 * p->ksplit)), dim3(NT), lds, s, *p);
+        pd_gemm_args r = *p;
+        r.ksplit = -p->ksplit;
+        hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(NT), lds, s, r);
+        return pd_check_launch();
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < TL::GRID ? ntiles : TL::GRID)), dim3(NT), lds, s, *p);
     return pd_check_launch();
 }
@@ -309,5 +373,18 @@ extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, v
         const int r = dispatch_stream(1, pro, epi, tile, nullptr, nullptr);
         return r == PD_OK ? epi : r;
     }
-    return dispatch_stream(0, pro, epi, tile, &p, (hipStream_t)stream);
+    // K-split for launches that leave most of the chip idle: parts of >= 4 slices, up to ~512 blocks
+    pd_gemm_args q = p;
+    q.ksplit = 1;
+    if (p.ksplit_ws && ((uintptr_t)p.ksplit_ws & 15) == 0) {
+        const long long ntiles = (long long)(p.M / tbm) * (p.N / tbn);
+        const int nk = (p.K + BK - 1) / BK;
+        long long ks = nk / 4;
+        if (ks > 8) ks = 8;
+        if (ks > 512 / ntiles) ks = 512 / ntiles;
+        while (ks >= 2 && ntiles * ks * tbm * tbn * 4 > PD_KSPLIT_MAX_BYTES) --ks;      // the partial sums are written and read back: keep them L2-sized
+        const long long need = ntiles * ks * tbm * tbn * 4;
+        if (ks >= 2 && ntiles < 192 && need <= p.ksplit_ws_bytes) q.ksplit = (int)ks;
+    }
+    return dispatch_stream(0, pro, epi, tile, &q, (hipStream_t)stream);
 }

@@ -67,7 +67,11 @@ class Engine:
                 and not kw.get("a_kmajor") and not kw.get("w_kmajor") and N % 64 == 0 \
                 and (kw.get("out_mode", 0) == 0 or (kw.get("out_mode") == OUT_TRANSPOSED and kw.get("glu"))):
             w3 = self.P.w3(W, K)
-        ops.gemm(A, W, Y, M, N, K, W3=w3, **kw)
+        ksw = None
+        if kw.get("batch", 1) == 1 and kw.get("out_mode", 0) == 0 and M <= 8192 and K >= 256 and not kw.get("a_kmajor"):
+            # few rows x long K (token-level projections at a handful of samples): scratch that lets pd_gemm cut K
+            ksw = self.ws.get("gemm_ksplit", 9 << 20)
+        ops.gemm(A, W, Y, M, N, K, W3=w3, ksplit_ws=ksw, **kw)
 
     def lws(self, name, *shape):
         """lane-private scratch: concurrent sample lanes never share a DiT intermediate"""

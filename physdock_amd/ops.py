@@ -34,7 +34,7 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
          pro_gstride=0, pro_act=ACT_NONE, rowscale_acc=None, bias=None, sBias=0, hn_w=None, hn_cols=0,
          hn_split=32, hn_eps=0.0, act=ACT_NONE, glu=0, rowscale=None, maskadd=None, maskval=0.0,
          mul=None, ldmul=0, mul_rows_per_group=0, mul_gstride=0, out_scale=1.0, res=None, ldres=0,
-         res_row_mod=0, sRes=0, out_mode=OUT_ROWMAJOR, T1=0, T2=0, frag_transpose=False, W3=None):
+         res_row_mod=0, sRes=0, out_mode=OUT_ROWMAJOR, T1=0, T2=0, frag_transpose=False, W3=None, ksplit_ws=None):
     """Y = epilogue(prologue(A) @ W^T); see include/physdock_hip.h pd_gemm_args.
     A/W/Y and the optional operands may be tensors or raw device addresses (ints)."""
     def P(x):
@@ -64,6 +64,8 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
     a.out_scale = out_scale
     a.res, a.ldres, a.res_row_mod, a.sRes = P(res), (ldres or n_out), res_row_mod, sRes
     a.out_mode, a.T1, a.T2, a.frag_transpose = out_mode, T1, T2, int(frag_transpose)
+    if ksplit_ws is not None and KSPLIT_GEMM:
+        a.ksplit_ws, a.ksplit_ws_bytes = ptr(ksplit_ws), ksplit_ws.numel() * 4
     if GEMM_HOOK is not None:
         return GEMM_HOOK(a, lambda: check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm"))
     check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm")
@@ -83,6 +85,9 @@ def lab_set_trace(kind, buf):
 #: use the pre-split bf16 x 6 contraction (csrc/gemm_split.hip) where a launcher is given split weights; False forces the
 #: fp32-MFMA kernels everywhere (A/B comparisons in the tests and the bench)
 SPLIT_GEMM = True
+
+#: K-split of launches that cannot fill the chip (few samples) when the caller hands pd_gemm a scratch buffer
+KSPLIT_GEMM = True
 
 #: the same switch for the attention kernel (csrc/attn_split.hip vs csrc/attention.hip)
 SPLIT_ATTN = True

@@ -1,0 +1,97 @@
+"""K-split of GEMM launches that cannot fill the chip (csrc/gemm_stream.hip, pd_gemm_args.ksplit_ws): partial accumulators
+in scratch, summed in fixed order by a second launch.  Same results as the unsplit launch to rounding, bit-identical from run to run.
+GPU only."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ws():
+    return torch.empty(9 << 20, device="cuda")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 512), (256, 512, 1408), (1024, 512, 1408), (2048, 128, 384), (320, 512, 1000)])
+def test_gate_residual_in_place(M, N, K):
+    """the token / atom output projections at 1-4 samples: x += gate * (h W^T + b), in place"""
+    from physdock_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    h = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    gate = torch.randn(4, N, generator=g)
+    x0 = torch.randn(M, N, generator=g)
+    want = x0 + gate[torch.arange(M) // (M // 4)] * (h @ W.T + b)
+    hd, Wd, bd, gd = h.cuda(), W.cuda(), b.cuda(), gate.cuda()
+    ws = _ws()
+    outs = []
+    for use, rep in ((None, 1), (ws, 3)):
+        for _ in range(rep):
+            x = x0.cuda().clone()
+            ops.gemm(hd, Wd, x, M, N, K, bias=bd, mul=gd, mul_rows_per_group=M // 4, mul_gstride=N, res=x, ksplit_ws=use)
+            outs.append(x.cpu())
+    torch.testing.assert_close(outs[0], want, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(outs[1], outs[0], rtol=1e-5, atol=1e-5)        # split vs unsplit: only the summation order differs
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])    # and the split order is fixed
+    if K >= 512 and (M // 4) % 64 == 0:                                    # (other gate groupings go to the general kernel)
+        assert not torch.equal(outs[1], outs[0])                              # the split path really ran
+
+
+def test_prologue_and_nonlinear_epilogues():
+    """norm prologue + per-head RMSNorm (q|k|v) and norm prologue + SwiGLU at a handful of rows: the epilogue sees the full sum"""
+    from physdock_amd import ops
+    from physdock_amd.packing import pack_glu
+    g = torch.Generator().manual_seed(3)
+    M, C = 256, 512
+    x = torch.randn(M, C, generator=g)
+    w, bsh = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xd, wd, bd = x.cuda(), w.cuda(), bsh.cuda()
+    st = torch.empty(M, 2, device="cuda")
+    ops.rowstats(xd, st, M, C, mode=ops.LN, eps=1e-5)
+    xn = F.layer_norm(x, (C,), w, bsh, 1e-5)
+    ws = _ws()
+    # q | k | v, head norm on q and k
+    Wq = torch.randn(3 * C, C, generator=g) / C ** 0.5
+    hw = 1 + 0.1 * torch.randn(2, 32, generator=g)
+    y = (xn @ Wq.T).reshape(M, 3, C // 32, 32)
+    hn = lambda t, w_: t * torch.rsqrt((t * t).mean(-1, keepdim=True) + 1e-8) * w_
+    want = torch.stack([hn(y[:, 0], hw[0]), hn(y[:, 1], hw[1]), y[:, 2]], 1).reshape(M, 3 * C)
+    got = []
+    for use in (None, ws, ws):
+        Y = torch.empty(M, 3 * C, device="cuda")
+        ops.gemm(xd, Wq.cuda(), Y, M, 3 * C, C, stats=st, pro_w=wd, pro_b=bd, hn_w=hw.cuda(), hn_cols=2 * C, hn_split=C, hn_eps=1e-8,
+                 ksplit_ws=use)
+        got.append(Y.cpu())
+    torch.testing.assert_close(got[0], want, rtol=3e-4, atol=3e-4)
+    torch.testing.assert_close(got[1], got[0], rtol=2e-5, atol=2e-5)
+    assert torch.equal(got[1], got[2])
+    # SwiGLU 512 -> 1408
+    Hd = 1408
+    W1, W3 = torch.randn(Hd, C, generator=g) / C ** 0.5, torch.randn(Hd, C, generator=g) / C ** 0.5
+    Wp, _ = pack_glu(W1, W3)
+    want = F.silu(xn @ W1.T) * (xn @ W3.T)
+    got = []
+    for use in (None, ws, ws):
+        Y = torch.empty(M, Hd, device="cuda")
+        ops.gemm(xd, Wp.cuda(), Y, M, 2 * Hd, C, stats=st, pro_w=wd, pro_b=bd, glu=1, ksplit_ws=use)
+        got.append(Y.cpu())
+    torch.testing.assert_close(got[0], want, rtol=3e-4, atol=3e-4)
+    torch.testing.assert_close(got[1], got[0], rtol=2e-5, atol=2e-5)
+    assert torch.equal(got[1], got[2])
+
+
+def test_large_launches_and_small_scratch_are_left_alone():
+    from physdock_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 16384, 512, 512                                   # fills the chip: never split
+    A, W = torch.randn(M, K, generator=g).cuda(), torch.randn(N, K, generator=g).cuda()
+    Y0, Y1 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.gemm(A, W, Y0, M, N, K)
+    ops.gemm(A, W, Y1, M, N, K, ksplit_ws=_ws())
+    assert torch.equal(Y0, Y1)
+    M = 256                                                     # would split, but the scratch is too small for the partial sums
+    Y0, Y1 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.gemm(A[:M], W, Y0, M, N, K)
+    ops.gemm(A[:M], W, Y1, M, N, K, ksplit_ws=torch.zeros(8192, device="cuda"))
+    assert torch.equal(Y0, Y1)
