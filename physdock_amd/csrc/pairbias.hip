@@ -13,6 +13,13 @@
 #include "common.h"
 #include "physdock_hip.h"
 
+#ifndef PD_PB_UB
+#define PD_PB_UB 8
+#endif
+#ifndef PD_PB_TR
+#define PD_PB_TR 8
+#endif
+
 namespace {
 
 template <int LPR>
@@ -25,15 +32,18 @@ __device__ __forceinline__ float group_sum(float v) {       // sum over the LPR 
     }
 }
 
-// C = 4 LPR channels, H heads; 4 waves per block, every wave walks 64-row tiles
-template <int LPR, int H>
+// C = 4 LPR channels, H heads; 4 waves per block, every wave walks TR-row tiles.  TR = 16 for C = 128: the per-row work is a
+// chain of dependent DPP reductions, so the kernel wants many short waves per SIMD (65 536 rows = 4 096 wave tiles), not 1 024
+// long ones (21 -> see NOTES); C = 16 rows are cheap and stay at 64.
+template <int LPR, int H, int TR>
 __global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict__ x, const float* __restrict__ Wf,
                                                        const float* __restrict__ c2, float* __restrict__ stats,
                                                        const float* __restrict__ maskadd, float maskval, float out_scale,
                                                        float* __restrict__ frag, long long M, int T1, int T2, int transpose,
                                                        int mode, float eps) {
-    constexpr int C = 4 * LPR, RPI = 64 / LPR, NI = 64 / RPI;
-    __shared__ float tile[4][64][H + 1];
+    constexpr int C = 4 * LPR, RPI = 64 / LPR, NI = TR / RPI;
+    static_assert(TR % RPI == 0 && TR % 4 == 0 && TR <= 64, "tile rows");
+    __shared__ float tile[4][TR][H + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR, grp = lane / LPR;
     f32x4 w[H];
@@ -43,26 +53,26 @@ __global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict_
         w[h] = *reinterpret_cast<const f32x4*>(Wf + h * C + 4 * sub);
         cb[h] = c2 ? c2[h] : 0.f;
     }
-    const long long ntile = (M + 63) / 64;
+    const long long ntile = (M + TR - 1) / TR;
     const int nq = transpose ? T2 : T1, nk = transpose ? T1 : T2;
     const int nqt = (nq + 31) >> 5, nkt = (nk + 31) >> 5;
     for (long long t = (long long)blockIdx.x * 4 + wave; t < ntile; t += (long long)gridDim.x * 4) {
-        const long long m0 = t * 64;
-        constexpr int UB = NI < 8 ? NI : 8;          // rows in flight per lane: UB independent 16-byte loads before any use
+        const long long m0 = t * TR;
+        constexpr int UB = NI < PD_PB_UB ? NI : PD_PB_UB;          // rows in flight per lane: UB independent 16-byte loads before any use
         for (int q0 = 0; q0 < NI; q0 += UB) {
             f32x4 vv[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int r = LPR == 32 ? (q0 + u) + 32 * grp : (q0 + u) * RPI + grp;
+                const int r = LPR == 32 ? (q0 + u) + (TR / 2) * grp : (q0 + u) * RPI + grp;
                 const long long row = m0 + r;
                 vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (row < M) vv[u] = *reinterpret_cast<const f32x4*>(x + row * C + 4 * sub);
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                // C = 128: half 0 takes rows 0..31 of the tile, half 1 rows 32..63 (two contiguous 512-byte reads per
+                // C = 128: half 0 takes the first TR/2 rows of the tile, half 1 the rest (two contiguous 512-byte reads per
                 // instruction); C = 16: 16 consecutive rows per instruction
-                const int r = LPR == 32 ? (q0 + u) + 32 * grp : (q0 + u) * RPI + grp;
+                const int r = LPR == 32 ? (q0 + u) + (TR / 2) * grp : (q0 + u) * RPI + grp;
                 const long long row = m0 + r;
                 const bool ok = row < M;
                 f32x4 v = vv[u];
@@ -90,8 +100,8 @@ __global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict_
         asm volatile("" ::: "memory");
         if (!transpose) {
             // rows m = (i, j): query i, key j; four consecutive j share one 16-byte slot of the fragment layout
-            for (int idx = lane; idx < H * 16; idx += 64) {
-                const int h = idx >> 4, quad = idx & 15;
+            for (int idx = lane; idx < H * (TR / 4); idx += 64) {
+                const int h = idx / (TR / 4), quad = idx % (TR / 4);
                 const long long m = m0 + 4 * quad;
                 if (m >= M) continue;
                 const int qi = (int)(m / T2), kj = (int)(m - (long long)qi * T2);
@@ -103,8 +113,8 @@ __global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict_
                 *reinterpret_cast<f32x4*>(frag + a) = o;
             }
         } else {
-            for (int idx = lane; idx < H * 64; idx += 64) {
-                const int h = idx >> 6, r = idx & 63;
+            for (int idx = lane; idx < H * TR; idx += 64) {
+                const int h = idx / TR, r = idx % TR;
                 const long long m = m0 + r;
                 if (m >= M) continue;
                 const int i = (int)(m / T2), j = (int)(m - (long long)i * T2);
@@ -118,13 +128,13 @@ __global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict_
     }
 }
 
-template <int LPR, int H>
+template <int LPR, int H, int TR>
 int launch(const float* x, const float* Wf, const float* c2, float* stats, const float* maskadd, float maskval, float out_scale,
            float* frag, long long M, int T1, int T2, int transpose, int mode, float eps, hipStream_t s) {
-    const long long ntile = (M + 63) / 64;
+    const long long ntile = (M + TR - 1) / TR;
     long long blocks = (ntile + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL((pair_bias_kernel<LPR, H>), dim3((unsigned)blocks), dim3(256), 0, s, x, Wf, c2, stats, maskadd, maskval,
+    hipLaunchKernelGGL((pair_bias_kernel<LPR, H, TR>), dim3((unsigned)blocks), dim3(256), 0, s, x, Wf, c2, stats, maskadd, maskval,
                        out_scale, frag, M, T1, T2, transpose, mode, eps);
     return pd_check_launch();
 }
@@ -141,7 +151,7 @@ PD_EXPORT int pd_pair_bias(const float* x, const float* Wf, const float* c2, flo
     if (out_scale == 0.f) out_scale = 1.f;
     hipStream_t s = (hipStream_t)stream;
 #define PD_PB(LPR, HH) if (C == 4 * LPR && H == HH) \
-        return launch<LPR, HH>(x, Wf, c2, stats_out, maskadd, maskval, out_scale, frag, M, T1, T2, frag_transpose, mode, eps, s);
+        return launch<LPR, HH, (LPR == 32 ? PD_PB_TR : 64)>(x, Wf, c2, stats_out, maskadd, maskval, out_scale, frag, M, T1, T2, frag_transpose, mode, eps, s);
     PD_PB(32, 4) PD_PB(32, 8) PD_PB(32, 16) PD_PB(4, 4) PD_PB(4, 24)
 #undef PD_PB
     return PD_ERR_UNSUPPORTED;

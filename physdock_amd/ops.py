@@ -109,10 +109,9 @@ def rownorm(x, y, M, Cdim, *, res=None, w=None, b=None, mode=RMS, eps=1e-8, act=
 
 
 #: (C, H) combinations pd_pair_bias is instantiated for, and the ones where it beats rowstats + GEMM on MI355X
-#: (tools/kbench.py --pair-bias: z H=4 21 vs 26 us; ap H=4 98 vs 547 us, H=24 330 vs 640 us; z H=16 44 vs 28 us - the 32-lane
-#: DPP reduction per head is the cost, so the wide-head z biases stay on the GEMM)
+#: (tools/kbench.py --pair-bias: z H=4 10 vs 26 us, H=8 14 vs 27, H=16 22 vs 29; ap H=4 101 vs 549 us, H=24 354 vs 639 us)
 PAIR_BIAS_SHAPES = {(128, 4), (128, 8), (128, 16), (16, 4), (16, 24)}
-PAIR_BIAS_FASTER = {(128, 4), (16, 4), (16, 24)}
+PAIR_BIAS_FASTER = {(128, 4), (128, 8), (128, 16), (16, 4), (16, 24)}
 
 
 def pair_bias(x, Wf, frag, T1, T2, Cdim, H, *, c2=None, stats_out=None, maskadd=None, maskval=0.0, out_scale=1.0,

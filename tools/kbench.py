@@ -66,7 +66,7 @@ if __name__ == "__main__" and "--pair-bias" not in sys.argv:
 def bench_pair_bias():
     import torch
     from physdock_amd import ops
-    for (C, H, T, tag) in [(128, 4, 256, "z tri"), (128, 16, 256, "z single"), (16, 4, 2048, "ap trunk"), (16, 24, 2048, "ap dit")]:
+    for (C, H, T, tag) in [(128, 4, 256, "z tri"), (128, 8, 256, "z msa row"), (128, 16, 256, "z single"), (16, 4, 2048, "ap trunk"), (16, 24, 2048, "ap dit")]:
         M = T * T
         x = torch.randn(M, C, device="cuda"); Wf = torch.randn(H, C, device="cuda"); mask = torch.ones(M, device="cuda")
         frag = torch.zeros(ops.bias_frag_numel(H, T, T), device="cuda"); st = torch.empty(M, 2, device="cuda")
