@@ -57,7 +57,7 @@ def build(force=False, verbose=True):
             cmd[1:1] = ["-DPD_GEMM_NOSTORE=1"]
         if os.environ.get("PD_ABL") and os.path.basename(src) == "gemm_split.hip":      # lab: main-loop ablations (wrong results)
             cmd[1:1] = ["-DPD_ABL=" + os.environ["PD_ABL"]]
-        for knob in ("PD_PB_UB", "PD_PB_TR"):
+        for knob in ("PD_PB_UB", "PD_PB_TR", "PD_PB_TR4"):
             if os.environ.get(knob) and os.path.basename(src) == "pairbias.hip":
                 cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
         if os.environ.get("PD_KSPLIT_MAX_BYTES") and os.path.basename(src) == "gemm_stream.hip":

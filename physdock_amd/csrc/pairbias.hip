@@ -19,6 +19,9 @@
 #ifndef PD_PB_TR
 #define PD_PB_TR 8
 #endif
+#ifndef PD_PB_TR4
+#define PD_PB_TR4 32
+#endif
 
 namespace {
 
@@ -151,7 +154,7 @@ PD_EXPORT int pd_pair_bias(const float* x, const float* Wf, const float* c2, flo
     if (out_scale == 0.f) out_scale = 1.f;
     hipStream_t s = (hipStream_t)stream;
 #define PD_PB(LPR, HH) if (C == 4 * LPR && H == HH) \
-        return launch<LPR, HH, (LPR == 32 ? PD_PB_TR : 64)>(x, Wf, c2, stats_out, maskadd, maskval, out_scale, frag, M, T1, T2, frag_transpose, mode, eps, s);
+        return launch<LPR, HH, (LPR == 32 ? PD_PB_TR : PD_PB_TR4)>(x, Wf, c2, stats_out, maskadd, maskval, out_scale, frag, M, T1, T2, frag_transpose, mode, eps, s);
     PD_PB(32, 4) PD_PB(32, 8) PD_PB(32, 16) PD_PB(4, 4) PD_PB(4, 24)
 #undef PD_PB
     return PD_ERR_UNSUPPORTED;

@@ -1,6 +1,6 @@
 #!/bin/bash
-# lab: rows per wave tile of pd_pair_bias for C = 128 (PD_PB_TR)
+# lab: rows per wave tile of pd_pair_bias: PD_PB_TR (C = 128), PD_PB_TR4 (C = 16)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for u in 64 32 16 8; do PD_PB_TR=$u python -m physdock_amd.build --force >/dev/null 2>&1; echo "TR=$u"; python tools/kbench.py --pair-bias 2>&1 | grep "pair_bias z"; done
+KNOB=${1:-PD_PB_TR4}
+for u in ${2:-64 32 16}; do env $KNOB=$u python -m physdock_amd.build --force >/dev/null 2>&1; echo "$KNOB=$u"; python tools/kbench.py --pair-bias 2>&1 | grep "pair_bias"; done
 python -m physdock_amd.build --force >/dev/null 2>&1
-python -m pytest tests/test_round2_gpu.py -q -k pair_bias 2>&1 | grep -E "passed|failed"
