@@ -338,6 +338,24 @@ def main():
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 3
             extra[f"samples_{Bx}"] = {"poses_per_s": Bx / dt, "ms_per_call": 1e3 * dt}
+        # BASELINE config #5 (screening_demo.sh: 20 samples per round, 40 kept, ranking, PDB output) for ONE ligand through the
+        # whole device-side flow: driver.redock = 2 rounds x (trunk + 40 steps at B=20) + template re-selection + alignment +
+        # ranking + PDB text of the 40 kept poses; 10 k ligands are independent systems (parallel.map_systems shards them)
+        from physdock_amd import driver
+        from physdock_amd.synthetic import pdb_meta
+        meta = pdb_meta({k: batch[k].numpy() for k in ("token_id_to_chunk_sizes", "asym_id", "is_ligand", "residue_index")})
+        rk = dict(ref_mol_poses=confs.to(device), physics_correction=True, max_samples=40, max_rounds=2, num_samples_per_round=20,
+                  steps=nsteps, karras_noise_schedule_power=1000, ranking=True, infer_meta_data=meta)
+        driver.redock(model, dbatch, seed=5, **rk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2):
+            res = driver.redock(model, dbatch, seed=6 + i, **rk)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        extra["screening_ligand"] = {"ligands_per_s": 1.0 / dt, "ms_per_ligand": 1e3 * dt, "rounds": len(res["rounds"]),
+                                     "samples_per_round": 20, "poses_kept": int(res["poses"].shape[0]),
+                                     "pdb_blocks": len(res["pdb_blocks"])}
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, P, batch, confs, args)
