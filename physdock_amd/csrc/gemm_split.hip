@@ -14,13 +14,16 @@
 // Structure = gemm_stream.hip (persistent blocks, XCD-aware tile order, norm prologue applied while staging A,
 // compile-time specialised epilogues straight from the accumulator fragments - the C fragment layout of the bf16 MFMA is
 // the same 32 x 32 layout, so gemm_tile_common.h is shared).  What differs:
-//   * W arrives PRE-SPLIT (packing.py: [3][N][Kp] bf16, Kp = K rounded up to 32, zero padded) - weights are constants;
-//   * A is split while it is staged: global fp32 -> registers -> (norm prologue) -> 3 x bf16 -> LDS;
-//   * LDS holds two stages of 16 k (one MFMA k-step) = one 32-k slice; rows are 48 bytes apart so that a ds_read_b128
-//     fragment read (row = lane & 31, 16 bytes at 16 * (lane >> 5)) is bank-conflict free (3 r mod 16 is a bijection on
-//     each of the instruction's 16-lane groups);
-//   * the next 32-k slice is requested from global memory before the MFMA block of the first stage and written into a
-//     stage right after every wave has finished reading it (LDS-only barriers: no vmcnt drain).
+//   * W arrives PRE-SPLIT and FRAGMENT-MAJOR (packing.split3_bf16: [3][N/32][Kp/16][64 lanes][8] bf16, Kp = K rounded up to
+//     32, zero padded) - weights are constants.  In the "direct W" tiles (struct STile, DW) a wave fetches its B fragments
+//     with one coalesced 16-byte load per lane straight into MFMA registers, one k-step ahead; W never touches LDS;
+//   * A is split while it is staged: global fp32 -> registers -> (norm prologue) -> 3 x bf16 -> LDS, two values per packed
+//     conversion;
+//   * DW tiles: an LDS stage holds a whole 32-k slice of A (80-byte rows: conflict-free ds_read_b128 fragments), two stages,
+//     ONE block barrier per slice.  The GLU tile (two B fragments per wave: no register room for direct buffers) keeps the
+//     first version of the loop: A and W through LDS in 16-k stages (48-byte rows), two barriers per slice;
+//   * the next slice is requested from global memory before the MFMA block and written to the other stage after it
+//     (LDS-only barriers: no vmcnt drain).
 #include <stdlib.h>
 #include "gemm_tile_common.h"
 
