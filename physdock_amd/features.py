@@ -60,13 +60,16 @@ def chain_runs(atom_asym):
     return atom_asym[starts].tolist(), starts + [int(atom_asym.size)]
 
 
-def token_bonds(x_gt, a_mask, atom_id_to_token_id, token_bonds_in, asym_id, is_ligand, threshold=2.4, return_search=False):
+def token_bonds(x_gt, a_mask, atom_id_to_token_id, token_bonds_in, asym_id, is_ligand, threshold=2.4, return_search=False,
+                a2t_host=None):
     """`_make_token_bonds` (feature_loader.py:853-911): token_bonds + the bonds found between every pair of chains of which
     at least one is a ligand.  x_gt [A,3], a_mask [A], atom_id_to_token_id [A] int64, token_bonds_in [T,T] on the device;
-    asym_id / is_ligand [T] host arrays (they only shape the launch)."""
+    asym_id / is_ligand [T] (and optionally a2t_host [A], saving a device -> host copy) host arrays: they only shape the launch."""
     import numpy as np
     dev = x_gt.device
-    a2t_host = atom_id_to_token_id.cpu().numpy() if isinstance(atom_id_to_token_id, torch.Tensor) else np.asarray(atom_id_to_token_id)
+    if a2t_host is None:
+        a2t_host = atom_id_to_token_id.cpu().numpy() if isinstance(atom_id_to_token_id, torch.Tensor) else np.asarray(atom_id_to_token_id)
+    a2t_host = np.asarray(a2t_host)
     asym_id, is_ligand = np.asarray(asym_id), np.asarray(is_ligand)
     ids, starts = chain_runs(asym_id[a2t_host])
     lig = [bool(is_ligand[a2t_host[s]]) for s in starts[:-1]]
@@ -129,7 +132,7 @@ def transform(raw_feats: dict, device, max_msa_clusters: int = 128, token_bond_t
         t.pop(k, None)
     # ---- _make_token_bonds (:853-911)
     t["token_bonds"] = token_bonds(t["x_gt"], t["a_mask"], t["atom_id_to_token_id"], t["token_bonds"], raw_feats["asym_id"],
-                                   raw_feats["is_ligand"], token_bond_threshold)
+                                   raw_feats["is_ligand"], token_bond_threshold, a2t_host=raw_feats["atom_id_to_token_id"])
     # ---- masks (:982-985)
     t["z_mask"] = outer_mask(t["s_mask"])
     t["ap_mask"] = outer_mask(t["a_mask"])
