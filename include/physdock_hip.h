@@ -36,6 +36,9 @@ typedef struct pd_gemm_args {
                                 shapes, the contraction runs as six bf16 MFMAs per block with fp32 accumulation
                                 (csrc/gemm_split.hip: at least the accuracy of the fp32 MFMA, 2.67x its peak rate); W must
                                 still be valid (ragged row remainders and ineligible shapes use it).  NULL: fp32 MFMA.   */
+    const void* A3;          /* optional: A already normalised and split into three bf16 parts [3][M][K] (pd_norm_split); K % 32
+                                == 0, no prologue fields.  Only the split-operand kernel reads it: a launch that cannot run there
+                                (no W3, ragged rows, too few tiles) returns PD_ERR_UNSUPPORTED instead of using the raw A.      */
     float* Y;
     int M, N, K;
     int lda, ldw, ldy;
@@ -97,6 +100,14 @@ int pd_rowstats(const float* x, float* stats, int M, int C, int ldx, int kmajor,
 /* ---- pd_rownorm: y = [res +] act(norm(x) * w + b) (standalone normalisation)            */
 int pd_rownorm(const float* x, float* y, const float* res, const float* w, const float* b,
                int M, int C, int mode, float eps, int act, void* stream);
+
+/* ---- pd_norm_split: rows normalised, modulated and split for pd_gemm_args.A3 -----------------
+ * out3 [3][M][C] bf16 (hi, mid, lo: a' = hi + mid + lo exactly) of a'[m,k] = (x[m,k] - mean_m) rstd_m w[g][k] + b[g][k],
+ * g = m / rows_per_group (0: one row of w / b for all; NULL w / b: 1 / 0) - the expression of pd_gemm's norm prologue
+ * (rms_norm.py:14-19, adaptive_layer_norm_zero.py:16-21) evaluated ONCE per element instead of once per column block of
+ * the GEMM that consumes it.  C % 32 == 0.                                                                            */
+int pd_norm_split(const float* x, int ldx, int M, int C, int mode, float eps, const float* w, const float* b,
+                  int rows_per_group, int gstride, void* out3, void* stream);
 
 /* ---- pd_pair_bias: attention pair bias in one streaming pass (pairbias.hip) -------------------
  * frag = fragment layout of [ (norm(x) . Wf^T + c2 + maskadd ? 0 : maskval) * out_scale ] for x [T1*T2, C] (C = 16 or 128),

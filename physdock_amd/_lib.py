@@ -40,7 +40,7 @@ def header_symbols():
 
 class GemmArgs(C.Structure):
     _fields_ = [
-        ("A", _fp), ("W", _fp), ("W3", _fp), ("Y", _fp),
+        ("A", _fp), ("W", _fp), ("W3", _fp), ("A3", _fp), ("Y", _fp),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("lda", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int),
         ("batch", C.c_int),
@@ -118,6 +118,7 @@ def _declare(L):
     sig("pd_gemm_variant", C.POINTER(GemmArgs))
     sig("pd_rowstats", p, p, i, i, i, i, i, f, p)
     sig("pd_rownorm", p, p, p, p, p, i, i, i, f, i, p)
+    sig("pd_norm_split", p, i, i, i, i, f, p, p, i, i, p, p)
     sig("pd_pair_bias", p, p, p, p, p, f, f, p, i, i, i, i, i, i, f, p)
     sig("pd_attention", C.POINTER(AttnArgs), p)
     sig("pd_attention_variant", C.POINTER(AttnArgs))
@@ -164,7 +165,7 @@ def _declare(L):
 def ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8, torch.bfloat16), (t.device, t.dtype)
     return t.data_ptr()
 
 

@@ -674,6 +674,8 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
+    if (p.A3)            // pre-split A: only the split-operand kernel can read it; anything else is an error, never the raw A
+        return pd_gemm_split_try(&p, pro, 128, stream, 0);
     if (use_stream() && stream_tile(cfg, p)) {
         pd_gemm_args head, tail;
         const int tile = stream_tile(cfg, p);

@@ -114,6 +114,12 @@ void gemm_split_kernel(const pd_gemm_args p) {
 
     const int a_row = tid / TPR_A, a_q = tid % TPR_A;
     const int w_row = tid / TPR_W, w_q = tid % TPR_W;
+    // PRO == 3: A arrives pre-split (pd_norm_split, [3][M][Kp] bf16): a thread copies one 16-byte chunk (8 k) per part
+    constexpr bool AS = PRO == 3;
+    static_assert(!AS || TPR_A == 4, "pre-split A: four 8-k chunks per row slice");
+    const __bf16* __restrict__ A3 = reinterpret_cast<const __bf16*>(p.A3);
+    const long long apart = (long long)p.M * (nk * 32);
+    bf16x8 ra3[3];
     f32x4 ra[2][CPH_A];                          // [half][i]: chunk 4*half + a_q + TPR_A*i of the thread's row
     bf16x8 rw[3][NW];                            // [part][i]: NW == 2 -> chunk w_q + 2 i (half i); NW == 1 -> chunk w_q (half w_q >> 1)
 
@@ -122,9 +128,14 @@ void gemm_split_kernel(const pd_gemm_args p) {
         if (k0 != 0) return;                      // ablation: no A traffic inside a tile
 #endif
         const int r = bm0 + a_row;                // full tiles only: always < M
+        if constexpr (AS) {
+            const __bf16* ap3 = A3 + (long long)r * (nk * 32) + k0 + 8 * a_q;
+#pragma unroll
+            for (int part = 0; part < 3; ++part) ra3[part] = *reinterpret_cast<const bf16x8*>(ap3 + part * apart);
+        }
         const float* ap = p.A + (long long)r * p.lda + k0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < (AS ? 0 : 2); ++h)
 #pragma unroll
             for (int i = 0; i < CPH_A; ++i) {
                 int kc = 16 * h + 4 * (a_q + TPR_A * i);
@@ -187,7 +198,7 @@ void gemm_split_kernel(const pd_gemm_args p) {
         // prologue state of the one A row this thread stages
         float st_mean = 0.f, st_rstd = 1.f;
         int grp_off = 0;
-        if constexpr (PRO != 0) {
+        if constexpr (PRO != 0 && !AS) {
             const int m = bm0 + a_row;
             st_mean = p.stats[2 * (long long)m];
             st_rstd = p.stats[2 * (long long)m + 1];
@@ -195,8 +206,15 @@ void gemm_split_kernel(const pd_gemm_args p) {
         }
         // norm prologue + k-tail zeroing + split + LDS store of one 16-k half of the slice held in ra / rw
         auto stage = [&](int h, int k0) {
+            if constexpr (AS) {
+                if ((a_q >> 1) == h) {
 #pragma unroll
-            for (int i = 0; i < CPH_A; ++i) {
+                    for (int part = 0; part < 3; ++part)
+                        *reinterpret_cast<bf16x8*>(sA(h, part) + a_row * PITCH + 8 * (a_q & 1)) = ra3[part];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < (AS ? 0 : CPH_A); ++i) {
                 const int c = a_q + TPR_A * i;                    // chunk inside the half
                 const int kc = k0 + 16 * h + 4 * c;
                 f32x4 v = ra[h][i];
@@ -261,8 +279,12 @@ void gemm_split_kernel(const pd_gemm_args p) {
         // ---- DW variants: the whole 32-k slice in ra goes to LDS stage s; fragments of k-step ks come from there and from wf[ks]
         auto stage2 = [&](int s, int k0) {
             __bf16* base = lds + s * TL::STAGE + a_row * PITCH2;
+            if constexpr (AS) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int part = 0; part < 3; ++part) *reinterpret_cast<bf16x8*>(base + part * BM * PITCH2 + 8 * a_q) = ra3[part];
+            }
+#pragma unroll
+            for (int h = 0; h < (AS ? 0 : 2); ++h)
 #pragma unroll
                 for (int i = 0; i < CPH_A; ++i) {
                     const int c = a_q + TPR_A * i;
@@ -399,6 +421,7 @@ int dispatch_split(int op, int pro, int epi, int tile, const pd_gemm_args* p, hi
     PD_SCASE(1, EPI_HN, 128, S128) PD_SCASE(2, EPI_HN, 128, S128)
     PD_SCASE(1, EPI_GLU, 128, S128G) PD_SCASE(2, EPI_GLU, 128, S128G) PD_SCASE(1, EPI_GLUT, 128, S128G)
     PD_SCASE(0, EPI_GATERES, 128, S128) PD_SCASE(0, EPI_TGATERES, 128, S128)
+    PD_SCASE(3, EPI_PLAIN, 128, S128) PD_SCASE(3, EPI_HN, 128, S128) PD_SCASE(3, EPI_GLU, 128, S128G)      // pre-split A
     PD_SCASE(0, EPI_PLAIN, 64, S64) PD_SCASE(1, EPI_PLAIN, 64, S64)
     PD_SCASE(1, EPI_HN, 64, S64) PD_SCASE(2, EPI_HN, 64, S64)
     PD_SCASE(0, EPI_GATERES, 64, S64) PD_SCASE(0, EPI_TGATERES, 64, S64)
@@ -419,7 +442,7 @@ extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, vo
     if (init_only == 1) {
         int rc = PD_OK;
         for (int T : {128, 64, 12864})
-            for (int P = 0; P < 3; ++P)
+            for (int P = 0; P < 4; ++P)
                 for (int E = 0; E < 6; ++E) {
                     const int r = dispatch_split(1, P, E, T, nullptr, nullptr);
                     if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
@@ -428,6 +451,10 @@ extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, vo
     }
     const pd_gemm_args& p = *args;
     if (!p.W3 || p.K % 4 != 0) return PD_ERR_UNSUPPORTED;
+    if (p.A3) {                                  // pre-split A: whole 32-k slices, 16-byte aligned, prologue already applied
+        if (pro != 0 || p.pro_act != PD_ACT_NONE || p.K % 32 != 0 || ((uintptr_t)p.A3 & 15) || tile != 128) return PD_ERR_UNSUPPORTED;
+        pro = 3;
+    }
 #ifdef PD_LAB
     if (const char* f = getenv("PD_SPLIT_TILE")) { if (tile == 128) tile = atoi(f); }
     if (tile == 1284 || tile == 1282) {

@@ -14,11 +14,14 @@ namespace {
 constexpr int MAXV = 4;   // float4 per lane: C <= LPR*16
 
 // LPR lanes cooperate on one row; rows are packed 64/LPR per wave, 4 waves per block.
-template <int LPR, bool WRITE>
+// WRITE: 0 statistics only, 1 normalised fp32 rows, 2 normalised + modulated rows as THREE bf16 parts (error-free split,
+// out3 = [3][M][C]: the pre-split A operand of csrc/gemm_split.hip, so that its staging is a plain copy)
+template <int LPR, int WRITE>
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                      float* __restrict__ y, const float* __restrict__ res,
                                                      const float* __restrict__ w, const float* __restrict__ b,
-                                                     int M, int C, int ldx, int mode, float eps, int act) {
+                                                     int M, int C, int ldx, int mode, float eps, int act,
+                                                     int rows_per_group = 0, int gstride = 0) {
     constexpr int RPB = 256 / LPR;
     const int sub = threadIdx.x % LPR;
     const long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
@@ -55,8 +58,32 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
         rstd = rsqrtf(q / (float)C + eps);
     }
     if (!ok) return;
-    if constexpr (!WRITE) {
+    if constexpr (WRITE == 0) {
         if (sub == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    } else if constexpr (WRITE == 2) {
+        // a' = (x - mean) rstd w[g][k] + b[g][k], g = row / rows_per_group: the GEMM prologue's expression, then the 3-way split
+        // (8-byte stores per part; pairing chunks into 16-byte stores measured slower: 27 -> 43 us at [16384, 512])
+        const long long goff = rows_per_group > 0 ? (row / rows_per_group) * (long long)gstride : 0;
+        unsigned short* out = reinterpret_cast<unsigned short*>(y);          // bf16 [3][M][C]
+        const long long part = (long long)M * C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = sub + i * LPR;
+            if (c >= nchunk) continue;
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                t[e] = (v[i][e] - mean) * rstd;
+                if (w) t[e] = t[e] * w[goff + c * 4 + e];
+                if (b) t[e] = t[e] + b[goff + c * 4 + e];
+            }
+            const pd_parts p0 = pd_split2(t[0], t[1]), p1 = pd_split2(t[2], t[3]);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            unsigned short* o = out + row * (long long)C + c * 4;
+            *reinterpret_cast<u32x2*>(o) = u32x2{p0.h, p1.h};
+            *reinterpret_cast<u32x2*>(o + part) = u32x2{p0.m, p1.m};
+            *reinterpret_cast<u32x2*>(o + 2 * part) = u32x2{p0.l, p1.l};
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
@@ -97,9 +124,9 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     stats[2 * m] = mean; stats[2 * m + 1] = rstd;
 }
 
-template <bool WRITE>
+template <int WRITE>
 int dispatch(const float* x, float* stats, float* y, const float* res, const float* w, const float* b,
-             int M, int C, int ldx, int mode, float eps, int act, hipStream_t s) {
+             int M, int C, int ldx, int mode, float eps, int act, hipStream_t s, int rows_per_group = 0, int gstride = 0) {
     if (C % 4 != 0 || ldx % 4 != 0 || ((uintptr_t)x & 15)) return PD_ERR_UNSUPPORTED;
     const int nchunk = C / 4;
     // lanes per row = min(64, pow2 >= C/4): one float4 per lane while the row fits a wave
@@ -110,7 +137,7 @@ int dispatch(const float* x, float* stats, float* y, const float* res, const flo
     {                                                                                              \
         const int rpb = 256 / L;                                                                   \
         hipLaunchKernelGGL((rownorm_kernel<L, WRITE>), dim3((M + rpb - 1) / rpb), dim3(256), 0, s, \
-                           x, stats, y, res, w, b, M, C, ldx, mode, eps, act);                     \
+                           x, stats, y, res, w, b, M, C, ldx, mode, eps, act, rows_per_group, gstride); \
     }
     switch (lpr) {
         case 4: PD_LAUNCH(4) break;
@@ -134,11 +161,19 @@ PD_EXPORT int pd_rowstats(const float* x, float* stats, int M, int C, int ldx, i
                            mode, eps);
         return pd_check_launch();
     }
-    return dispatch<false>(x, stats, nullptr, nullptr, nullptr, nullptr, M, C, ldx, mode, eps, 0, s);
+    return dispatch<0>(x, stats, nullptr, nullptr, nullptr, nullptr, M, C, ldx, mode, eps, 0, s);
 }
 
 PD_EXPORT int pd_rownorm(const float* x, float* y, const float* res, const float* w, const float* b, int M, int C,
                          int mode, float eps, int act, void* stream) {
     if (!x || !y || M <= 0 || C <= 0) return PD_ERR_ARG;
-    return dispatch<true>(x, nullptr, y, res, w, b, M, C, C, mode, eps, act, (hipStream_t)stream);
+    return dispatch<1>(x, nullptr, y, res, w, b, M, C, C, mode, eps, act, (hipStream_t)stream);
+}
+
+PD_EXPORT int pd_norm_split(const float* x, int ldx, int M, int C, int mode, float eps, const float* w, const float* b,
+                            int rows_per_group, int gstride, void* out3, void* stream) {
+    if (!x || !out3 || M <= 0 || C <= 0) return PD_ERR_ARG;
+    if (C % 32 != 0 || ((uintptr_t)out3 & 15)) return PD_ERR_UNSUPPORTED;      // rows of whole 32-k slices, 16-byte aligned
+    return dispatch<2>(x, nullptr, reinterpret_cast<float*>(out3), nullptr, w, b, M, C, ldx, mode, eps, 0, (hipStream_t)stream,
+                       rows_per_group, gstride);
 }

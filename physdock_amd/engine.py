@@ -73,9 +73,9 @@ class Engine:
             ksw = self.ws.get("gemm_ksplit", 9 << 20)
         ops.gemm(A, W, Y, M, N, K, W3=w3, ksplit_ws=ksw, **kw)
 
-    def lws(self, name, *shape):
+    def lws(self, name, *shape, dtype=torch.float32):
         """lane-private scratch: concurrent sample lanes never share a DiT intermediate"""
-        return self.ws.get(f"{name}@{self.lane}", *shape)
+        return self.ws.get(f"{name}@{self.lane}", *shape, dtype=dtype)
 
     def stats(self, x, M, C, mode, eps, name="stats", kmajor=False, ldx=None):
         st = self.ws.get(f"{name}@{self.lane}", M, 2)
@@ -452,11 +452,21 @@ class Engine:
         H = C // 32
         grp = dict(pro_rows_per_group=N, pro_gstride=tab_ld) if per_sample else {}
         mgrp = dict(mul_rows_per_group=N if per_sample else rows, mul_gstride=tab_ld if per_sample else 0)
-        st = self.stats(x, rows, C, LN, eps)
+        # wide rows (token DiT, C = 512) in chip-filling launches: AdaLN-normalise and split the activations ONCE
+        # (pd_norm_split) instead of in every column block of the projection that consumes them (12 / 22 of them)
+        presplit = ops.SPLIT_GEMM and ops.PRESPLIT_GEMM and C >= 256 and C % 32 == 0 and rows % 128 == 0 and (rows // 128) * (3 * C // 128) >= 256
+        a3 = self.lws("dit_a3", 3, rows, C, dtype=torch.bfloat16) if presplit else None
+        ng = dict(rows_per_group=N if per_sample else 0, gstride=tab_ld if per_sample else 0)
         qkv = self.lws("dit_qkv", rows, 3 * C)
-        self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
-                 pro_w=off(tab, tab_off + C), hn_w=P.headnorm(prefix + ".attention"), hn_cols=2 * C, hn_split=C,
-                 hn_eps=eps, **grp)
+        if presplit and ops.PRESPLIT_QKV:
+            ops.norm_split(x, a3, rows, C, mode=LN, eps=eps, b=off(tab, tab_off), w=off(tab, tab_off + C), **ng)
+            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, A3=a3, hn_w=P.headnorm(prefix + ".attention"),
+                      hn_cols=2 * C, hn_split=C, hn_eps=eps)
+        else:
+            st = self.stats(x, rows, C, LN, eps)
+            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
+                      pro_w=off(tab, tab_off + C), hn_w=P.headnorm(prefix + ".attention"), hn_cols=2 * C, hn_split=C,
+                      hn_eps=eps, **grp)
         o = self.lws("dit_o", rows, C)
         st3 = (N * 3 * C, 3 * C)
         ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, nq=N, nk=nk, nbatch=B, nheads=H,
@@ -464,11 +474,15 @@ class Engine:
                       ws=self.attn_ws(B, N, nk, H))
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)
-        st = self.stats(x, rows, C, LN, eps)
         W13, hidden = P.glu(prefix + ".transition.feed_forward")
         h = self.lws("dit_h", rows, hidden)
         o2 = tab_off + 3 * C
-        self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, o2), pro_w=off(tab, o2 + C), glu=1, **grp)
+        if presplit:
+            ops.norm_split(x, a3, rows, C, mode=LN, eps=eps, b=off(tab, o2), w=off(tab, o2 + C), **ng)
+            self.gemm(x, W13, h, rows, 2 * hidden, C, A3=a3, glu=1)
+        else:
+            st = self.stats(x, rows, C, LN, eps)
+            self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, o2), pro_w=off(tab, o2 + C), glu=1, **grp)
         W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
         self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, o2 + 2 * C), res=x, **mgrp)
 

@@ -1,0 +1,84 @@
+"""Pre-split A operand of the split GEMM (pd_norm_split -> pd_gemm_args.A3): the norm prologue and the 3-way bf16 split of
+the activations evaluated once per element instead of once per column block.  GPU only."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(M, C, G, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, C, generator=g) * 1.7 + 0.3
+    tab = torch.randn(G, 2 * C, generator=g) * 0.3 + 1          # [shift | scale] per sample group
+    return x, tab
+
+
+def test_norm_split_is_an_exact_decomposition_of_the_prologue():
+    from physdock_amd import ops
+    M, C, G = 1024, 512, 4
+    x, tab = _setup(M, C, G, 1)
+    xd, td = x.cuda(), tab.cuda()
+    out3 = torch.empty(3, M, C, dtype=torch.bfloat16, device="cuda")
+    ops.norm_split(xd, out3, M, C, mode=ops.LN, eps=1e-5, b=td, w=td.data_ptr() + 4 * C, rows_per_group=M // G, gstride=2 * C)
+    got = out3.float().sum(0).cpu()                                   # hi + mid + lo, exact in fp32
+    xn = F.layer_norm(x, (C,), None, None, 1e-5).reshape(G, M // G, C) * tab[:, None, C:] + tab[:, None, :C]
+    torch.testing.assert_close(got, xn.reshape(M, C), rtol=2e-6, atol=2e-6)
+    # RMS mode, one gain row, no shift
+    w = 1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(2))
+    ops.norm_split(xd, out3, M, C, mode=ops.RMS, eps=1e-8, w=w.cuda())
+    want = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-8) * w
+    torch.testing.assert_close(out3.float().sum(0).cpu(), want, rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("kind", ["qkv_headnorm", "swiglu"])
+def test_presplit_gemm_matches_the_prologue_gemm(kind):
+    from physdock_amd import ops
+    from physdock_amd.packing import pack_glu, split3_bf16
+    M, C, G = 128 * 64, 512, 8
+    x, tab = _setup(M, C, G, 3)
+    g = torch.Generator().manual_seed(4)
+    xd, td = x.cuda(), tab.cuda()
+    st = torch.empty(M, 2, device="cuda")
+    ops.rowstats(xd, st, M, C, mode=ops.LN, eps=1e-5)
+    grp = dict(stats=st, pro_b=td, pro_w=td.data_ptr() + 4 * C, pro_rows_per_group=M // G, pro_gstride=2 * C)
+    out3 = torch.empty(3, M, C, dtype=torch.bfloat16, device="cuda")
+    ops.norm_split(xd, out3, M, C, mode=ops.LN, eps=1e-5, b=td, w=td.data_ptr() + 4 * C, rows_per_group=M // G, gstride=2 * C)
+    if kind == "qkv_headnorm":
+        N = 3 * C
+        W = (torch.randn(N, C, generator=g) / C ** 0.5).cuda()
+        hw = (1 + 0.1 * torch.randn(2, 32, generator=g)).cuda()
+        kw = dict(hn_w=hw, hn_cols=2 * C, hn_split=C, hn_eps=1e-8)
+        Nout = N
+    else:
+        Hd = 1408
+        W1, W3_ = torch.randn(Hd, C, generator=g) / C ** 0.5, torch.randn(Hd, C, generator=g) / C ** 0.5
+        W = pack_glu(W1, W3_)[0].cuda()
+        N, Nout, kw = 2 * Hd, Hd, dict(glu=1)
+    W3 = split3_bf16(W)
+    Y0, Y1 = torch.empty(M, Nout, device="cuda"), torch.empty(M, Nout, device="cuda")
+    seen = []
+    import ctypes as C_
+    ops.GEMM_HOOK = lambda a, launch: (seen.append(ops._lib.init().pd_gemm_variant(C_.byref(a))), launch())
+    try:
+        ops.gemm(xd, W, Y0, M, N, C, W3=W3, **grp, **kw)
+    finally:
+        ops.GEMM_HOOK = None
+    assert seen[0] >= 1000000                                       # the reference run is the split kernel with the prologue
+    ops.gemm(xd, W, Y1, M, N, C, W3=W3, A3=out3, **kw)
+    torch.testing.assert_close(Y1, Y0, rtol=3e-5, atol=3e-5)
+    assert torch.isfinite(Y1).all() and float(Y1.abs().max()) > 0.1
+
+
+def test_presplit_operand_is_never_silently_ignored():
+    from physdock_amd import ops
+    from physdock_amd.packing import split3_bf16
+    M, C = 256, 512                                               # far too few tiles for the split kernel
+    x = torch.randn(M, C, device="cuda")
+    W = torch.randn(512, C, device="cuda")
+    out3 = torch.empty(3, M, C, dtype=torch.bfloat16, device="cuda")
+    ops.norm_split(x, out3, M, C)
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, W, torch.empty(M, 512, device="cuda"), M, 512, C, W3=split3_bf16(W), A3=out3)
+    with pytest.raises(RuntimeError):                              # no split weights at all
+        ops.gemm(x.repeat(64, 1), W, torch.empty(64 * M, 512, device="cuda"), 64 * M, 512, C, A3=out3.repeat(1, 64, 1))
