@@ -82,3 +82,27 @@ def test_presplit_operand_is_never_silently_ignored():
         ops.gemm(x, W, torch.empty(M, 512, device="cuda"), M, 512, C, W3=split3_bf16(W), A3=out3)
     with pytest.raises(RuntimeError):                              # no split weights at all
         ops.gemm(x.repeat(64, 1), W, torch.empty(64 * M, 512, device="cuda"), 64 * M, 512, C, A3=out3.repeat(1, 64, 1))
+
+
+def test_per_sample_adaln_tables_through_the_presplit_path():
+    """forward() (training-time API, 48 noise levels = 48 AdaLN table rows): the token DiT takes the pre-split path with one
+    table row per sample; same result as the prologue path"""
+    from physdock_amd import PhysDock, PhysDockConfig, ops, param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import cfg1_batch
+    cfg = PhysDockConfig(model_name="medium")
+    model = PhysDock(cfg)
+    model.load_state_dict(seeded_state_dict(param_shapes(cfg), seed=0), strict=True)
+    model = model.cuda().eval()
+    dbatch = {k: v.cuda() for k, v in cfg1_batch(0).items()}
+    outs = []
+    try:
+        for flag in (True, False):
+            ops.PRESPLIT_GEMM = flag
+            torch.manual_seed(11)
+            outs.append(model(dbatch)["x_denoised"].cpu())
+    finally:
+        ops.PRESPLIT_GEMM = True
+    assert outs[0].shape[0] == cfg.model.num_augmentation_sample and torch.isfinite(outs[0]).all()
+    assert not torch.equal(outs[0], outs[1])                       # two different kernels ...
+    rel = float((outs[0] - outs[1]).abs().max() / outs[1].abs().max())
+    assert rel < 2e-5, rel                                         # ... the same arithmetic up to rounding order
