@@ -60,20 +60,32 @@ def test_ref_mol_without_a_way_to_relax_raises(small):
 
 
 # ------------------------------------------------------------------ G9: the reference itself at the benchmark shapes
-@pytest.mark.parametrize("tag", ["cfg1", "ragged", "cfg2"])
+@pytest.mark.parametrize("tag", ["cfg1", "ragged", "cfg2", "cfg1_b16"])
 def test_medium_trajectories_vs_reference(medium, tag):
     """north_star bar at full size, against the reference (not the oracle): final coordinates within 1e-3 A RMSD with
     the same seeded weights, synthetic crop and recorded noise"""
     from physdock_amd.synthetic import cfg1_batch, cfg2_batch, make_batch, toy_relax_fn
     g = load_golden(f"g9_medium_{tag}")
-    batch = {"cfg1": lambda: cfg1_batch(0), "ragged": lambda: make_batch(221, 8, 35, 64, 2), "cfg2": lambda: cfg2_batch(0)}[tag]()
+    batch = {"cfg1": lambda: cfg1_batch(0), "ragged": lambda: make_batch(221, 8, 35, 64, 2), "cfg2": lambda: cfg2_batch(0),
+             "cfg1_b16": lambda: cfg1_batch(0)}[tag]()
     nz = golden_noise(g)
     B = nz["init"].shape[0]
     kw = dict(num_sample=B, steps=g["steps"], karras_noise_schedule_power=1000, noise=nz, align_ref_pos=False)
     if "ref_mol_poses" in g:
         kw.update(align_ref_pos=True, ref_mol={"conf": g["mol_conf"]}, relax_fn=toy_relax_fn, ref_mol_poses=g["ref_mol_poses"],
                   use_ref_mol_poses=True, mmff_gamma_0_factor=g["mmff_gamma_0_factor"])
-    x = medium.sample_diffusion(to_dev(batch), **kw)
+    if tag == "cfg1_b16":       # 16 samples: the loop must run on the split-operand kernels the B = 64 benchmark uses
+        from physdock_amd import ops
+        seen = []
+        ops.GEMM_HOOK = lambda a, launch: (seen.append(ops._lib.init().pd_gemm_variant(C.byref(a))), launch())
+        try:
+            x = medium.sample_diffusion(to_dev(batch), use_graph=False, **kw)
+        finally:
+            ops.GEMM_HOOK = None
+        n_split = sum(v >= 1000000 for v in seen)
+        assert n_split > 0.6 * len(seen), (n_split, len(seen))
+    else:
+        x = medium.sample_diffusion(to_dev(batch), **kw)
     r = rmsd(x.cpu(), g["x_pred"])
     print(f"medium/{tag}: T={batch['target_feat'].shape[0]} A={batch['ref_pos'].shape[0]} B={B} steps={g['steps']}: "
           f"RMSD vs reference {r:.3e} A (|x| max {float(g['x_pred'].abs().max()):.0f} A)")

@@ -212,6 +212,9 @@ def main_g9(RefPhysDock, RefConfig, ref_model_module):
         # (>= 10 steps so that the trajectory has contracted: after 4 steps of the p=1000 schedule |x| is still ~3700 A
         #  and one fp32 ulp of the coordinates is already 2e-4 A)
         ("cfg2", cfg2_batch(0), 1, 10, False),
+        # 16 samples: every launch of the loop is large enough for the split-operand (bf16 x 6) GEMM / attention kernels, the
+        # pre-split A path and the 64 x 64 split tiles - the kernels the B = 64 benchmark runs on - against the reference itself
+        ("cfg1_b16", cfg1_batch(0), 16, 6, False),
     )
     only = os.environ.get("PD_G9_ONLY")              # e.g. PD_G9_ONLY=cfg2: regenerate one case
     for tag, batch, B, steps, physics in cases:
