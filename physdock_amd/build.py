@@ -22,15 +22,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-#: per-source extra flags.  attention.hip: the SLP vectoriser packs the softmax's f32 adds/muls into v_pk_*_f32,
-#: which issue slower beside MFMAs on gfx950 (cdna guide: packed f32 VALU is an anti-lever next to MFMA).
-#: gemm_split.hip: with SLP vectorisation hipcc (ROCm 7.2) packs the norm prologue into v_pk_add/mul/fma_f32 on a
-#: register pair that a global_load_dwordx2 has just returned; on MI355X the kernel then intermittently stages wrong A
-#: rows for lanes 48-63 of a wave (the last VALU pass) in the first staging after a tile change - seen only in the
-#: multi-tile 32x64 / 64x64 wave layouts, gone with any perturbation of the schedule, and gone in every shape / 6 x
-#: repetition of tools/diag_split3.py without the packed ops (NOTES.md).  Scalar f32 VALU is also what the CDNA guide
-#: recommends beside MFMAs.  tests/test_gemm_split_gpu.py::test_split_multi_tile_stress guards it.
-EXTRA_FLAGS = {"gemm_split.hip": ["-fno-slp-vectorize"], "attn_split.hip": ["-fno-slp-vectorize"]}
+#: No packed-fp32 VALU anywhere (v_pk_add / mul / fma_f32).  hipcc (ROCm 7.2) forms them both in the SLP vectoriser and when it
+#: lowers explicit float2 / float4 arithmetic; on MI355X a packed op that reads a register pair a global_load has just returned
+#: intermittently sees stale data in lanes 48-63 (the last pass of the wave) - whole output rows with (row % 8) in {6, 7} off
+#: by O(1).  Timing decides: on an otherwise idle GPU the fp32 kernels never showed it (every parity test passed bit-
+#: reproducibly), the first split GEMM did in multi-tile blocks (NOTES.md "staging hazard"), and with a second kernel stream on
+#: the same CUs the generic GEMM with a norm prologue did in 1 of 2 launches (tools/concurrent_gemm_stress.py KIND=normproj:
+#: 146 of 300 launches wrong; 0 of 300 with this flag set).  -fno-slp-vectorize alone leaves the ops that come from vector
+#: types; disabling the target feature removes them all (the host pass prints "not a recognized feature", harmless).
+#: Scalar f32 VALU is also what the CDNA guide recommends beside MFMAs.
+#: tests/test_gemm_split_gpu.py::test_split_multi_tile_stress and tests/test_concurrent_streams_gpu.py guard it.
+NO_PACKED_F32 = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+EXTRA_FLAGS = {}
 
 
 def build(force=False, verbose=True):
@@ -45,6 +48,8 @@ def build(force=False, verbose=True):
         objs.append(obj)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
+        if os.environ.get("PD_NO_EXTRA_FLAGS") != "1":
+            cmd[1:1] = NO_PACKED_F32
         if os.environ.get("PD_LAB"):          # lab build: in-kernel phase traces + getenv tuning overrides (never shipped)
             cmd[1:1] = ["-DPD_LAB=1"]
         if os.environ.get("PD_BK") and os.path.basename(src) == "gemm.hip":
