@@ -356,6 +356,17 @@ def main():
         extra["screening_ligand"] = {"ligands_per_s": 1.0 / dt, "ms_per_ligand": 1e3 * dt, "rounds": len(res["rounds"]),
                                      "samples_per_round": 20, "poses_kept": int(res["poses"].shape[0]),
                                      "pdb_blocks": len(res["pdb_blocks"])}
+        # the same ligands two at a time on two HIP streams of this GPU (parallel.StreamPool): their half-empty tail rounds overlap
+        from physdock_amd.parallel import StreamPool
+        pool = StreamPool(model, n=2)
+        pool.map(lambda m, sd_: driver.redock(m, dbatch, seed=sd_, **rk), [20, 21])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pool.map(lambda m, sd_: driver.redock(m, dbatch, seed=sd_, **rk), [30, 31, 32, 33])
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / 4
+        extra["screening_ligand"].update(two_streams_ligands_per_s=1.0 / dt2, two_streams_ms_per_ligand=1e3 * dt2)
+        del pool
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, P, batch, confs, args)

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from typing import Dict, Optional
 
 import torch
@@ -27,6 +28,9 @@ from . import ops
 from .engine import Engine, off
 from .packing import PackedWeights
 from .params import param_shapes
+
+
+_CAPTURE_LOCK = threading.Lock()
 
 
 def _register(root: nn.Module, name: str, tensor: torch.Tensor):
@@ -406,16 +410,20 @@ class PhysDock(nn.Module):
                 if brk is not None:
                     host_relax()
             if use_graph:
-                torch.cuda.synchronize()
-                execs = []
-                cap = torch.cuda.Stream()
-                with torch.cuda.stream(cap):
-                    for seg, brk in segments:
-                        ops.check(L.pd_graph_begin(ops.stream()), "graph_begin")
-                        run_segment(seg)
-                        ex = C.c_void_p()
-                        ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
-                        execs.append(ex)
+                # one capture at a time per process: objects driven from several host threads (parallel.StreamPool) replay
+                # concurrently, but two overlapping captures make unrelated launches of the other thread fail
+                with _CAPTURE_LOCK:
+                    torch.cuda.synchronize()
+                    execs = []
+                    cap = torch.cuda.Stream()
+                    with torch.cuda.stream(cap):
+                        for seg, brk in segments:
+                            ops.check(L.pd_graph_begin(ops.stream()), "graph_begin")
+                            run_segment(seg)
+                            ex = C.c_void_p()
+                            ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
+                            execs.append(ex)
+                    torch.cuda.synchronize()
                 self._graphs[key] = {"exec": execs}
                 while len(self._graphs) > self.max_cached_graphs:
                     old = self._graphs.pop(next(iter(self._graphs)))

@@ -85,10 +85,6 @@ def test_two_samplers_on_two_streams_agree_with_the_quiet_result(small_model_inp
         return m.cuda().eval()
     quiet = make().sample_diffusion(dbatch, **kw).cpu()
     models, streams, outs = [make(), make()], [torch.cuda.Stream(), torch.cuda.Stream()], [[], []]
-    for m, st in zip(models, streams):          # first call of each object (workspace allocation, step-loop capture) on its own
-        with torch.cuda.stream(st):
-            m.sample_diffusion(dbatch, **kw)
-        st.synchronize()
 
     def work(k):
         with torch.cuda.stream(streams[k]):
@@ -102,3 +98,21 @@ def test_two_samplers_on_two_streams_agree_with_the_quiet_result(small_model_inp
         t.join()
     for o in outs:
         assert len(o) == 6 and all(torch.equal(x.cpu(), quiet) for x in o)
+
+
+def test_stream_pool_maps_systems_in_order_with_unchanged_poses(small_model_inputs):
+    from physdock_amd import PhysDock
+    from physdock_amd.parallel import StreamPool
+    cfg, P, batch = small_model_inputs
+    model = PhysDock(cfg)
+    model.load_state_dict(P, strict=True)
+    model = model.cuda().eval()
+    dbatch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    kw = dict(num_sample=6, steps=6, karras_noise_schedule_power=1000, align_ref_pos=False)
+    seeds = list(range(7))
+    want = [model.sample_diffusion(dbatch, seed=s_, **kw).cpu() for s_ in seeds]
+    pool = StreamPool(model, n=2)
+    got = pool.map(lambda m, s_: m.sample_diffusion(dbatch, seed=s_, **kw).cpu(), seeds)
+    assert len(got) == len(seeds) and all(torch.equal(a, b) for a, b in zip(got, want))
+    with pytest.raises(ValueError):
+        pool.map(lambda m, s_: (_ for _ in ()).throw(ValueError("boom")), [1, 2])
