@@ -36,6 +36,40 @@ NO_PACKED_F32 = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", 
 EXTRA_FLAGS = {}
 
 
+def compile_cmd(src, out, mode=("-c",)):
+    """the hipcc command line of one source file (shared by build() and the device-assembly check in
+    tests/test_build_rules_cpu.py, which passes mode=("-S", "--cuda-device-only"))"""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    base = os.path.basename(src)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+           "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, *mode, src, "-o", out]
+    if os.environ.get("PD_NO_EXTRA_FLAGS") != "1":
+        cmd[1:1] = NO_PACKED_F32
+    if os.environ.get("PD_LAB"):          # lab build: in-kernel phase traces + getenv tuning overrides (never shipped)
+        cmd[1:1] = ["-DPD_LAB=1"]
+    if os.environ.get("PD_BK") and base == "gemm.hip":
+        cmd[1:1] = ["-DPD_BK=" + os.environ["PD_BK"]]
+    if os.environ.get("PD_STREAM_NOEMIT") and base == "gemm_stream.hip":
+        cmd[1:1] = ["-DPD_STREAM_NOEMIT=1"]
+    if os.environ.get("PD_STREAM_SAMETILE") and base == "gemm_stream.hip":
+        cmd[1:1] = ["-DPD_STREAM_SAMETILE=1"]
+    if os.environ.get("PD_GEMM_NOSTORE") and base == "gemm.hip":
+        cmd[1:1] = ["-DPD_GEMM_NOSTORE=1"]
+    if os.environ.get("PD_ABL") and base == "gemm_split.hip":      # lab: main-loop ablations (wrong results)
+        cmd[1:1] = ["-DPD_ABL=" + os.environ["PD_ABL"]]
+    for knob in ("PD_PB_UB", "PD_PB_TR", "PD_PB_TR4"):
+        if os.environ.get(knob) and base == "pairbias.hip":
+            cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
+    if os.environ.get("PD_KSPLIT_MAX_BYTES") and base == "gemm_stream.hip":
+        cmd[1:1] = ["-DPD_KSPLIT_MAX_BYTES=" + os.environ["PD_KSPLIT_MAX_BYTES"]]
+    for knob in ("PD_SPLIT_MIN_TILES", "PD_SPLIT_MIN_TILES_SMALL"):
+        if os.environ.get(knob) and base == "gemm_split.hip":
+            cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
+    if os.environ.get("PD_NO_EXTRA_FLAGS") != "1":
+        cmd[1:1] = EXTRA_FLAGS.get(base, [])
+    return cmd
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
@@ -46,33 +80,7 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-               "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj]
-        if os.environ.get("PD_NO_EXTRA_FLAGS") != "1":
-            cmd[1:1] = NO_PACKED_F32
-        if os.environ.get("PD_LAB"):          # lab build: in-kernel phase traces + getenv tuning overrides (never shipped)
-            cmd[1:1] = ["-DPD_LAB=1"]
-        if os.environ.get("PD_BK") and os.path.basename(src) == "gemm.hip":
-            cmd[1:1] = ["-DPD_BK=" + os.environ["PD_BK"]]
-        if os.environ.get("PD_STREAM_NOEMIT") and os.path.basename(src) == "gemm_stream.hip":
-            cmd[1:1] = ["-DPD_STREAM_NOEMIT=1"]
-        if os.environ.get("PD_STREAM_SAMETILE") and os.path.basename(src) == "gemm_stream.hip":
-            cmd[1:1] = ["-DPD_STREAM_SAMETILE=1"]
-        if os.environ.get("PD_GEMM_NOSTORE") and os.path.basename(src) == "gemm.hip":
-            cmd[1:1] = ["-DPD_GEMM_NOSTORE=1"]
-        if os.environ.get("PD_ABL") and os.path.basename(src) == "gemm_split.hip":      # lab: main-loop ablations (wrong results)
-            cmd[1:1] = ["-DPD_ABL=" + os.environ["PD_ABL"]]
-        for knob in ("PD_PB_UB", "PD_PB_TR", "PD_PB_TR4"):
-            if os.environ.get(knob) and os.path.basename(src) == "pairbias.hip":
-                cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
-        if os.environ.get("PD_KSPLIT_MAX_BYTES") and os.path.basename(src) == "gemm_stream.hip":
-            cmd[1:1] = ["-DPD_KSPLIT_MAX_BYTES=" + os.environ["PD_KSPLIT_MAX_BYTES"]]
-        for knob in ("PD_SPLIT_MIN_TILES", "PD_SPLIT_MIN_TILES_SMALL"):
-            if os.environ.get(knob) and os.path.basename(src) == "gemm_split.hip":
-                cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
-        if os.environ.get("PD_NO_EXTRA_FLAGS") != "1":
-            cmd[1:1] = EXTRA_FLAGS.get(os.path.basename(src), [])
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        procs.append((src, subprocess.Popen(compile_cmd(src, obj), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:

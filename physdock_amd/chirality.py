@@ -7,8 +7,10 @@ centre's CIP label flips exactly when its geometric handedness flips, so the com
 (kernel `pd_chirality`): no per-pose device-to-host copy, no per-pose RDKit call.  Which atoms are stereocentres is
 chemistry the host supplies once per ligand: from RDKit when it is installed (`from_rdkit`), from a bond list
 (`centres_from_bonds`: every atom with four distinct neighbours, or three plus an implicit hydrogen when asked), or
-explicitly.  **Parity with RDKit's perception is unpinned** (RDKit is not installed here): a centre RDKit would not label
-(e.g. two identical substituents) can be passed in and is then simply required to keep its handedness.
+explicitly.  `centres_from_bonds(..., elements=)` drops atoms whose substituents are topologically equivalent (gem-dimethyl,
+CF3, t-butyl, sulfonyl ...), which is what RDKit's legacy perception does through canonical atom ranks; **parity with
+RDKit's perception is pinned only where RDKit is importable** (tests/test_rdkit_gpu.py), hand-built molecules are tested
+everywhere (tests/test_chirality_cpu.py).
 """
 from __future__ import annotations
 
@@ -19,12 +21,76 @@ import torch
 from . import ops
 
 
-def centres_from_bonds(n_atoms: int, bonds: Iterable[Tuple[int, int]], min_neighbours: int = 4) -> List[Tuple[int, int, int, int]]:
-    """(centre, n1, n2, n3) for every atom with >= min_neighbours neighbours in the bond graph; neighbours in index order"""
+def symmetry_classes(n_atoms: int, bonds: Iterable[Tuple[int, int]], elements: Optional[Sequence[int]] = None,
+                     bond_orders: Optional[Sequence[float]] = None) -> List[int]:
+    """Topological symmetry classes of the atoms of a molecular graph: Morgan-style refinement of the invariant
+    (element, degree, sum of bond orders) by the sorted multiset of (bond order, class) of the neighbours until the
+    partition stops splitting - the information RDKit's legacy stereo perception takes from `CanonicalRankAtoms(mol,
+    breakTies=False)`: two atoms share a class exactly when no walk of the graph tells them apart."""
+    bonds = [(int(i), int(j)) for i, j in bonds]
+    orders = [1.0] * len(bonds) if bond_orders is None else [float(o) for o in bond_orders]
+    if len(orders) != len(bonds):
+        raise ValueError("one bond order per bond")
     adj = [[] for _ in range(n_atoms)]
+    for (i, j), o in zip(bonds, orders):
+        adj[i].append((j, o)); adj[j].append((i, o))
+    el = [0] * n_atoms if elements is None else [int(e) for e in elements]
+    if len(el) != n_atoms:
+        raise ValueError("one element per atom")
+    inv = [(el[a], len(adj[a]), round(sum(o for _, o in adj[a]), 3)) for a in range(n_atoms)]
+
+    def ranks(keys):
+        order = {k: r for r, k in enumerate(sorted(set(keys)))}
+        return [order[k] for k in keys]
+    cls = ranks(inv)
+    for _ in range(n_atoms):
+        nxt = ranks([(cls[a], tuple(sorted((o, cls[b]) for b, o in adj[a]))) for a in range(n_atoms)])
+        if len(set(nxt)) == len(set(cls)):
+            break
+        cls = nxt
+    return cls
+
+
+def centres_from_bonds(n_atoms: int, bonds: Iterable[Tuple[int, int]], min_neighbours: int = 4,
+                       elements: Optional[Sequence[int]] = None, bond_orders: Optional[Sequence[float]] = None,
+                       implicit_h: Optional[Sequence[int]] = None) -> List[Tuple[int, int, int, int]]:
+    """(centre, n1, n2, n3) of the tetrahedral stereocentres of a bond graph; neighbours in index order.
+
+    With `elements` (atomic numbers) the perception follows what `Chem.FindMolChiralCenters` reports for ordinary
+    organic ligands (redocking.py:231-238): an atom with four substituents - explicit neighbours plus at most one
+    implicit hydrogen (`implicit_h[a]`, or with min_neighbours=3 one hydrogen assumed on a carbon with three single-bonded
+    neighbours) - is a centre only when its substituents fall into pairwise DIFFERENT symmetry classes (`symmetry_classes`);
+    gem-dimethyl, CF3, t-butyl, sulfonyl / phosphoryl centres and CH2 groups are therefore not centres and a pose is
+    never rejected for their index-space handedness.  Not covered: stereo that depends on other stereocentres
+    (pseudo-asymmetric atoms), nitrogen inversion rules beyond "three-coordinate N is not a centre", atropisomers.
+    Without `elements` the graph carries no chemistry and every atom with >= min_neighbours distinct neighbours is
+    returned (the caller asks for exactly these atoms to keep their handedness)."""
+    bonds = [(int(i), int(j)) for i, j in bonds]
+    adj = [set() for _ in range(n_atoms)]
     for i, j in bonds:
-        adj[i].append(j); adj[j].append(i)
-    return [(c, *sorted(set(nb))[:3]) for c, nb in enumerate(adj) if len(set(nb)) >= max(3, min_neighbours)]
+        adj[i].add(j); adj[j].add(i)
+    if elements is None:
+        return [(c, *sorted(nb)[:3]) for c, nb in enumerate(adj) if len(nb) >= max(3, min_neighbours)]
+    cls = symmetry_classes(n_atoms, bonds, elements, bond_orders)
+    orders = {}
+    for (i, j), o in zip(bonds, [1.0] * len(bonds) if bond_orders is None else bond_orders):
+        orders[(i, j)] = orders[(j, i)] = float(o)
+    out = []
+    for c, nb in enumerate(adj):
+        deg = len(nb)
+        if implicit_h is not None:
+            n_h = int(implicit_h[c])
+        else:
+            all_single = all(orders[(c, b)] == 1.0 for b in nb)
+            n_h = 1 if (min_neighbours <= 3 and deg == 3 and int(elements[c]) == 6 and all_single) else 0
+        if n_h > 1 or deg + n_h != 4 or deg < 3:
+            continue                     # two identical hydrogens, or not four-coordinate
+        if int(elements[c]) == 7 and deg == 3:
+            continue                     # three-coordinate nitrogen inverts: RDKit does not label it (outside small rings)
+        if len({cls[b] for b in nb}) != deg:
+            continue                     # two substituents no walk of the graph tells apart
+        out.append((c, *sorted(nb)[:3]))
+    return out
 
 
 class ChiralityReference:

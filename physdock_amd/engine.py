@@ -454,7 +454,9 @@ class Engine:
         mgrp = dict(mul_rows_per_group=N if per_sample else rows, mul_gstride=tab_ld if per_sample else 0)
         # wide rows (token DiT, C = 512) in chip-filling launches: AdaLN-normalise and split the activations ONCE
         # (pd_norm_split) instead of in every column block of the projection that consumes them (12 / 22 of them)
-        presplit = ops.SPLIT_GEMM and ops.PRESPLIT_GEMM and C >= 256 and C % 32 == 0 and rows % 128 == 0 and (rows // 128) * (3 * C // 128) >= 256
+        W13, hidden = P.glu(prefix + ".transition.feed_forward")
+        presplit = ops.SPLIT_GEMM and ops.PRESPLIT_GEMM and C >= 256 and C % 32 == 0 \
+            and ops.presplit_supported(rows, 3 * C, C, hn=True) and ops.presplit_supported(rows, 2 * hidden, C, glu=1)
         a3 = self.lws("dit_a3", 3, rows, C, dtype=torch.bfloat16) if presplit else None
         ng = dict(rows_per_group=N if per_sample else 0, gstride=tab_ld if per_sample else 0)
         qkv = self.lws("dit_qkv", rows, 3 * C)
@@ -474,7 +476,6 @@ class Engine:
                       ws=self.attn_ws(B, N, nk, H))
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)
-        W13, hidden = P.glu(prefix + ".transition.feed_forward")
         h = self.lws("dit_h", rows, hidden)
         o2 = tab_off + 3 * C
         if presplit:

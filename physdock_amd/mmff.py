@@ -305,6 +305,8 @@ def synthetic_terms(n_atoms: int, seed: int = 0, coords: Optional[np.ndarray] = 
             eps[i, j] = eps[j, i] = np.sqrt(ep[i] * ep[j])
             qq[i, j] = qq[j, i] = q[i] * q[j] * (0.75 if d[i, j] == 3 else 1.0)
     terms = MMFFTerms(n, bonds, bond_par, angles, angle_par, sb_idx, sb_par, oops, oop_par, tors, tors_par, R, eps, qq)
+    # the per-atom quantities the pair tables were made from (what a parameter source such as RDKit exposes per atom)
+    terms.per_atom = {"charge": q, "vdw_Rstar": Rst, "vdw_eps": ep}
     return terms, coords
 
 

@@ -424,7 +424,10 @@ class PhysDock(nn.Module):
                             ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
                             execs.append(ex)
                     torch.cuda.synchronize()
-                self._graphs[key] = {"exec": execs}
+                # the captured launches hold raw device addresses: keep the MMFF table object whose tables were captured alive
+                # with the graph (a later call with an EQUAL table - same signature, e.g. rebuilt from the same RDKit
+                # molecule - replays against these tables, not against its own freshly built and soon freed ones)
+                self._graphs[key] = {"exec": execs, "terms": relaxer.terms if relaxer.kind == "device" else None}
                 while len(self._graphs) > self.max_cached_graphs:
                     old = self._graphs.pop(next(iter(self._graphs)))
                     for ex in old["exec"]:

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 
 import torch
 
@@ -17,16 +18,45 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, OUT_BIASFRAG, OUT_
 RMS, LN = 0, 1
 
 _CONST = {}
+_CONST_LOCK = threading.Lock()
 
 
 def const_vec(val, n):
-    """Cached device vector of a constant (ones / zeros for an absent norm gain / shift)."""
+    """Cached device vector of a constant (ones / zeros for an absent norm gain / shift).  The cache is shared by every
+    host thread / HIP stream of the process (parallel.StreamPool): a vector is published only after the fill has
+    completed on the device, so a launch on another stream can never read it half-written."""
     key = (float(val), torch.cuda.current_device())
     v = _CONST.get(key)
     if v is None or v.numel() < n:
-        v = torch.full((max(n, 4096),), float(val), device="cuda", dtype=torch.float32)
-        _CONST[key] = v
+        with _CONST_LOCK:
+            v = _CONST.get(key)
+            if v is None or v.numel() < n:
+                v = torch.full((max(n, 4096),), float(val), device="cuda", dtype=torch.float32)
+                torch.cuda.current_stream().synchronize()
+                _CONST[key] = v
     return v
+
+
+_PRESPLIT_OK = {}
+
+
+def presplit_supported(M, N, K, *, glu=0, hn=False):
+    """Does the library take a [3][M][K] pre-split A operand (pd_gemm_args.A3) for this projection?  Asked of the
+    library itself (pd_gemm_variant: tile-count threshold, alignment and epilogue rules live in csrc/gemm_split.hip),
+    so a differently tuned build changes the answer here, not an error in pd_gemm."""
+    key = (M, N, K, int(glu), bool(hn))
+    r = _PRESPLIT_OK.get(key)
+    if r is None:
+        a = GemmArgs()
+        a.A = a.W = a.Y = a.W3 = a.A3 = 1 << 20          # never dereferenced by the query: aligned placeholders
+        a.M, a.N, a.K = M, N, K
+        a.lda, a.ldw, a.ldy = K, K, (N // 2 if glu else N)
+        a.batch, a.glu, a.out_scale = 1, int(glu), 1.0
+        if hn:
+            a.hn_w, a.hn_cols, a.hn_split = 1 << 20, 0, 32
+        r = _lib.init().pd_gemm_variant(C.byref(a)) >= 1000000
+        _PRESPLIT_OK[key] = r
+    return r
 
 
 def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0, sY=0,

@@ -7,10 +7,12 @@ asked to use them without being given any (model.py:188-203).  RDKit is a third-
 and its arithmetic is not restated by the reference, so this module offers three ways to run the branch, all behind the
 unchanged `sample_diffusion(ref_mol=...)` argument:
 
-* **device** - `ref_mol` is (or converts to) a table of MMFF94 terms (`mmff.MMFFTerms`): the relaxation runs in the HIP
-  kernel `pd_mmff_relax` inside the captured step loop, no host round trip (mmff.py, csrc/mmff.hip);
-* **host RDKit** - `ref_mol` is an RDKit molecule and RDKit is importable: the reference's own call sequence, per step, on
-  the host (`rdkit_get_next_step_pos`); the step loop is then captured in segments around the host calls;
+* **device** - `ref_mol` is a table of MMFF94 terms (`mmff.MMFFTerms`), or an RDKit molecule with `mmff_backend="device"`
+  (tables read from RDKit's getters and self-checked, mmff.py): the relaxation runs in the HIP kernel `pd_mmff_relax`
+  inside the captured step loop, no host round trip (csrc/mmff.hip);
+* **host RDKit** - `ref_mol` is an RDKit molecule and RDKit is importable (the default for an RDKit molecule): the
+  reference's own call sequence, per step, on the host (`rdkit_get_next_step_pos`); the step loop is then captured in
+  segments around the host calls;
 * **injected** - `relax_fn(ref_mol, ligand_pos [B,L,3], mmff_iters) -> [B,L,3]` (same signature as the reference's
   `get_next_step_pos`): what the parity fixtures use, with the identical function patched into the reference.
 
@@ -90,8 +92,35 @@ class Relaxer:
         return out
 
 
+#: per-molecule memo of the device tables built from an RDKit molecule (the build reads ~10^3 RDKit getters and runs a
+#: self-check on the GPU; the step-loop graph cache keys on the table's content hash, see model.py)
+_TERMS_MEMO: "dict[int, tuple]" = {}
+_TERMS_MEMO_MAX = 32
+
+#: what `mmff_backend="auto"` does with an RDKit molecule: "host" = the reference's own RDKit call sequence (default: the
+#: trajectory of RDKit's optimiser is what the reference produces), "device" = the HIP kernel with tables read from RDKit
+#: (self-checked against RDKit's energy / gradient on the input conformer; tests/test_rdkit_gpu.py pins it where RDKit exists)
+AUTO_BACKEND_FOR_RDKIT_MOL = "host"
+
+
+def _memo_terms(ref_mol, strict):
+    from . import mmff
+    key = id(ref_mol)
+    hit = _TERMS_MEMO.get(key)
+    if hit is not None and hit[0] is ref_mol:
+        return hit[1]
+    terms = mmff.terms_from_rdkit(ref_mol, strict=strict)
+    if terms is not None:
+        if len(_TERMS_MEMO) >= _TERMS_MEMO_MAX:
+            _TERMS_MEMO.pop(next(iter(_TERMS_MEMO)))
+        _TERMS_MEMO[key] = (ref_mol, terms)          # holds the molecule: id() stays unique while the entry lives
+    return terms
+
+
 def resolve_relaxer(ref_mol, relax_fn: Optional[Callable], mmff_backend: str = "auto") -> Relaxer:
     """Pick the execution mode of the relaxation branch for this call (see module docstring)."""
+    if mmff_backend not in ("auto", "host", "device"):
+        raise ValueError(f"mmff_backend={mmff_backend!r}: expected 'auto', 'host' or 'device'")
     if ref_mol is None:
         return Relaxer("none")
     if relax_fn is not None:
@@ -103,8 +132,9 @@ def resolve_relaxer(ref_mol, relax_fn: Optional[Callable], mmff_backend: str = "
         if not have_rdkit():
             raise RuntimeError("ref_mol is an RDKit molecule but RDKit is not importable in this process; pass "
                                "physdock_amd.mmff.MMFFTerms (device relaxation) or relax_fn=")
-        if mmff_backend in ("auto", "device"):
-            terms = mmff.terms_from_rdkit(ref_mol, strict=(mmff_backend == "device"))
+        want = AUTO_BACKEND_FOR_RDKIT_MOL if mmff_backend == "auto" else mmff_backend
+        if want == "device":
+            terms = _memo_terms(ref_mol, strict=(mmff_backend == "device"))
             if terms is not None:
                 return Relaxer("device", terms=terms, ref_mol=ref_mol)
         return Relaxer("host", fn=rdkit_get_next_step_pos, ref_mol=ref_mol)

@@ -60,14 +60,14 @@ def test_ref_mol_without_a_way_to_relax_raises(small):
 
 
 # ------------------------------------------------------------------ G9: the reference itself at the benchmark shapes
-@pytest.mark.parametrize("tag", ["cfg1", "ragged", "cfg2", "cfg1_b16"])
+@pytest.mark.parametrize("tag", ["cfg1", "ragged", "cfg2", "cfg1_b16", "cfg1_40"])
 def test_medium_trajectories_vs_reference(medium, tag):
     """north_star bar at full size, against the reference (not the oracle): final coordinates within 1e-3 A RMSD with
     the same seeded weights, synthetic crop and recorded noise"""
     from physdock_amd.synthetic import cfg1_batch, cfg2_batch, make_batch, toy_relax_fn
     g = load_golden(f"g9_medium_{tag}")
     batch = {"cfg1": lambda: cfg1_batch(0), "ragged": lambda: make_batch(221, 8, 35, 64, 2), "cfg2": lambda: cfg2_batch(0),
-             "cfg1_b16": lambda: cfg1_batch(0)}[tag]()
+             "cfg1_b16": lambda: cfg1_batch(0), "cfg1_40": lambda: cfg1_batch(0)}[tag]()
     nz = golden_noise(g)
     B = nz["init"].shape[0]
     kw = dict(num_sample=B, steps=g["steps"], karras_noise_schedule_power=1000, noise=nz, align_ref_pos=False)

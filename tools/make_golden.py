@@ -215,6 +215,9 @@ def main_g9(RefPhysDock, RefConfig, ref_model_module):
         # 16 samples: every launch of the loop is large enough for the split-operand (bf16 x 6) GEMM / attention kernels, the
         # pre-split A path and the 64 x 64 split tiles - the kernels the B = 64 benchmark runs on - against the reference itself
         ("cfg1_b16", cfg1_batch(0), 16, 6, False),
+        # the SCHEDULE the benchmark times: 40 steps (p = 1000) with every physics branch - 23 noisy template-projection
+        # steps, 17 relaxation steps - so that the timed call is compared with the reference itself, not through a chain
+        ("cfg1_40", cfg1_batch(0), 2, 40, True),
     )
     only = os.environ.get("PD_G9_ONLY")              # e.g. PD_G9_ONLY=cfg2: regenerate one case
     for tag, batch, B, steps, physics in cases:
