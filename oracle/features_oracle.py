@@ -19,16 +19,28 @@ SYMBOLS = ("H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe 
            "Po At Rn Fr Ra Ac Th Pa U Np Pu Am Cm Bk Cf Es Fm Md No Lr Rf Db Sg Bh Hs Mt Ds Rg Cn Nh Fl Mc Lv Ts Og").split()
 
 
-def make_feats(t, msa_inds):
-    """feature_loader.py:803-851 (num_recycles None); the random row choice of :813 is passed in"""
-    t["target_feat"] = torch.cat([F.one_hot(t["restype"].long(), 32).float(), t["profile"].float(),
-                                  t["deletion_mean"][..., None].float()], dim=-1)
-    msa, dele = t["msa"][msa_inds], t["deletion_matrix"][msa_inds]
+def _msa_feat(msa, dele):
     has_deletion = torch.clamp(dele.float(), min=0., max=1.)
     pi = torch.acos(torch.zeros(1)) * 2
     deletion_value = torch.atan(dele / 3.) * (2. / pi)
-    t["msa_feat"] = torch.cat([F.one_hot(msa.long(), 32).float(), has_deletion[..., None].float(),
-                               deletion_value[..., None].float()], dim=-1)
+    return torch.cat([F.one_hot(msa.long(), 32).float(), has_deletion[..., None].float(), deletion_value[..., None].float()], dim=-1)
+
+
+def make_feats(t, msa_inds, num_recycles=None):
+    """feature_loader.py:803-851; the random row choices of :813 / :829 are passed in.  num_recycles None: msa_inds is one
+    index list.  Otherwise (:826-844) one list per round, each indexing the PREVIOUS round's subsample - the reference
+    overwrites tensors["msa"] inside the loop - and the rounds are stacked as batch_msa_feat (msa_feat = round 0)."""
+    t["target_feat"] = torch.cat([F.one_hot(t["restype"].long(), 32).float(), t["profile"].float(),
+                                  t["deletion_mean"][..., None].float()], dim=-1)
+    if num_recycles is None:
+        t["msa_feat"] = _msa_feat(t["msa"][msa_inds], t["deletion_matrix"][msa_inds])
+    else:
+        msa, dele, rounds = t["msa"], t["deletion_matrix"], []
+        for i in range(num_recycles):
+            msa, dele = msa[msa_inds[i]], dele[msa_inds[i]]
+            rounds.append(_msa_feat(msa, dele))
+        t["msa_feat"] = rounds[0]
+        t["batch_msa_feat"] = torch.stack(rounds, dim=0)
     for k in ("msa", "deletion_mean", "profile", "deletion_matrix"):
         t.pop(k, None)
     return t
@@ -71,10 +83,10 @@ def dgram_from_positions(pos, min_bin=3.25, max_bin=50.75, no_bins=39, inf=1e8):
     return ((d2 > lower) * (d2 < upper)).type(d2.dtype)
 
 
-def transform(raw_feats, msa_inds, threshold=2.4):
+def transform(raw_feats, msa_inds, threshold=2.4, num_recycles=None):
     """feature_loader.py:970-998, inference mode"""
     t = {k: torch.from_numpy(np.array(v)) for k, v in raw_feats.items()}
-    t = make_token_bonds(make_feats(t, msa_inds), threshold)
+    t = make_token_bonds(make_feats(t, msa_inds, num_recycles), threshold)
     t["z_mask"] = t["s_mask"][None] * t["s_mask"][:, None]
     t["ap_mask"] = t["a_mask"][None] * t["a_mask"][:, None]
     t["is_dna"] = torch.zeros_like(t["is_protein"])

@@ -11,6 +11,8 @@ MSA pairing (`FeatureLoader.load`, :1004-1173) - stays on the host and out of sc
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 
 from . import ops
@@ -99,10 +101,15 @@ def token_bonds(x_gt, a_mask, atom_id_to_token_id, token_bonds_in, asym_id, is_l
     return out
 
 
-def transform(raw_feats: dict, device, max_msa_clusters: int = 128, token_bond_threshold: float = 2.4, msa_inds=None) -> dict:
-    """`FeatureLoader.transform(raw_feats)` (feature_loader.py:970-998) in inference mode (no padding, t_mask = 1,
-    num_recycles None): numpy arrays in, the model's feature dict on `device` out.  The MSA row subsample draws
-    `torch.randperm(len(msa))` from the host generator exactly like the reference (:813), or takes `msa_inds`."""
+def transform(raw_feats: dict, device, max_msa_clusters: int = 128, token_bond_threshold: float = 2.4, msa_inds=None,
+              num_recycles: Optional[int] = None) -> dict:
+    """`FeatureLoader.transform(raw_feats)` (feature_loader.py:970-998) in inference mode (no padding, t_mask = 1): numpy
+    arrays in, the model's feature dict on `device` out.  The MSA row subsample draws `torch.randperm(len(msa))` from the
+    host generator exactly like the reference (:813), or takes `msa_inds`.  With `num_recycles` (what the drivers' loader
+    sets to max_rounds, redocking.py:96) the reference draws one subsample per round, each from the PREVIOUS round's rows
+    (:826-844: `tensors["msa"]` is overwritten inside the loop): `msa_inds` is then one index list per round, the rounds are
+    stacked as `batch_msa_feat [rounds,S,T,34]` (what driver.redock reads in rounds >= 1, redocking.py:188) and `msa_feat`
+    is round 0."""
     import numpy as np
     dev = torch.device(device)
     if dev.type != "cuda":
@@ -119,15 +126,31 @@ def transform(raw_feats: dict, device, max_msa_clusters: int = 128, token_bond_t
                                ops.ptr(t["deletion_mean"].float().contiguous()), ops.ptr(target), T, 32, n_prof, sp()), "pd_target_feat")
     t["target_feat"] = target
     S = int(t["msa"].shape[0])
-    if msa_inds is None:
-        msa_inds = [0] + torch.randperm(S)[:max_msa_clusters - 1].tolist()
-    inds = torch.tensor(list(msa_inds), dtype=torch.int64, device=dev)
     pi = torch.acos(torch.zeros(1)) * 2                                     # the reference's fp32 pi and 2 / pi (:819-820)
     two_over_pi = float((2. / pi).item())
-    msa_feat = torch.empty(len(msa_inds), T, 34, device=dev, dtype=torch.float32)
-    ops.check(L.pd_msa_feat(ops.ptr(t["msa"].to(torch.int64).contiguous()), ops.ptr(t["deletion_matrix"].float().contiguous()), ops.ptr(inds),
-                            two_over_pi, ops.ptr(msa_feat), len(msa_inds), T, 32, sp()), "pd_msa_feat")
-    t["msa_feat"] = msa_feat
+    msa64, dele = t["msa"].to(torch.int64).contiguous(), t["deletion_matrix"].float().contiguous()
+
+    def msa_feat_of(rows):                                                  # rows: indices into the ORIGINAL msa
+        inds = torch.tensor(list(rows), dtype=torch.int64, device=dev)
+        out = torch.empty(len(rows), T, 34, device=dev, dtype=torch.float32)
+        ops.check(L.pd_msa_feat(ops.ptr(msa64), ops.ptr(dele), ops.ptr(inds), two_over_pi, ops.ptr(out), len(rows), T, 32, sp()),
+                  "pd_msa_feat")
+        return out
+    if num_recycles is None:
+        if msa_inds is None:
+            msa_inds = [0] + torch.randperm(S)[:max_msa_clusters - 1].tolist()
+        t["msa_feat"] = msa_feat_of(msa_inds)
+    else:
+        rows, rounds = list(range(S)), []
+        for i in range(int(num_recycles)):
+            pick = list(msa_inds[i]) if msa_inds is not None else [0] + torch.randperm(len(rows))[:max_msa_clusters - 1].tolist()
+            rows = [rows[j] for j in pick]                                  # composition = re-subsampling the subsample
+            rounds.append(msa_feat_of(rows))
+        if len({r.shape[0] for r in rounds}) != 1:
+            raise ValueError("the re-sampled MSAs differ in depth (the reference's torch.stack fails the same way: it needs "
+                             f"at least max_msa_clusters - 1 = {max_msa_clusters - 1} MSA rows)")
+        t["msa_feat"] = rounds[0]
+        t["batch_msa_feat"] = torch.stack(rounds, dim=0)
     for k in ("msa", "deletion_mean", "profile", "deletion_matrix"):
         t.pop(k, None)
     # ---- _make_token_bonds (:853-911)

@@ -82,9 +82,9 @@ def map_systems(fn, systems, costs=None, dst: int = 0):
     """Run `fn(system)` for this rank's share of `systems` (by-system / by-ligand sharding: BASELINE configs 3 and 5)
     and collect the picklable results on `dst` in the original order (None on the other ranks).  One
     `gather_object` at the end; the systems themselves never move."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return [fn(s) for s in systems]
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = dist.get_world_size(), dist.get_rank()      # world size 1 still goes through the collective (RCCL self-test)
     mine = system_shard(len(systems), rank, world, costs)
     local = [(i, fn(systems[i])) for i in mine]
     bufs = [None] * world if rank == dst else None

@@ -152,6 +152,16 @@ def cfg2_batch(seed=0):
     return make_batch(448, 9, 64, 128, seed)
 
 
+def system(n_protein=224, atoms_per_res=9, n_ligand=32, n_msa=128, seed=0, n_conf=40):
+    """One synthetic docking SYSTEM as the drivers see it (redocking.py:156-232 / screening.py:100-116 after featurisation):
+    the feature dict, reference conformers of its ligand, and the loader's naming tables for PDB output.  Different
+    (n_protein, n_ligand) give different - generally ragged - token / atom counts."""
+    batch = make_batch(n_protein, atoms_per_res, n_ligand, n_msa, seed)
+    meta = pdb_meta({k: batch[k].numpy() for k in ("token_id_to_chunk_sizes", "asym_id", "is_ligand", "residue_index")}, seed=seed)
+    return {"batch": batch, "ref_mol_poses": reference_conformers(batch, n_conf=n_conf, seed=seed + 1), "infer_meta_data": meta,
+            "name": f"syn_p{n_protein}_l{n_ligand}_s{seed}"}
+
+
 def small_batch(seed=0):
     """T=24 (20 protein x 4 atoms... ) sized for the committed fixtures: T=24, A=96, S=8."""
     return make_batch(18, 5, 6, 8, seed)

@@ -72,3 +72,15 @@ def test_chain_runs_and_no_cpu_path():
     assert chain_runs(np.array([], dtype=np.int64)) == ([], [0])
     with pytest.raises(RuntimeError, match="MI355X"):
         transform(raw_features(0), "cpu")
+
+
+def test_g13_recycles_oracle_vs_reference():
+    """the drivers' loader (num_recycles = max_rounds, feature_loader.py:826-844): every round re-samples the PREVIOUS
+    round's subsample; batch_msa_feat stacks the rounds"""
+    from physdock_amd.synthetic import raw_features
+    g = load_golden("g13_transform_recycles")
+    out = forc.transform(raw_features(0), g["msa_inds"].tolist(), num_recycles=3)
+    assert torch.equal(out["batch_msa_feat"], g["batch_msa_feat"]) and torch.equal(out["msa_feat"], g["msa_feat"])
+    assert torch.equal(out["batch_msa_feat"][0], out["msa_feat"])
+    assert not torch.equal(out["batch_msa_feat"][1], out["batch_msa_feat"][0])
+    assert torch.equal(out["target_feat"], g["target_feat"]) and torch.equal(out["token_bonds"], g["token_bonds"])

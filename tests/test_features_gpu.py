@@ -161,3 +161,24 @@ def test_transform_and_pdb_at_the_benchmark_crop_vs_oracle():
     assert len(blocks) == 64
     for b in (0, 31, 63):
         assert blocks[b] == forc.write_pdb_block(x[b], meta)
+
+
+def test_g13_recycles_hip_vs_reference():
+    """transform(num_recycles=3) = the loader the drivers build (redocking.py:96): batch_msa_feat [rounds,S,T,34] with every
+    round drawn from the previous round's rows, from the host generator like the reference or from explicit index lists"""
+    from physdock_amd.features import transform
+    from physdock_amd.synthetic import raw_features
+    g = load_golden("g13_transform_recycles")
+    raw = raw_features(0)
+    torch.manual_seed(300)                            # the same host draws as the reference run (make_golden.main_g13)
+    out = transform(raw, "cuda", max_msa_clusters=16, num_recycles=3)
+    out2 = transform(raw, "cuda", max_msa_clusters=16, num_recycles=3, msa_inds=g["msa_inds"].tolist())
+    for o in (out, out2):
+        got = o["batch_msa_feat"].cpu()
+        assert got.shape == g["batch_msa_feat"].shape
+        assert torch.equal(got[..., :33], g["batch_msa_feat"][..., :33])
+        torch.testing.assert_close(got[..., 33], g["batch_msa_feat"][..., 33], rtol=0, atol=1.2e-7)
+        assert torch.equal(o["msa_feat"], o["batch_msa_feat"][0])
+        assert torch.equal(o["target_feat"].cpu(), g["target_feat"]) and torch.equal(o["token_bonds"].cpu(), g["token_bonds"])
+    with pytest.raises(ValueError, match="differ in depth"):          # too few MSA rows: the reference's torch.stack fails too
+        transform(raw, "cuda", max_msa_clusters=64, num_recycles=2)

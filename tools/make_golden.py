@@ -361,6 +361,21 @@ def main_g13():
         npz(f"g13_transform_{seed}", msa_inds=np.asarray(inds), out_keys=np.asarray(sorted(out.keys())),
             **{k: out[k] for k in keys})
         print("   token bonds added:", int((out["token_bonds"].numpy() - raw["token_bonds"]).sum()) // 2)
+    # the drivers' loader: num_recycles = max_rounds re-sampled MSAs (redocking.py:96, feature_loader.py:826-844) - every round
+    # draws from the PREVIOUS round's subsample (`tensors["msa"]` is overwritten inside the loop)
+    loader.num_recycles = 3
+    raw = raw_features(0)
+    torch.manual_seed(300)
+    out = loader.transform({k: v.copy() for k, v in raw.items()})
+    torch.manual_seed(300)
+    inds, n_rows = [], raw["msa"].shape[0]
+    for _ in range(3):
+        inds.append([0] + torch.randperm(n_rows)[:loader.max_msa_clusters - 1].tolist())
+        n_rows = len(inds[-1])
+    assert torch.equal(out["msa_feat"], out["batch_msa_feat"][0])
+    npz("g13_transform_recycles", msa_inds=np.asarray(inds), batch_msa_feat=out["batch_msa_feat"], msa_feat=out["msa_feat"],
+        target_feat=out["target_feat"], token_bonds=out["token_bonds"])
+    loader.num_recycles = None
     raw = raw_features(0)
     meta = pdb_meta(raw)
     g = torch.Generator().manual_seed(9)
