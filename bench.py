@@ -47,25 +47,29 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the B=1 / B=20 side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the B=1 / B=20 / cfg2 / MMFF / screening side measurements")
+    ap.add_argument("--launch-log", default=None, help="write the GEMM / attention launch sequence (symbol, shape) of the timed "
+                                                       "calls as JSON (tools/pmc_report.py joins it with rocprofv3 dispatches)")
     return ap.parse_args()
+
+
+def make_crop(name, device):
+    """synthetic crop of a named configuration + 40 synthetic reference conformers of its ligand"""
+    from physdock_amd import synthetic
+    batch = {"small": synthetic.small_batch, "cfg1": synthetic.cfg1_batch, "cfg2": synthetic.cfg2_batch}[name](0)
+    confs = synthetic.reference_conformers(batch, n_conf=40, seed=1)
+    dbatch = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    return batch, dbatch, confs
 
 
 def build_inputs(args, device):
     from physdock_amd import PhysDock, PhysDockConfig, param_shapes, seeded_state_dict, small_config
-    from physdock_amd import synthetic
-    if args.cfg == "small":
-        cfg = small_config()
-        batch = synthetic.small_batch(0)
-    else:
-        cfg = PhysDockConfig(model_name=args.model)
-        batch = synthetic.cfg1_batch(0) if args.cfg == "cfg1" else synthetic.cfg2_batch(0)
+    cfg = small_config() if args.cfg == "small" else PhysDockConfig(model_name=args.model)
+    batch, dbatch, confs = make_crop(args.cfg, device)
     P = seeded_state_dict(param_shapes(cfg), seed=0)      # trained weights are not available offline
-    confs = synthetic.reference_conformers(batch, n_conf=40, seed=1)
     model = PhysDock(cfg)
     model.load_state_dict(P, strict=True)
     model = model.to(device).eval()
-    dbatch = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
     return cfg, P, batch, dbatch, confs, model
 
 
@@ -129,6 +133,7 @@ def cpu_baseline(cfg, P, batch, confs, args):
             by_b[str(B)] = {"poses_per_s": B / (t_trunk + n * t_step), "t_step_s": t_step}
     return {"value": by_b["20"]["poses_per_s"], "unit": "poses/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "by_samples": by_b, "t_trunk_s": t_trunk, "wall_s": time.perf_counter() - t_all,
+            "extrapolated": True, "trunk_repeats_timed": 2, "loop_steps_per_timed_call": 2,
             "sample": f"oracle (torch CPU fp32, {cores} threads, {cpu_model()}): conditioning trunk 1 warm-up + 2 timed "
                       f"(median {t_trunk:.1f} s); reverse-diffusion loop as 2-step sampler calls with the template-projection "
                       f"physics branch, 1 warm-up + 3 timed per B in (1, 20) (median {by_b['1']['t_step_s']:.2f} / "
@@ -141,16 +146,25 @@ class LaunchTimer:
 
     GEMM_NAMES = {0: "128, 128, 2, 2", 1: "128, 64, 2, 2", 2: "128, 32, 4, 1", 3: "64, 64, 2, 2"}
 
-    def __init__(self, ops):
+    def __init__(self, ops, time_launches=True):
         self.ops = ops
-        self.rec = {}      # kernel symbol -> [events, flops]
+        self.time_launches = time_launches
+        self.rec = {}      # kernel symbol -> [events, flops, bytes]
+        self.shape_rec = {}  # (kernel symbol, shape string) -> [events, flops, bytes]
         self.split = {}    # kernel symbol -> runs on the bf16 matrix pipe (split operands)
+        self.log = []      # launch order: [symbol, shape string]  (joined with rocprofv3 dispatches by tools/pmc_report.py)
 
-    def _add(self, name, e0, e1, flops, nbytes=0.0):
-        r = self.rec.setdefault(name, [[], 0.0, 0.0])
-        r[0].append((e0, e1))
-        r[1] += flops
-        r[2] += nbytes
+    def _launch(self, name, shape, launch, flops, nbytes=0.0):
+        self.log.append([name, shape])
+        if not self.time_launches:
+            return launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); launch(); e1.record()
+        for store, key in ((self.rec, name), (self.shape_rec, (name, shape))):
+            r = store.setdefault(key, [[], 0.0, 0.0])
+            r[0].append((e0, e1))
+            r[1] += flops
+            r[2] += nbytes
 
     def __enter__(self):
         ops = self.ops
@@ -166,27 +180,29 @@ class LaunchTimer:
                                                          "true" if lay == 2 else "false", "false" if scalar else "true", pro)
             if streamed:        # persistent direct-epilogue variant (csrc/gemm_stream.hip)
                 name = "gemm_stream_kernel<%d, %d, Tile<%s> >" % (pro, epi, ("128, 128, 2", "64, 64, 2", "128, 64, 4")[tcode])
-                if split:       # 3 x bf16 split-operand variant (csrc/gemm_split.hip)
+                if split:       # 3 x bf16 split-operand variant (csrc/gemm_split.hip); names as rocprofv3 prints them:
+                    # PRO = 3 when A arrives pre-split (pd_gemm_args.A3); the STile's last argument = direct-W loop
+                    glu_tile = epi in (2, 5)
                     name = "gemm_split_kernel<%d, %d, STile<%s> >" % (
-                        pro, epi, (("128, 128, 4, 8" if epi == 2 else "128, 128, 2, 8"), "64, 64, 2, 4", "128, 64, 4, 4")[tcode])
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); launch(); e1.record()
+                        3 if a.A3 else pro, epi,
+                        (("128, 128, 4, 8, false" if glu_tile else "128, 128, 2, 8, true"), "64, 64, 2, 4, true", "128, 64, 4, 4, true")[tcode])
             nb = max(a.batch, 1)
             n_out = a.N // 2 if a.glu else a.N
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))
-            self._add(name, e0, e1, 2.0 * a.M * a.N * a.K * nb, byt)
             self.split[name] = split
+            shape = "M=%d N=%d K=%d" % (a.M, a.N, a.K) + (" x%d" % nb if nb > 1 else "")
+            self._launch(name, shape, launch, 2.0 * a.M * a.N * a.K * nb, byt)
+
         def attn_hook(a, launch):
             v = L.pd_attention_variant(C.byref(a))          # 4 / 8 waves per block, or 4 + 100 * key chunks
             name = "attn_kernel<%d, %s>" % (v % 100, "true" if v > 100 else "false")
             if v >= 1000:       # bf16 matrix pipe, split operands (csrc/attn_split.hip)
                 name = "attn_split_kernel<%d>" % (v % 100)
             self.split[name] = v >= 1000
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); launch(); e1.record()
             c = a.nheads * 32                    # q, o: nq rows; k, v: nk rows; the bias tile set is read once per launch
             byt = 4.0 * a.nbatch * c * (2 * a.nq + 2 * a.nk) + (4.0 * a.nheads * a.nq * a.nk if a.bias else 0.0)
-            self._add(name, e0, e1, 4.0 * a.nbatch * a.nheads * a.nq * a.nk * 32, byt)
+            shape = "batch=%d heads=%d nq=%d nk=%d%s" % (a.nbatch, a.nheads, a.nq, a.nk, " bias" if a.bias else "")
+            self._launch(name, shape, launch, 4.0 * a.nbatch * a.nheads * a.nq * a.nk * 32, byt)
         ops.GEMM_HOOK = gemm_hook
         ops.ATTN_HOOK = attn_hook
         return self
@@ -195,13 +211,15 @@ class LaunchTimer:
         self.ops.GEMM_HOOK = None
         self.ops.ATTN_HOOK = None
 
-    def summary(self):
+    def summary(self, by_shape=False):
         torch.cuda.synchronize()
         out = []
-        for name, (ev, fl, by) in self.rec.items():
+        for key, (ev, fl, by) in (self.shape_rec if by_shape else self.rec).items():
             t = sum(a.elapsed_time(b) for a, b in ev) * 1e-3
-            out.append(dict(kernel=name, launches=len(ev), total_s=t, avg_launch_ms=1e3 * t / len(ev),
-                            flop_per_launch=fl / len(ev), tflops=fl / t / 1e12, algorithmic_bytes_per_launch=by / len(ev)))
+            d = dict(kernel=key[0], shape=key[1]) if by_shape else dict(kernel=key)
+            d.update(launches=len(ev), total_s=t, avg_launch_ms=1e3 * t / len(ev), flop_per_launch=fl / len(ev),
+                     tflops=fl / t / 1e12, algorithmic_bytes_per_launch=by / len(ev))
+            out.append(d)
         return sorted(out, key=lambda d: -d["total_s"])
 
 
@@ -248,6 +266,11 @@ def main():
 
     for i in range(args.warmup):
         one_call(i)
+    logger = None
+    if args.launch_log and rank == 0:        # profiling runs only (eager calls): shapes of every launch, no events, no timing claim
+        from physdock_amd import ops as _ops
+        logger = LaunchTimer(_ops, time_launches=False)
+        logger.__enter__()
     if dist:
         td.barrier()
     torch.cuda.synchronize()
@@ -258,6 +281,10 @@ def main():
     if dist:
         td.barrier()
     elapsed = time.perf_counter() - t0
+    if logger is not None:
+        logger.__exit__()
+        with open(args.launch_log, "w") as f:
+            json.dump(logger.log, f)
     if dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -305,15 +332,20 @@ def main():
             summ = lt.summary()
         dom = summ[0]
         traffic, traffic_src = None, None
-        pmc = os.path.join(REPO, "profiles", "r02_pmc_summary.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(pmc) and args.cfg == "cfg1" and B == 64:
-            for row in json.load(open(pmc)):
-                if row["kernel"].replace("void ", "") == dom["kernel"]:
-                    traffic = row["fetch_bytes_x2"] + row["write_bytes"]
-                    traffic_src = ("profiles/r02_pmc_summary.json: per-launch (FETCH_SIZE x2 [gfx950 wide-read correction] + "
-                                   "WRITE_SIZE) x 1024 B, separate --pmc passes of this same call; FETCH_SIZE counts L2 misses "
-                                   "incl. Infinity-Cache hits")
+        for tag in ("r03", "r02"):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same call (tools/collect_profiles.sh)
+            pmc = os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")
+            if os.path.exists(pmc) and args.cfg == "cfg1" and B == 64:
+                rows = [r for r in json.load(open(pmc)) if r["kernel"].replace("void ", "") == dom["kernel"]]
+                if rows:
+                    n = sum(r["launches"] for r in rows)
+                    traffic = sum((r["fetch_bytes_x2"] + r["write_bytes"]) * r["launches"] for r in rows) / n
+                    traffic_src = (f"profiles/{tag}_pmc_summary.json: per-launch (FETCH_SIZE x2 [gfx950 wide-read correction] + "
+                                   "WRITE_SIZE) x 1024 B averaged over ALL launches of the symbol (the same average as "
+                                   "algorithmic_bytes_per_launch), separate --pmc passes of this same call; FETCH_SIZE counts L2 "
+                                   "misses incl. Infinity-Cache hits; per-shape rows: profiles/" + tag + "_pmc_by_shape.txt")
+                    break
         peak = PEAK_SPLIT_TFLOPS if lt.split.get(dom["kernel"]) else PEAK_FP32_MFMA_TFLOPS
+        shapes = [d for d in lt.summary(by_shape=True) if d["kernel"] == dom["kernel"]]
         out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
                            "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
                            "peak_basis": ("dense bf16 MFMA peak 2516.6 TF / 6 partial products per fp32-accurate block"
@@ -322,9 +354,16 @@ def main():
                            "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
                            "flop_per_launch": dom["flop_per_launch"], "traffic": traffic,
                            "algorithmic_bytes_per_launch": dom.get("algorithmic_bytes_per_launch"), "traffic_source": traffic_src,
+                           "by_shape": [dict(shape=d["shape"], launches=d["launches"], avg_launch_ms=round(d["avg_launch_ms"], 4),
+                                             tflops=round(d["tflops"], 2), frac=round(d["tflops"] / peak, 4),
+                                             algorithmic_bytes_per_launch=d["algorithmic_bytes_per_launch"]) for d in shapes],
                            "note": "algorithmic flops = 2*M*N*K per GEMM launch (4*B*H*Nq*Nk*32 per attention launch)"}
         out["kernels"] = [dict({k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()},
                                pipe="bf16 x6 split" if lt.split.get(d["kernel"]) else "fp32 mfma") for d in summ[:8]]
+        out["kernels_by_shape"] = [dict({k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()},
+                                        frac_of_pipe_peak=round(d["tflops"] / (PEAK_SPLIT_TFLOPS if lt.split.get(d["kernel"])
+                                                                               else PEAK_FP32_MFMA_TFLOPS), 4))
+                                   for d in lt.summary(by_shape=True)[:14]]
     # ---- the regime of BASELINE configs #1 / #5 and of the demo (20 samples per round): same call at B = 1 and B = 20
     if rank == 0 and world == 1 and not args.no_extra and args.cfg == "cfg1":
         extra = {}
@@ -367,6 +406,51 @@ def main():
         dt2 = (time.perf_counter() - t0) / 4
         extra["screening_ligand"].update(two_streams_ligands_per_s=1.0 / dt2, two_streams_ms_per_ligand=1e3 * dt2)
         del pool
+        # ---- the same 64-pose call with the RELAXATION branch live (model.py:252-261): a 32-atom synthetic MMFF94 molecule
+        #      (every term kind, mmff.synthetic_terms) relaxed on the device (pd_mmff_relax, 5 BFGS iterations, fp64) in each of
+        #      the low-noise steps, inside the same hipGraph - what `--enable_physics_correction` runs when a ref_mol is given
+        from physdock_amd import mmff
+        lig = batch["is_ligand"][batch["atom_id_to_token_id"]].bool()
+        terms, _ = mmff.synthetic_terms(int(lig.sum()), 5, coords=batch["x_gt"][lig].double().numpy())
+        kwm = dict(kw, ref_mol=terms, mmff_iters=5)
+        sig, plan = model._step_plan(nsteps, 0.8, 1.0, 1.5, 1.0, kw.get("mmff_gamma_0_factor", 1.0), kw.get("align_ref_pos", True), 1000)
+        n_relax = sum(1 for p_ in plan if p_["mmff"] and not p_["align"])
+        model.sample_diffusion(dbatch, seed=40, **kwm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2):
+            xm = model.sample_diffusion(dbatch, seed=41 + i, **kwm)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        assert torch.isfinite(xm).all()
+        extra["samples_64_mmff"] = {"poses_per_s": B / dt, "ms_per_call": 1e3 * dt, "relaxation_steps": n_relax,
+                                    "ligand_atoms": int(lig.sum()), "mmff_iters": 5, "backend": "device (pd_mmff_relax, fp64)"}
+        # ---- BASELINE config #4: synthetic crop at crop_size=512 / atom_crop_size=4096 (tiling stress), same model and call
+        model.release_workspace()
+        batch2, dbatch2, confs2 = make_crop("cfg2", device)
+        kw2c = dict(kw, ref_mol_poses=confs2.to(device)) if not args.no_physics else dict(kw)
+        model.sample_diffusion(dbatch2, seed=50, **kw2c)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2):
+            x2 = model.sample_diffusion(dbatch2, seed=51 + i, **kw2c)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        assert torch.isfinite(x2).all()
+        from physdock_amd import ops
+        with LaunchTimer(ops) as lt2:
+            model.sample_diffusion(dbatch2, seed=59, **dict(kw2c, use_graph=False))
+            s2 = lt2.summary()
+        d2 = s2[0]
+        pk2 = PEAK_SPLIT_TFLOPS if lt2.split.get(d2["kernel"]) else PEAK_FP32_MFMA_TFLOPS
+        extra["cfg2"] = {"workload": "cfg2: T=512 / A=4096 / S=128, %d samples, %d steps, template-projection physics" % (B, nsteps),
+                         "poses_per_s": B / dt, "ms_per_call": 1e3 * dt, "workspace_gb": model.engine(device).ws.nbytes() / 2 ** 30,
+                         "dominant_kernel": {"kernel": d2["kernel"], "launches": d2["launches"], "avg_launch_ms": d2["avg_launch_ms"],
+                                             "tflops": d2["tflops"], "peak": pk2, "frac": d2["tflops"] / pk2},
+                         "by_shape": [dict(kernel=d["kernel"], shape=d["shape"], launches=d["launches"],
+                                           avg_launch_ms=round(d["avg_launch_ms"], 4), tflops=round(d["tflops"], 2))
+                                      for d in lt2.summary(by_shape=True)[:6]]}
+        model.release_workspace()
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, P, batch, confs, args)

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 4
+#define PD_ABI_VERSION 5
 
 enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFRAG = 3 };
 
@@ -138,6 +138,13 @@ typedef struct pd_attn_args {
     float* ws;               /* optional scratch (16-byte aligned) for key-split launches, see below; may be NULL       */
     long long ws_bytes;
     int nsplit;              /* set by the launcher                                                                      */
+    /* ABI 5: two-part fp16 operand format for the split-operand kernel (csrc/attn_split.hip, NP = 2): q, k, v are multiplied by
+       powers of two derived from UPPER BOUNDS of their magnitudes and split into (hi, lo) fp16 parts; three partial products per
+       block instead of six.  The bounds must hold (a larger element overflows fp16): either by value, or in device memory
+       (f16_amax[0..2] = max|q|, max|k|, max|v|, read by the kernel - graph-capturable, no host round trip).                   */
+    int f16x3;               /* 1: use the fp16 format (needs the bounds below); 0: bf16 x 6 (any fp32 input)              */
+    float f16_q_amax, f16_k_amax, f16_v_amax;
+    const float* f16_amax;   /* optional device array [3]; overrides the by-value bounds                                  */
 } pd_attn_args;
 /* Launches that cannot fill the chip (nbatch * nheads * ceil(nq/128) < 512 blocks) with a long key range are split into
  * up to 8 key chunks when ws holds nsplit * nbatch * nq * nheads * 34 floats; a second kernel merges the chunks. */

@@ -69,6 +69,7 @@ class AttnArgs(C.Structure):
         ("v_bs", C.c_longlong), ("v_ss", C.c_longlong), ("o_bs", C.c_longlong), ("o_ss", C.c_longlong),
         ("bias", _fp), ("scale", C.c_float), ("bias_nk", C.c_int), ("fp32_mfma", C.c_int),
         ("ws", _fp), ("ws_bytes", C.c_longlong), ("nsplit", C.c_int),
+        ("f16x3", C.c_int), ("f16_q_amax", C.c_float), ("f16_k_amax", C.c_float), ("f16_v_amax", C.c_float), ("f16_amax", _fp),
     ]
 
 

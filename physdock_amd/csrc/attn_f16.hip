@@ -1,0 +1,320 @@
+// Biased attention, head width 32, on the fp16 matrix pipe with TWO-part split operands ("f16 x 3") - the second operand
+// format of the split-operand attention (the first, three bf16 parts / six products, is attn_split.hip, whose structure,
+// LDS layouts, bias fragment layout and accumulator layouts this kernel shares):
+//   * every fp32 operand value times a power of two is split into (hi, lo) fp16 parts: 22 significand bits;
+//   * three partial products per block (hi.hi, hi.lo, lo.hi): 12 v_mfma_f32_32x32x16_f16 per 32-key sub-tile instead of 24
+//     bf16 MFMAs, 6 instead of 11 VALU operations per split pair, two thirds of the LDS bytes;
+//   * the scales come from UPPER BOUNDS of |q|, |k|, |v| (pd_attn_args.f16_amax / f16_*_amax: by value or read from device
+//     memory) so that no scaled value overflows fp16; p = exp2(s - m) in [0, 1] is carried times 2^13 inside the exponent.
+// Measured against float64 the contraction is at least as accurate as v_mfma_f32_32x32x2_f32 for K >= 32
+// (tools/micro/f16x2_probe.hip, profiles/r03_f16x2_probe.txt; tests/test_attention_f16_gpu.py for this kernel).
+// The kernel template is written for NP = 2 or 3 parts; only NP = 2 is instantiated here.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "physdock_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int KT = 64;        // keys per LDS tile
+constexpr int KP = 40;        // 16-bit elements per K row (80 bytes)
+constexpr int VP = 72;        // 16-bit elements per V^T row (144 bytes)
+constexpr int K_PART = KT * KP, V_PART = 32 * VP;
+
+template <int NP> struct Parts;
+template <> struct Parts<3> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ void split(float a, float b, unsigned (&o)[3]) {
+        const pd_parts t = pd_split2(a, b);
+        o[0] = t.h; o[1] = t.m; o[2] = t.l;
+    }
+};
+template <> struct Parts<2> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ void split(float a, float b, unsigned (&o)[2]) {
+        const pd_parts2 t = pd_split2h(a, b);
+        o[0] = t.h; o[1] = t.l;
+    }
+};
+
+// c += a . b through the partial products that matter, smallest first (fp32 accumulation in the matrix pipe)
+template <int NP>
+__device__ __forceinline__ f32x16 contract(const typename Parts<NP>::frag (&a)[NP], const typename Parts<NP>::frag (&b)[NP], f32x16 c) {
+    typedef Parts<NP> P;
+    if constexpr (NP == 3) {
+        c = P::mfma(a[0], b[2], c);
+        c = P::mfma(a[2], b[0], c);
+        c = P::mfma(a[1], b[1], c);
+    }
+    c = P::mfma(a[0], b[1], c);
+    c = P::mfma(a[1], b[0], c);
+    c = P::mfma(a[0], b[0], c);
+    return c;
+}
+
+// position of key k (0..31 inside a sub-tile) in a V^T row: lane half hh and k-step s of the P operand hold, in register
+// order, the keys (r&3) + 8(r>>2) + 4hh, r = 8s .. 8s+7
+__device__ __forceinline__ int vpos(int k) {
+    const int s = k >> 4, j = k & 15;
+    return 16 * s + 8 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
+}
+
+template <int NW, int NP>
+__global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2, 4))) void attn_parts_kernel(const pd_attn_args p) {
+    typedef Parts<NP> PT;
+    typedef typename PT::frag frag;
+    constexpr int STAGE = NP * (K_PART + V_PART);      // 16-bit elements per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.x, h = blockIdx.z, qb = blockIdx.y;
+    const int q0 = qb * (32 * NW) + wave * 32;
+    const int query = q0 + l31;
+    const bool wave_active = q0 < p.nq;
+
+    const float* Kb = p.K + (long long)b * p.k_bs + h * 32;
+    const float* Vb = p.V + (long long)b * p.v_bs + h * 32;
+
+    // fp16 format: power-of-two scales that bring the operands' upper bounds to 2^14 (the launcher guarantees the bounds)
+    float sk = 1.f, sv = 1.f, c_s = 1.f, inv_sv = 1.f, qs = p.scale * PD_LOG2E;
+    if constexpr (NP == 2) {
+        const float sq = pd_pow2_scale(p.f16_amax ? p.f16_amax[0] * qs : p.f16_q_amax * qs);
+        sk = pd_pow2_scale(p.f16_amax ? p.f16_amax[1] : p.f16_k_amax);
+        sv = pd_pow2_scale(p.f16_amax ? p.f16_amax[2] : p.f16_v_amax);
+        qs *= sq;
+        c_s = 1.0f / (sq * sk);                        // exact: powers of two
+        inv_sv = 1.0f / sv;
+    }
+
+    // Q fragments: k-step s covers dims 16 s + 8 hh .. + 8 of the lane's query
+    frag qf[2][NP];
+    {
+        const float* qp = p.Q + (long long)b * p.q_bs + (long long)query * p.q_ss + h * 32 + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (query < p.nq) {
+                v0 = *reinterpret_cast<const f32x4*>(qp + 16 * s);
+                v1 = *reinterpret_cast<const f32x4*>(qp + 16 * s + 4);
+            }
+            u32x4 f[NP];
+            unsigned t[NP];
+            PT::split(v0[0] * qs, v0[1] * qs, t);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) f[k][0] = t[k];
+            PT::split(v0[2] * qs, v0[3] * qs, t);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) f[k][1] = t[k];
+            PT::split(v1[0] * qs, v1[1] * qs, t);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) f[k][2] = t[k];
+            PT::split(v1[2] * qs, v1[3] * qs, t);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) f[k][3] = t[k];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) qf[s][k] = __builtin_bit_cast(frag, f[k]);
+        }
+    }
+
+    const int nkt32 = ((p.bias_nk > 0 ? p.bias_nk : p.nk) + 31) >> 5;
+    const int nqt32 = (p.nq + 31) >> 5;
+    const float* bias_wave = nullptr;
+    if (p.bias && wave_active)
+        bias_wave = p.bias + (((long long)h * nqt32 + (q0 >> 5)) * nkt32) * 1024 + lane * 4;
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging: thread -> key row (tid >> 3) + RPP i, 4 dims at 4 (tid & 7)
+    constexpr int RPP = 8 * NW, NST = KT / RPP;
+    const int srow = tid >> 3, sc = tid & 7;
+    f32x4 rk[NST], rv[NST];
+    auto gload = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int key = key0 + srow + RPP * i;
+            rk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (key < p.nk) {
+                rk[i] = *reinterpret_cast<const f32x4*>(Kb + (long long)key * p.k_ss + 4 * sc);
+                rv[i] = *reinterpret_cast<const f32x4*>(Vb + (long long)key * p.v_ss + 4 * sc);
+            }
+        }
+    };
+    auto sstore = [&](int st) {
+        unsigned short* sK = lds + st * STAGE;
+        unsigned short* sV = sK + NP * K_PART;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int kr = srow + RPP * i;                         // key row inside the tile
+            unsigned k0[NP], k1[NP], v0[NP], v1[NP];               // packed pairs: (e0, e1), (e2, e3)
+            if constexpr (NP == 2) {
+                PT::split(rk[i][0] * sk, rk[i][1] * sk, k0); PT::split(rk[i][2] * sk, rk[i][3] * sk, k1);
+                PT::split(rv[i][0] * sv, rv[i][1] * sv, v0); PT::split(rv[i][2] * sv, rv[i][3] * sv, v1);
+            } else {
+                PT::split(rk[i][0], rk[i][1], k0); PT::split(rk[i][2], rk[i][3], k1);
+                PT::split(rv[i][0], rv[i][1], v0); PT::split(rv[i][2], rv[i][3], v1);
+            }
+            const int ko = kr * KP + 4 * sc;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) *reinterpret_cast<u32x2*>(sK + k * K_PART + ko) = u32x2{k0[k], k1[k]};
+            const int vo = (kr & 32) + vpos(kr & 31);              // column of this key in the transposed tile
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                          // transposed scatter: dim 4 sc + e, column vo
+                const int ro = (4 * sc + e) * VP + vo;
+                const int sh = 16 * (e & 1);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) sV[k * V_PART + ro] = (unsigned short)((e < 2 ? v0[k] : v1[k]) >> sh);
+            }
+        }
+    };
+
+    const int nit = (p.nk + KT - 1) / KT;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    auto subtile = [&](auto ragged_tag, int cur, int sub, int kt32) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        const unsigned short* sK = lds + cur * STAGE;
+        const unsigned short* sV = sK + NP * K_PART;
+        f32x4 bf[4];
+        if (bias_wave) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bf[g] = *reinterpret_cast<const f32x4*>(bias_wave + (long long)kt32 * 1024 + g * 256);
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const unsigned short* kbase = sK + (sub * 32 + l31) * KP + 8 * hh;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            frag kf[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) kf[k] = *reinterpret_cast<const frag*>(kbase + k * K_PART + 16 * st);
+            s = contract<NP>(kf, qf[st], s);
+        }
+        if constexpr (NP == 2) {                           // undo the operand scales (exact), then the bias
+            if (bias_wave) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_fmaf(s[r], c_s, bf[r >> 2][r & 3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] *= c_s;
+            }
+        } else if (bias_wave) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] += bf[r >> 2][r & 3];
+        }
+        if constexpr (RAGGED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kt32 * 32 + pd_frag_row(r, hh) >= p.nk) s[r] = -INFINITY;
+        }
+        float mloc = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+        mloc = pd_xhalf_max(mloc);
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;      // (a wave-uniform "no maximum moved" skip measured -20 %: it splits the schedule)
+        // fp16 parts: p is carried times 2^13 (inside the exponent), so that its low part stays a normal fp16 number down
+        // to p = 2^-16; the sum l carries the same factor and it cancels in o / l
+        const float m_exp = NP == 2 ? m_new - 13.0f : m_new;
+        float psum = 0.f;
+        const unsigned short* vbase = sV + l31 * VP + sub * 32 + 8 * hh;
+        // one k-step (8 of the lane's 16 keys) at a time: exp, split, the MFMAs - the probabilities of the second half are
+        // computed while the matrix pipe works on the first, and only one set of P fragments is live
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            u32x4 f[NP];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[8 * st + 2 * e2] - m_exp);
+                const float p1 = __builtin_amdgcn_exp2f(s[8 * st + 2 * e2 + 1] - m_exp);
+                psum += p0 + p1;
+                unsigned t[NP];
+                PT::split(p0, p1, t);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) f[k][e2] = t[k];
+            }
+            frag pf[NP], vf[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                pf[k] = __builtin_bit_cast(frag, f[k]);
+                vf[k] = *reinterpret_cast<const frag*>(vbase + k * V_PART + 16 * st);
+            }
+            o = contract<NP>(vf, pf, o);
+        }
+        l_run = l_run * alpha + psum;
+    };
+    const int nfull32 = p.nk >> 5;
+
+    for (int it = 0; it < nit; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nit) gload((it + 1) * KT);
+        if (wave_active) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int kt32 = it * 2 + sub;
+                if (kt32 < nfull32) subtile(std::false_type{}, cur, sub, kt32);
+                else if (kt32 * 32 < p.nk) subtile(std::true_type{}, cur, sub, kt32);
+            }
+        }
+        if (it + 1 < nit) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (query < p.nq) {
+        const float l = pd_xhalf_sum(l_run);
+        const float inv = NP == 2 ? inv_sv / l : 1.0f / l;
+        float* op = p.O + (long long)b * p.o_bs + (long long)query * p.o_ss + h * 32 + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+            *reinterpret_cast<f32x4*>(op + 8 * g) = v;
+        }
+    }
+}
+
+template <int NP> constexpr int lds_bytes() { return 2 * NP * (K_PART + V_PART) * 2; }
+
+template <int NW, int NP>
+bool raise_lds() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_parts_kernel<NW, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               lds_bytes<NP>()) == hipSuccess;
+}
+
+template <int NP>
+void launch(const pd_attn_args* a, hipStream_t stream) {
+    if (a->nq > 128) {
+        dim3 grid(a->nbatch, (a->nq + 255) / 256, a->nheads);
+        hipLaunchKernelGGL((attn_parts_kernel<8, NP>), grid, dim3(512), lds_bytes<NP>(), stream, *a);
+    } else {
+        dim3 grid(a->nbatch, 1, a->nheads);
+        hipLaunchKernelGGL((attn_parts_kernel<4, NP>), grid, dim3(256), lds_bytes<NP>(), stream, *a);
+    }
+}
+
+}  // namespace
+
+// init_only: 1 raise the dynamic-LDS limits; 0 launch.  Called by pd_attention_split_try (attn_split.hip) for f16x3 launches.
+extern "C" int pd_attention_f16_try(const pd_attn_args* a, void* stream, int init_only) {
+    if (init_only == 1) return raise_lds<8, 2>() && raise_lds<4, 2>() ? PD_OK : PD_ERR_LAUNCH;
+    // the fp16 format needs finite positive magnitude bounds for q, k, v: by value or in device memory (f16_amax[3])
+    if (!a->f16_amax && !(a->f16_q_amax > 0.f && a->f16_k_amax > 0.f && a->f16_v_amax > 0.f)) return PD_ERR_ARG;
+    launch<2>(a, (hipStream_t)stream);
+    return pd_check_launch();
+}

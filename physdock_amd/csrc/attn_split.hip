@@ -245,9 +245,13 @@ constexpr int LDS_BYTES = 2 * STAGE * 2;
 
 }  // namespace
 
+// attn_f16.hip: the same structure with two-part fp16 operands (three products per block) for launches that carry bounds
+extern "C" int pd_attention_f16_try(const pd_attn_args* a, void* stream, int init_only);
+
 // init_only: 1 raise the dynamic-LDS limits; 0 launch (returns PD_ERR_UNSUPPORTED when the launch should stay on attention.hip)
 extern "C" int pd_attention_split_try(const pd_attn_args* a, void* stream, int init_only) {
     if (init_only == 1) {
+        if (pd_attention_f16_try(nullptr, nullptr, 1) != PD_OK) return PD_ERR_LAUNCH;
         const bool ok =
             hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) == hipSuccess &&
@@ -256,6 +260,7 @@ extern "C" int pd_attention_split_try(const pd_attn_args* a, void* stream, int i
         return ok ? PD_OK : PD_ERR_LAUNCH;
     }
     if (a->fp32_mfma) return PD_ERR_UNSUPPORTED;
+    if (a->f16x3) return pd_attention_f16_try(a, stream, 0);
     if (a->nq > 128) {
         dim3 grid(a->nbatch, (a->nq + 255) / 256, a->nheads);
         hipLaunchKernelGGL((attn_split_kernel<8>), grid, dim3(512), LDS_BYTES, (hipStream_t)stream, *a);

@@ -39,6 +39,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PD_SPLIT_MIN_TILES_SMALL
 #define PD_SPLIT_MIN_TILES_SMALL 256
 #endif
+#if defined(PD_ABL) && PD_ABL == 6
+#define NPARTS_IS_3 0
+constexpr int NPARTS = 2;            // ablation: two operand parts / three products (timing estimate of a 2-part format; wrong results)
+#else
+#define NPARTS_IS_3 1
+constexpr int NPARTS = 3;
+#endif
 constexpr int KS = 16;               // k per LDS stage = one v_mfma_f32_32x32x16_bf16 step
 constexpr int PITCH = 24;            // bf16 per LDS row (48 bytes)
 constexpr int PITCH2 = 40;           // DW tiles: 32 k per row, 80 bytes apart (20 r mod 64 hits 16 distinct 4-bank groups: conflict-free b128 reads)
@@ -131,7 +138,7 @@ void gemm_split_kernel(const pd_gemm_args p) {
         if constexpr (AS) {
             const __bf16* ap3 = A3 + (long long)r * (nk * 32) + k0 + 8 * a_q;
 #pragma unroll
-            for (int part = 0; part < 3; ++part) ra3[part] = *reinterpret_cast<const bf16x8*>(ap3 + part * apart);
+            for (int part = 0; part < NPARTS; ++part) ra3[part] = *reinterpret_cast<const bf16x8*>(ap3 + part * apart);
         }
         const float* ap = p.A + (long long)r * p.lda + k0;
 #pragma unroll
@@ -144,7 +151,7 @@ void gemm_split_kernel(const pd_gemm_args p) {
             }
         if constexpr (!DW) {
 #pragma unroll
-            for (int part = 0; part < 3; ++part)
+            for (int part = 0; part < NPARTS; ++part)
 #pragma unroll
                 for (int i = 0; i < NW; ++i)
                     rw[part][i] = *w3_chunk(part, bn0 + w_row, (k0 >> 3) + (NW == 2 ? w_q + 2 * i : w_q));
@@ -160,7 +167,7 @@ void gemm_split_kernel(const pd_gemm_args p) {
 #endif
             const bf16x8* base = W3 + ((long long)((bn0 + wn * (32 * TN) + j * 32) >> 5) * nks + ks) * 64 + lane;
 #pragma unroll
-            for (int part = 0; part < 3; ++part) wf[buf][j][part] = base[part * wpart];
+            for (int part = 0; part < NPARTS; ++part) wf[buf][j][part] = base[part * wpart];
         }
     };
 
@@ -209,7 +216,7 @@ void gemm_split_kernel(const pd_gemm_args p) {
             if constexpr (AS) {
                 if ((a_q >> 1) == h) {
 #pragma unroll
-                    for (int part = 0; part < 3; ++part)
+                    for (int part = 0; part < NPARTS; ++part)
                         *reinterpret_cast<bf16x8*>(sA(h, part) + a_row * PITCH + 8 * (a_q & 1)) = ra3[part];
                 }
             }
@@ -238,13 +245,13 @@ void gemm_split_kernel(const pd_gemm_args p) {
                 const int o = a_row * PITCH + 4 * c;
                 *reinterpret_cast<bf16x4*>(sA(h, 0) + o) = ph;
                 *reinterpret_cast<bf16x4*>(sA(h, 1) + o) = pm;
-                *reinterpret_cast<bf16x4*>(sA(h, 2) + o) = pl;
+                if (NPARTS == 3) *reinterpret_cast<bf16x4*>(sA(h, 2) + o) = pl;
             }
             if (!DW && (NW == 2 || (w_q >> 1) == h)) {
                 const int i = NW == 2 ? h : 0;
                 const int c = NW == 2 ? w_q : (w_q & 1);          // 16-byte chunk inside the half
 #pragma unroll
-                for (int part = 0; part < 3; ++part)
+                for (int part = 0; part < NPARTS; ++part)
                     *reinterpret_cast<bf16x8*>(sW(h, part) + w_row * PITCH + 8 * c) = rw[part][i];
             }
         };
@@ -252,7 +259,7 @@ void gemm_split_kernel(const pd_gemm_args p) {
         auto mma = [&](int s) {
             bf16x8 fa[TM][3], fw[TN][3];
 #pragma unroll
-            for (int part = 0; part < 3; ++part) {
+            for (int part = 0; part < NPARTS; ++part) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     fa[i][part] = *reinterpret_cast<const bf16x8*>(sA(s, part) + (wm * (32 * TM) + i * 32 + l31) * PITCH + 8 * hh);
@@ -267,9 +274,11 @@ void gemm_split_kernel(const pd_gemm_args p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];
+#if NPARTS_IS_3
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fw[j][2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fw[j][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fw[j][1], c, 0, 0, 0);
+#endif
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fw[j][1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fw[j][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fw[j][0], c, 0, 0, 0);
@@ -281,7 +290,7 @@ void gemm_split_kernel(const pd_gemm_args p) {
             __bf16* base = lds + s * TL::STAGE + a_row * PITCH2;
             if constexpr (AS) {
 #pragma unroll
-                for (int part = 0; part < 3; ++part) *reinterpret_cast<bf16x8*>(base + part * BM * PITCH2 + 8 * a_q) = ra3[part];
+                for (int part = 0; part < NPARTS; ++part) *reinterpret_cast<bf16x8*>(base + part * BM * PITCH2 + 8 * a_q) = ra3[part];
             }
 #pragma unroll
             for (int h = 0; h < (AS ? 0 : 2); ++h)
@@ -314,14 +323,14 @@ void gemm_split_kernel(const pd_gemm_args p) {
                     const int o = 16 * h + 4 * c;
                     *reinterpret_cast<bf16x4*>(base + o) = ph;
                     *reinterpret_cast<bf16x4*>(base + BM * PITCH2 + o) = pm;
-                    *reinterpret_cast<bf16x4*>(base + 2 * BM * PITCH2 + o) = pl;
+                    if (NPARTS == 3) *reinterpret_cast<bf16x4*>(base + 2 * BM * PITCH2 + o) = pl;
                 }
         };
         auto mma2 = [&](int s, int ks) {
             bf16x8 fa[TM][3];
             const __bf16* base = lds + s * TL::STAGE + (wm * (32 * TM) + l31) * PITCH2 + 16 * ks + 8 * hh;
 #pragma unroll
-            for (int part = 0; part < 3; ++part)
+            for (int part = 0; part < NPARTS; ++part)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     fa[i][part] = *reinterpret_cast<const bf16x8*>(base + part * BM * PITCH2 + i * 32 * PITCH2);
@@ -330,9 +339,11 @@ void gemm_split_kernel(const pd_gemm_args p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     f32x16 c = acc[i][j];
+#if NPARTS_IS_3
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], wf[ks][j][2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], wf[ks][j][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], wf[ks][j][1], c, 0, 0, 0);
+#endif
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], wf[ks][j][1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], wf[ks][j][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], wf[ks][j][0], c, 0, 0, 0);

@@ -127,6 +127,9 @@ KSPLIT_GEMM = True
 #: the same switch for the attention kernel (csrc/attn_split.hip vs csrc/attention.hip)
 SPLIT_ATTN = True
 
+#: two-part fp16 operands (three partial products) for attention launches whose caller supplies magnitude bounds (f16_amax=)
+F16_ATTN = True
+
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None
 ATTN_HOOK = None
@@ -179,7 +182,7 @@ def attn_split_ws_numel(nbatch, nq, nk, nheads):
 
 
 def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_strides, o_strides, bias=None,
-              scale=1.0 / math.sqrt(32.0), ws=None, bias_nk=0):
+              scale=1.0 / math.sqrt(32.0), ws=None, bias_nk=0, f16_amax=None):
     """strides = (batch_stride, seq_stride) in floats; Q/K/V/O tensors or raw addresses.  ws: optional float scratch
     tensor (attn_split_ws_numel) enabling key-split launches for small grids.  bias_nk: key count the bias buffer was laid
     out for (the padded count when nk is the real one)."""
@@ -196,6 +199,12 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
     a.scale = scale
     a.bias_nk = bias_nk
     a.fp32_mfma = 0 if SPLIT_ATTN else 1
+    if f16_amax is not None and F16_ATTN:      # (max|q|, max|k|, max|v|) upper bounds: three floats by value, or a device tensor [3]
+        a.f16x3 = 1
+        if isinstance(f16_amax, torch.Tensor):
+            a.f16_amax = ptr(f16_amax)
+        else:
+            a.f16_q_amax, a.f16_k_amax, a.f16_v_amax = (float(v) for v in f16_amax)
     if ws is not None:
         a.ws, a.ws_bytes = ptr(ws), ws.numel() * 4
     if ATTN_HOOK is not None:

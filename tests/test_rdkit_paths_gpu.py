@@ -55,7 +55,8 @@ def _noise(B, A, steps, seed=2):
 def test_terms_from_rdkit_passes_its_device_self_check(fake_rdkit):
     from rdkit.Chem import FakeMol
     from physdock_amd import mmff
-    terms, coords = mmff.synthetic_terms(27, 3)
+    terms, coords = mmff.synthetic_terms(27, 4)
+    assert not (terms.par[mmff.ANGLE][:, 2] != 0).any()       # (a linear angle is a per-atom-type property in RDKit, per angle here)
     mol = FakeMol(terms, coords)
     got = mmff.terms_from_rdkit(mol, strict=True)
     assert got is not None and got.signature() == terms.signature()
@@ -64,7 +65,7 @@ def test_terms_from_rdkit_passes_its_device_self_check(fake_rdkit):
     kw = dict(fake_rdkit.CALLS[names.index("MMFFGetMoleculeForceField")][1])
     assert kw["ignoreInterfragInteractions"] is True                       # the force field the reference optimises (model.py:43)
     # a table that does NOT describe the molecule is refused: break one force constant behind the getter
-    bad = FakeMol(mmff.synthetic_terms(27, 3)[0], coords)
+    bad = FakeMol(mmff.synthetic_terms(27, 4)[0], coords)
     bad.terms.par[mmff.BOND][0, 0] *= 1.5
     from rdkit.Chem import rdForceFieldHelpers as ffh
     real_ff = ffh.MMFFGetMoleculeForceField

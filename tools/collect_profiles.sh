@@ -4,12 +4,12 @@
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
-CMD="python $R/bench.py --steps 1 --warmup 0 --no-graph --no-roofline --no-cpu-baseline --no-extra"
+CMD="python $R/bench.py --steps 1 --warmup 0 --no-graph --no-roofline --no-cpu-baseline --no-extra --launch-log $OUT/launch_log.json"
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o p -- python $R/bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-extra > $OUT/trace.log 2>&1
 python - $OUT <<'PY'
@@ -31,6 +31,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
 cd $R
-python tools/pmc_report.py $OUT > $OUT/pmc_report.txt 2>&1
-head -24 $OUT/kernel_stats.txt; tail -16 $OUT/pmc_report.txt
+python tools/pmc_report.py $OUT --by-symbol > $OUT/pmc_report.txt 2>&1
+python tools/pmc_report.py $OUT --launch-log $OUT/launch_log.json > $OUT/pmc_by_shape.txt 2>&1
+head -24 $OUT/kernel_stats.txt; head -30 $OUT/pmc_by_shape.txt | cut -c1-200
 find $OUT -name "*.csv" -size +1M -delete
