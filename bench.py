@@ -30,6 +30,18 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6         # same guide: dense bf16 MFMA peak (v_mfm
 #: kernels that contract on the bf16 pipe with 3-way split operands issue SIX bf16 MFMAs per fp32-accurate block, so their
 #: ceiling in algorithmic (fp32-equivalent) FLOP/s is the bf16 peak / 6
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
+
+
+def pipe_peak(nprod):
+    """ceiling in algorithmic (fp32-equivalent) TFLOP/s of a kernel by the number of 16-bit MFMA products it issues per
+    fp32-accurate block: 0 = fp32 MFMA, 6 = three-part bf16 operands, 3 = two-part fp16 operands"""
+    return PEAK_FP32_MFMA_TFLOPS if not nprod else PEAK_BF16_MFMA_TFLOPS / nprod
+
+
+def pipe_name(nprod):
+    return {0: "fp32 mfma", 6: "bf16 x6 split", 3: "f16 x3 split"}.get(int(nprod or 0), "?")
+
+
 DIT_GFLOP_PER_SAMPLE_STEP = 39.8       # SURVEY §8(d), cfg1
 TRUNK_GFLOP = 2742.0                   # SURVEY §8(d), cfg1
 
@@ -189,16 +201,18 @@ class LaunchTimer:
             nb = max(a.batch, 1)
             n_out = a.N // 2 if a.glu else a.N
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))
-            self.split[name] = split
+            self.split[name] = 6 if split else 0
             shape = "M=%d N=%d K=%d" % (a.M, a.N, a.K) + (" x%d" % nb if nb > 1 else "")
             self._launch(name, shape, launch, 2.0 * a.M * a.N * a.K * nb, byt)
 
         def attn_hook(a, launch):
             v = L.pd_attention_variant(C.byref(a))          # 4 / 8 waves per block, or 4 + 100 * key chunks
             name = "attn_kernel<%d, %s>" % (v % 100, "true" if v > 100 else "false")
-            if v >= 1000:       # bf16 matrix pipe, split operands (csrc/attn_split.hip)
+            if v >= 2000:       # fp16 matrix pipe, two-part operands, three products per block (csrc/attn_f16.hip)
+                name = "attn_parts_kernel<%d, 2>" % (v % 100)
+            elif v >= 1000:     # bf16 matrix pipe, three-part operands, six products per block (csrc/attn_split.hip)
                 name = "attn_split_kernel<%d>" % (v % 100)
-            self.split[name] = v >= 1000
+            self.split[name] = 3 if v >= 2000 else (6 if v >= 1000 else 0)
             c = a.nheads * 32                    # q, o: nq rows; k, v: nk rows; the bias tile set is read once per launch
             byt = 4.0 * a.nbatch * c * (2 * a.nq + 2 * a.nk) + (4.0 * a.nheads * a.nq * a.nk if a.bias else 0.0)
             shape = "batch=%d heads=%d nq=%d nk=%d%s" % (a.nbatch, a.nheads, a.nq, a.nk, " bias" if a.bias else "")
@@ -344,12 +358,13 @@ def main():
                                    "algorithmic_bytes_per_launch), separate --pmc passes of this same call; FETCH_SIZE counts L2 "
                                    "misses incl. Infinity-Cache hits; per-shape rows: profiles/" + tag + "_pmc_by_shape.txt")
                     break
-        peak = PEAK_SPLIT_TFLOPS if lt.split.get(dom["kernel"]) else PEAK_FP32_MFMA_TFLOPS
+        peak = pipe_peak(lt.split.get(dom["kernel"]))
         shapes = [d for d in lt.summary(by_shape=True) if d["kernel"] == dom["kernel"]]
         out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
                            "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
-                           "peak_basis": ("dense bf16 MFMA peak 2516.6 TF / 6 partial products per fp32-accurate block"
-                                          if lt.split.get(dom["kernel"]) else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                           "peak_basis": ("dense bf16 / fp16 MFMA peak 2516.6 TF / %d partial products per fp32-accurate block"
+                                          % lt.split[dom["kernel"]] if lt.split.get(dom["kernel"])
+                                          else "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
                            "frac_of_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
                            "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
                            "flop_per_launch": dom["flop_per_launch"], "traffic": traffic,
@@ -359,10 +374,10 @@ def main():
                                              algorithmic_bytes_per_launch=d["algorithmic_bytes_per_launch"]) for d in shapes],
                            "note": "algorithmic flops = 2*M*N*K per GEMM launch (4*B*H*Nq*Nk*32 per attention launch)"}
         out["kernels"] = [dict({k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()},
-                               pipe="bf16 x6 split" if lt.split.get(d["kernel"]) else "fp32 mfma") for d in summ[:8]]
+                               pipe=pipe_name(lt.split.get(d["kernel"]))) for d in summ[:8]]
         out["kernels_by_shape"] = [dict({k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()},
-                                        frac_of_pipe_peak=round(d["tflops"] / (PEAK_SPLIT_TFLOPS if lt.split.get(d["kernel"])
-                                                                               else PEAK_FP32_MFMA_TFLOPS), 4))
+                                        pipe=pipe_name(lt.split.get(d["kernel"])),
+                                        frac_of_pipe_peak=round(d["tflops"] / pipe_peak(lt.split.get(d["kernel"])), 4))
                                    for d in lt.summary(by_shape=True)[:14]]
     # ---- the regime of BASELINE configs #1 / #5 and of the demo (20 samples per round): same call at B = 1 and B = 20
     if rank == 0 and world == 1 and not args.no_extra and args.cfg == "cfg1":
@@ -442,7 +457,7 @@ def main():
             model.sample_diffusion(dbatch2, seed=59, **dict(kw2c, use_graph=False))
             s2 = lt2.summary()
         d2 = s2[0]
-        pk2 = PEAK_SPLIT_TFLOPS if lt2.split.get(d2["kernel"]) else PEAK_FP32_MFMA_TFLOPS
+        pk2 = pipe_peak(lt2.split.get(d2["kernel"]))
         extra["cfg2"] = {"workload": "cfg2: T=512 / A=4096 / S=128, %d samples, %d steps, template-projection physics" % (B, nsteps),
                          "poses_per_s": B / dt, "ms_per_call": 1e3 * dt, "workspace_gb": model.engine(device).ws.nbytes() / 2 ** 30,
                          "dominant_kernel": {"kernel": d2["kernel"], "launches": d2["launches"], "avg_launch_ms": d2["avg_launch_ms"],

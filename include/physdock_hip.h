@@ -84,12 +84,23 @@ typedef struct pd_gemm_args {
     void* ksplit_ws;
     long long ksplit_ws_bytes;
     int ksplit;                  /* set by the launcher                                      */
+    /* ABI 5: two-part fp16 operand format (csrc/gemm_f16.hip: three fp16 MFMAs per block instead of six bf16 ones).  Used when
+       all of W2, w_inv and a_amax are given and the launch is a chip-filling full-tile row-major problem; otherwise the launch
+       falls through to W3 / fp32 as before.  The caller guarantees |A'[m,k]| <= *a_amax for the A the contraction sees (after
+       the prologue): a larger element overflows fp16.  pd_dit_bounds derives such bounds for the DiT blocks.                  */
+    const void* W2;              /* W[n,:] * w_scale[n] as two fp16 parts (hi, lo), fragment-major [2][ceil(N/32)][Kp/16][64][8]
+                                    (packing.split2_f16); w_scale[n] = power of two that brings max_k |W[n,k]| below 2^14      */
+    const float* w_inv;          /* [N]  1 / w_scale[n]                                                                        */
+    const void* A2;              /* optional: A already normalised, modulated, scaled by the power of two pd_gemm derives from
+                                    *a_amax, and split into two fp16 parts [2][M][K] (pd_norm_split2); K % 32 == 0, no prologue  */
+    const float* a_amax;         /* device scalar: upper bound of |A'|                                                         */
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
 /* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling);
  * id % 10000 >= 5000: gemm_stream_kernel<id % 10, (id / 10000) % 10, Tile> (csrc/gemm_stream.hip) takes it,
  * Tile = (id / 100000) % 10: 0 -> <128,128,2>, 1 -> <64,64,2>, 2 -> <128,64,4>; id >= 1000000: the split-operand
- * kernel gemm_split_kernel<...> (csrc/gemm_split.hip) with the same template arguments */
+ * kernel gemm_split_kernel<...> (csrc/gemm_split.hip) with the same template arguments; id >= 2000000: gemm_f16_kernel<...>
+ * (csrc/gemm_f16.hip, two-part fp16 operands) */
 int pd_gemm_variant(const pd_gemm_args* args);
 
 /* ---- pd_rowstats: per-row (mean, rstd) for the GEMM prologue --------------------------
@@ -108,6 +119,10 @@ int pd_rownorm(const float* x, float* y, const float* res, const float* w, const
  * the GEMM that consumes it.  C % 32 == 0.                                                                            */
 int pd_norm_split(const float* x, int ldx, int M, int C, int mode, float eps, const float* w, const float* b,
                   int rows_per_group, int gstride, void* out3, void* stream);
+/* pd_norm_split2 (ABI 5): the same rows times the power of two derived from the device scalar *a_amax (an upper bound of |a'|),
+ * as TWO fp16 parts out2 [2][M][C] (hi, lo) - the pre-split A operand pd_gemm_args.A2 of csrc/gemm_f16.hip.                    */
+int pd_norm_split2(const float* x, int ldx, int M, int C, int mode, float eps, const float* w, const float* b,
+                   int rows_per_group, int gstride, const float* a_amax, void* out2, void* stream);
 
 /* ---- pd_pair_bias: attention pair bias in one streaming pass (pairbias.hip) -------------------
  * frag = fragment layout of [ (norm(x) . Wf^T + c2 + maskadd ? 0 : maskval) * out_scale ] for x [T1*T2, C] (C = 16 or 128),
@@ -150,7 +165,7 @@ typedef struct pd_attn_args {
  * up to 8 key chunks when ws holds nsplit * nbatch * nq * nheads * 34 floats; a second kernel merges the chunks. */
 int pd_attention(const pd_attn_args* args, void* stream);
 /* waves per block (4 or 8 = template argument of attn_kernel) pd_attention picks for these arguments; 4 + 100 * nsplit for
- * a key-split launch; 1000 + waves for attn_split_kernel<waves> (profiling) */
+ * a key-split launch; 1000 + waves for attn_split_kernel<waves>, 2000 + waves for attn_parts_kernel<waves, 2> (profiling) */
 int pd_attention_variant(const pd_attn_args* args);
 
 /* ---- pair-representation / pooling kernels (pair.hip) ----------------------------------
@@ -251,6 +266,12 @@ int pd_pairwise_rmsd(const float* x, const int* idx, const float* ref, float* D,
 int pd_euler(const float* x_hat, const float* x_den, const float* x_proj, const float* w, float t_hat, float eta, float dt,
              float* x_next, int B, int A, void* stream);
 int pd_timestep_embed(const float* tau, float* emb, int n, void* stream);
+/* pd_dit_bounds (ABI 5): rigorous magnitude bounds of a DiT block's activations from the AdaLN table alone, for the two-part fp16
+ * operand format: tab [nrows][ld] holds per DiT block (shift | 1 + scale | gate) x (attention, transition), C channels each;
+ * consts [nblocks][4] = (q bound, k bound, max_n ||Wv_n||_2, max_n ||W1_n||_2 max_n ||W3_n||_2) from the weights;
+ * out [nrows][nblocks][8] = (|q|, |k|, |v| = |o|, |y|, |y'|, |h|, 0, 0) upper bounds (see csrc/sampler.hip for the derivation;
+ * reference adaptive_layer_norm_zero.py:16-21, attentions.py:241-265, transitions.py:27-30).                                   */
+int pd_dit_bounds(const float* tab, int nrows, int ld, int nblocks, int C, const float* consts, float* out, void* stream);
 /* chirality accept / reject of B poses without leaving the device (replaces the per-pose RDKit rebuild + R/S comparison of
  * redocking.py:264-281,303-317): centres[nc][4] = (centre atom, three neighbour atoms), indices into the A atoms of a pose;
  * sign of the signed volume (n1-c).((n2-c)x(n3-c)) vs ref_sign[nc] (+1 / -1); accept[b] = 1 iff every centre matches.

@@ -58,6 +58,7 @@ class GemmArgs(C.Structure):
         ("out_mode", C.c_int), ("T1", C.c_int), ("T2", C.c_int), ("frag_transpose", C.c_int),
         ("vecA", C.c_int), ("vecW", C.c_int), ("vecY", C.c_int),
         ("ksplit_ws", _fp), ("ksplit_ws_bytes", C.c_longlong), ("ksplit", C.c_int),
+        ("W2", _fp), ("w_inv", _fp), ("A2", _fp), ("a_amax", _fp),
     ]
 
 
@@ -156,6 +157,8 @@ def _declare(L):
     sig("pd_euler", p, p, p, p, f, f, f, p, i, i, p)
     sig("pd_pairwise_rmsd", p, p, p, p, p, i, i, i, p)
     sig("pd_timestep_embed", p, p, i, p)
+    sig("pd_dit_bounds", p, i, i, i, i, p, p, p)
+    sig("pd_norm_split2", p, i, i, i, i, f, p, p, i, i, p, p, p)
     sig("pd_mmff_energy_grad", p, p, p, p, i, p)
     sig("pd_mmff_relax", p, p, p, p, p, ll, i, i, i, p)
     sig("pd_chirality", p, p, p, p, p, i, i, i, p)

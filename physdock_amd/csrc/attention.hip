@@ -283,7 +283,7 @@ PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
     // the bf16 split-operand kernel pays off when the launch fills the chip (>= one 32-query wave per SIMD); smaller launches
     // are latency-bound and stay on the fp32-MFMA kernel (with its key-split option)
     if (!a->fp32_mfma && attn_nsplit(a) <= 1 && (long long)a->nbatch * a->nheads * ((a->nq + 31) / 32) >= 1024)
-        return 1000 + (a->nq > 128 ? 8 : 4);
+        return (a->f16x3 ? 2000 : 1000) + (a->nq > 128 ? 8 : 4);      // 2000 +: two-part fp16 operands (attn_f16.hip)
 #ifdef PD_LAB
     static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
 #else

@@ -533,13 +533,23 @@ extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, v
 // gemm_split.hip: the same persistent structure on the bf16 matrix pipe (3 x bf16 split operands, needs args->W3)
 extern "C" int pd_gemm_split_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only);
 
-// the persistent kernel family a launch goes to: split-operand bf16 when the caller supplied pre-split weights, else fp32
-static int persistent_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only, bool* split = nullptr) {
+// gemm_f16.hip: the same structure on the fp16 matrix pipe (2 x fp16 split operands with power-of-two scales; needs args->W2,
+// w_inv and the magnitude bound a_amax)
+extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only);
+
+// the persistent kernel family a launch goes to: two-part fp16 operands when the caller supplied scaled weights AND a bound of
+// |A|, three-part bf16 operands when it supplied pre-split weights, else fp32.  *split: 0 fp32, 1 bf16 x 6, 2 f16 x 3
+static int persistent_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only, int* split = nullptr) {
+    if (args && args->W2 && args->w_inv && args->a_amax && !(args->A3 && !args->A2)) {
+        const int r = pd_gemm_f16_try(args, pro, tile, stream, init_only);
+        if (r != PD_ERR_UNSUPPORTED) { if (split) *split = 2; return r; }
+    }
+    if (args && args->A2 && !args->A3) return PD_ERR_UNSUPPORTED;       // a pre-split fp16 A is readable by the fp16 kernel only
     if (args && args->W3) {
         const int r = pd_gemm_split_try(args, pro, tile, stream, init_only);
-        if (r != PD_ERR_UNSUPPORTED) { if (split) *split = true; return r; }
+        if (r != PD_ERR_UNSUPPORTED) { if (split) *split = 1; return r; }
     }
-    if (split) *split = false;
+    if (split) *split = 0;
     return pd_gemm_stream_try(args, pro, tile, stream, init_only);
 }
 
@@ -549,6 +559,7 @@ PD_EXPORT int pd_init(void) {
     int rc = pd_gemm_stream_try(nullptr, 0, 0, nullptr, 1);
     { const int r = pd_attention_init(); if (r != PD_OK) rc = r; }
     { const int r = pd_gemm_split_try(nullptr, 0, 0, nullptr, 1); if (r != PD_OK) rc = r; }
+    { const int r = pd_gemm_f16_try(nullptr, 0, 0, nullptr, 1); if (r != PD_OK) rc = r; }
     for (int cfg = 0; cfg < 4; ++cfg)
         for (int lay = 0; lay < 3; ++lay)
             for (int vec = 0; vec < 2; ++vec)
@@ -658,12 +669,17 @@ PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     pd_gemm_args p = *args;
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
+    if (v >= 0 && (p.A3 || p.A2)) {  // pre-split A: exactly pd_gemm's rule - a split-operand kernel on the whole problem, or nothing
+        int split = 0;
+        const int epi = persistent_try(&p, pro, 128, nullptr, 2, &split);
+        return epi >= 0 && split ? v + 5000 + 10000 * epi + 1000000 * split : v;
+    }
     if (v >= 0 && use_stream() && stream_tile(cfg, p)) {
         pd_gemm_args head, tail;
         const int tile = stream_tile(cfg, p);
-        bool split = false;
+        int split = 0;
         const int epi = persistent_try(split_rows(p, pro, tile, head, tail) ? &head : &p, pro, tile, nullptr, 2, &split);
-        if (epi >= 0) return v + 5000 + 10000 * epi + 100000 * (tile == 128 ? 0 : tile == 64 ? 1 : 2) + (split ? 1000000 : 0);
+        if (epi >= 0) return v + 5000 + 10000 * epi + 100000 * (tile == 128 ? 0 : tile == 64 ? 1 : 2) + 1000000 * split;
     }
     return v;
 }
@@ -674,8 +690,12 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
-    if (p.A3)            // pre-split A: only the split-operand kernel can read it; anything else is an error, never the raw A
-        return pd_gemm_split_try(&p, pro, 128, stream, 0);
+    if (p.A3 || p.A2) {  // pre-split A: only a split-operand kernel can read it; anything else is an error, never the raw A
+        int split = 0;
+        const int q = persistent_try(&p, pro, 128, nullptr, 2, &split);
+        if (q < 0 || !split) return PD_ERR_UNSUPPORTED;
+        return split == 2 ? pd_gemm_f16_try(&p, pro, 128, stream, 0) : pd_gemm_split_try(&p, pro, 128, stream, 0);
+    }
     if (use_stream() && stream_tile(cfg, p)) {
         pd_gemm_args head, tail;
         const int tile = stream_tile(cfg, p);

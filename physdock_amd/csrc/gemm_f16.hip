@@ -1,0 +1,419 @@
+// fp32-accurate GEMM on the fp16 matrix pipe: two-part operand splitting with power-of-two scales ("f16 x 3").
+//
+// Second operand format of the split-operand GEMM (the first, three bf16 parts / six products, is gemm_split.hip, whose
+// structure - persistent 128 x 128 tiles on eight waves, XCD-aware tile order, pre-split fragment-major weights fetched
+// straight into MFMA registers, A split while it is staged, epilogues from gemm_tile_common.h - this file shares):
+//   * every operand value times a power of two is split into a = h + l, h = fp16(a), l = fp16(a - h): 22 significand bits
+//     (pd_split2h, common.h), and a product is the sum of three partial products h.h + h.l + l.h, each accumulated in fp32
+//     by v_mfma_f32_32x32x16_f16 - three MFMAs per 32 x 32 x 16 block instead of six, two thirds of the operand bytes through
+//     LDS / registers, 6 instead of 11 VALU operations per split pair.  Effective peak 2.5 PF / 3 = 839 TF;
+//   * measured against float64 (tools/micro/f16x2_probe.hip, profiles/r03_f16x2_probe.txt; tests/test_gemm_f16_gpu.py) the
+//     result is at least as accurate as v_mfma_f32_32x32x2_f32's for every K >= 32 and operand ranges up to 2^+-20 inside
+//     a row - the fp32 MFMA rounds once per product, this one once per 16 products;
+//   * fp16's exponent range is the price: a scaled value above 65504 would overflow.  So the format is used only where an
+//     UPPER BOUND of |A| is known before the launch: the weights are scaled per output row at pack time (exact, w_inv[n]
+//     undoes it in the epilogue), A by 2^e with e from the bound `a_amax` (a device scalar, so launches stay graph-capturable).
+//     In the DiT blocks every A operand has a rigorous bound that follows from LayerNorm + the AdaLN table alone
+//     (pd_dit_bounds, sampler.hip); everything else stays on the bf16 x 6 kernel, which needs no bound.
+// A arrives as fp32 (split while it is staged, after the norm prologue and the scale) or pre-split by pd_norm_split2
+// ([2][M][K] fp16, PRO == 3: the staging is a 16-byte copy).
+#include <stdlib.h>
+#include "gemm_tile_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef PD_F16_MIN_TILES
+#define PD_F16_MIN_TILES 256
+#endif
+constexpr int NPARTS = 2;            // operand parts: (hi, lo) fp16
+constexpr int PITCH = 24;            // LDS-W tiles: 16 k per row, 48 bytes apart
+constexpr int PITCH2 = 40;           // DW tiles: 32 k per row, 80 bytes apart (conflict-free ds_read_b128 fragments)
+
+template <int BM_, int BN_, int WM_, int NWAVES_, bool DW_>
+struct FTile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = NWAVES_ / WM_, NT = 64 * NWAVES_;
+    static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    static constexpr bool DW = DW_;      // direct W: the B fragments go from global memory straight into MFMA registers
+    static constexpr int STAGE = DW ? NPARTS * BM * PITCH2 : NPARTS * (BM + BN) * PITCH;      // fp16 elements per stage
+    static constexpr int LDS_BYTES = 2 * STAGE * 2;
+    static constexpr int BLOCKS_PER_CU = 2;
+    static constexpr int WAVES_PER_SIMD = NWAVES_ * BLOCKS_PER_CU / 4;
+    static constexpr int GRID = 256 * BLOCKS_PER_CU;
+};
+
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0); outstanding global loads stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// four scaled values -> (hi, lo) fp16 parts, two values per packed conversion
+__device__ __forceinline__ void split4h(const f32x4& v, f16x4& h, f16x4& l) {
+    const pd_parts2 p0 = pd_split2h(v[0], v[1]), p1 = pd_split2h(v[2], v[3]);
+    h = __builtin_bit_cast(f16x4, (u32x2){p0.h, p1.h});
+    l = __builtin_bit_cast(f16x4, (u32x2){p0.l, p1.l});
+}
+
+template <int PRO, int EPI, class TL>
+__global__ __launch_bounds__(TL::NT) __attribute__((amdgpu_waves_per_eu(TL::WAVES_PER_SIMD, TL::WAVES_PER_SIMD)))
+void gemm_f16_kernel(const pd_gemm_args p) {
+    constexpr int BM = TL::BM, BN = TL::BN, TM = TL::TM, TN = TL::TN;
+    constexpr int XSLOTS = TL::GRID / 8;
+    constexpr int SNT = TL::NT;
+    constexpr int TPR_A = SNT / BM;              // threads per A row (4); a row of a 32-k slice = 8 f32x4 chunks
+    constexpr int CPH_A = 4 / TPR_A;             // chunks per thread per 16-k half
+    constexpr int TPR_W = SNT / BN;              // threads per W row; a row of a 32-k slice of one part = 4 f16x8 chunks
+    constexpr int NW = 4 / TPR_W;                // W chunks per thread per part per slice
+    constexpr bool DW = TL::DW;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / TL::WN, wn = wave % TL::WN;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int nMb = p.M / BM, nNb = p.N / BN;
+    const int ntiles = nMb * nNb;
+    const int nk = (p.K + 31) / 32;
+    const int nks = 2 * nk;                       // 16-k steps per (zero padded) weight row
+    // pre-split scaled weights, fragment-major: [2 parts][N / 32 row blocks][nks k-steps][64 lanes][8 fp16]
+    const f16x8* __restrict__ W2 = reinterpret_cast<const f16x8*>(p.W2);
+    const long long wpart = (long long)((p.N + 31) / 32) * nks * 64;          // in 16-byte units
+    auto w2_chunk = [&](int part, int n, int kchunk) {                          // kchunk = k / 8
+        return W2 + part * wpart + ((long long)(n >> 5) * nks + (kchunk >> 1)) * 64 + (kchunk & 1) * 32 + (n & 31);
+    };
+    // power-of-two scale of A from its magnitude bound; the epilogue undoes it together with the weights' row scales
+    const float a_s = pd_pow2_scale(*p.a_amax);
+    const float inv_a_s = 1.0f / a_s;
+
+    auto sA = [&](int s, int part) { return lds + s * TL::STAGE + part * BM * PITCH; };
+    auto sW = [&](int s, int part) { return lds + s * TL::STAGE + NPARTS * BM * PITCH + part * BN * PITCH; };
+
+    const int a_row = tid / TPR_A, a_q = tid % TPR_A;
+    const int w_row = tid / TPR_W, w_q = tid % TPR_W;
+    // PRO == 3: A arrives pre-split and pre-scaled (pd_norm_split2, [2][M][Kp] fp16): a thread copies one 16-byte chunk per part
+    constexpr bool AS = PRO == 3;
+    static_assert(!AS || TPR_A == 4, "pre-split A: four 8-k chunks per row slice");
+    const _Float16* __restrict__ A2 = reinterpret_cast<const _Float16*>(p.A2);
+    const long long apart = (long long)p.M * (nk * 32);
+    f16x8 ra2[NPARTS];
+    f32x4 ra[2][CPH_A];                          // [half][i]: chunk 4*half + a_q + TPR_A*i of the thread's row
+    f16x8 rw[NPARTS][NW];
+
+    auto gload = [&](int bm0, int bn0, int k0) {
+        const int r = bm0 + a_row;                // full tiles only: always < M
+        if constexpr (AS) {
+            const _Float16* ap2 = A2 + (long long)r * (nk * 32) + k0 + 8 * a_q;
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part) ra2[part] = *reinterpret_cast<const f16x8*>(ap2 + part * apart);
+        }
+        const float* ap = p.A + (long long)r * p.lda + k0;
+#pragma unroll
+        for (int h = 0; h < (AS ? 0 : 2); ++h)
+#pragma unroll
+            for (int i = 0; i < CPH_A; ++i) {
+                int kc = 16 * h + 4 * (a_q + TPR_A * i);
+                kc = k0 + kc < p.K ? kc : 0;      // clamped address; zeroed in the staging (K % 4 == 0 is required)
+                ra[h][i] = *reinterpret_cast<const f32x4*>(ap + kc);
+            }
+        if constexpr (!DW) {
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    rw[part][i] = *w2_chunk(part, bn0 + w_row, (k0 >> 3) + (NW == 2 ? w_q + 2 * i : w_q));
+        }
+    };
+    // DW: this wave's B fragments of 16-k step `ks` of column block bn0, straight into MFMA operand registers
+    f16x8 wf[2][TN][NPARTS];
+    auto wfrag = [&](int buf, int bn0, int ks) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const f16x8* base = W2 + ((long long)((bn0 + wn * (32 * TN) + j * 32) >> 5) * nks + ks) * 64 + lane;
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part) wf[buf][j][part] = base[part * wpart];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+    const bool grouped = gridDim.x == TL::GRID && nMb >= 8;
+    TileOrder ord;
+    ord.init(nMb, nNb, grouped ? blockIdx.x & 7 : 0, grouped ? 8 : 1, XSLOTS);
+    const int t_step = grouped ? XSLOTS : gridDim.x;
+    const int t_end = grouped ? ord.ntiles : ntiles;
+    int tile = grouped ? blockIdx.x >> 3 : blockIdx.x;
+    if (tile >= t_end) return;
+    auto coords = [&](int t, int& bm0, int& bn0) {
+        int mb, nb;
+        if (grouped) ord.get(t, mb, nb);
+        else { mb = t % nMb; nb = t / nMb; }
+        bm0 = mb * BM; bn0 = nb * BN;
+    };
+    int bm0, bn0;
+    coords(tile, bm0, bn0);
+    gload(bm0, bn0, 0);
+    if constexpr (DW) { wfrag(0, bn0, 0); wfrag(1, bn0, 1); }
+
+    for (; tile < t_end; tile += t_step) {
+        const int n0 = bn0 + wn * (32 * TN) + l31;
+        float c0[TN], c1[TN], cs[TN];
+        const int gate_row = bm0 + wm * (32 * TM);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            c0[j] = p.bias ? p.bias[n0 + 32 * j] : 0.f;
+            c1[j] = 1.f;
+            cs[j] = p.w_inv[n0 + 32 * j] * inv_a_s;          // undoes both operand scales (powers of two: exact)
+            if constexpr (EPI == EPI_HN) c1[j] = p.hn_w[((n0 + 32 * j) / p.hn_split) * 32 + l31];
+            if constexpr (EPI == EPI_GATERES)
+                c1[j] = p.mul ? p.mul[(long long)(gate_row / p.mul_rows_per_group) * p.mul_gstride + n0 + 32 * j] : 1.f;
+        }
+        // prologue state of the one A row this thread stages
+        float st_mean = 0.f, st_rstd = 1.f;
+        int grp_off = 0;
+        if constexpr (PRO != 0 && !AS) {
+            const int m = bm0 + a_row;
+            st_mean = p.stats[2 * (long long)m];
+            st_rstd = p.stats[2 * (long long)m + 1];
+            if constexpr (PRO == 2) grp_off = (m / p.pro_rows_per_group) * p.pro_gstride;
+        }
+        // norm prologue, scale, k-tail zeroing and split of one f32x4 chunk
+        auto prep = [&](f32x4 v, int kc, f16x4& ph, f16x4& pl) {
+            if constexpr (PRO != 0) {
+                const int kl = kc < p.K ? kc : 0;
+                const f32x4 pw = *reinterpret_cast<const f32x4*>(p.pro_w + grp_off + kl);
+                const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pro_b + grp_off + kl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (v[e] - st_mean) * st_rstd * pw[e] + pb[e];
+            }
+            if (p.pro_act == PD_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (p.pro_act == PD_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pd_silu(v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= a_s;
+            if (kc >= p.K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            split4h(v, ph, pl);
+        };
+        // ---- LDS-W tiles (GLU: a wave owns both columns of a pair): one 16-k half of the slice held in ra / rw
+        auto stage = [&](int h, int k0) {
+            if constexpr (AS) {
+                if ((a_q >> 1) == h) {
+#pragma unroll
+                    for (int part = 0; part < NPARTS; ++part)
+                        *reinterpret_cast<f16x8*>(sA(h, part) + a_row * PITCH + 8 * (a_q & 1)) = ra2[part];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < (AS ? 0 : CPH_A); ++i) {
+                const int c = a_q + TPR_A * i;                    // chunk inside the half
+                f16x4 ph, pl;
+                prep(ra[h][i], k0 + 16 * h + 4 * c, ph, pl);
+                const int o = a_row * PITCH + 4 * c;
+                *reinterpret_cast<f16x4*>(sA(h, 0) + o) = ph;
+                *reinterpret_cast<f16x4*>(sA(h, 1) + o) = pl;
+            }
+            if (!DW && (NW == 2 || (w_q >> 1) == h)) {
+                const int i = NW == 2 ? h : 0;
+                const int c = NW == 2 ? w_q : (w_q & 1);          // 16-byte chunk inside the half
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part)
+                    *reinterpret_cast<f16x8*>(sW(h, part) + w_row * PITCH + 8 * c) = rw[part][i];
+            }
+        };
+        // three partial products per (i, j) fragment pair of one 16-k stage, smallest first
+        auto mma = [&](int s) {
+            f16x8 fa[TM][NPARTS], fw[TN][NPARTS];
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i][part] = *reinterpret_cast<const f16x8*>(sA(s, part) + (wm * (32 * TM) + i * 32 + l31) * PITCH + 8 * hh);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fw[j][part] = *reinterpret_cast<const f16x8*>(sW(s, part) + (wn * (32 * TN) + j * 32 + l31) * PITCH + 8 * hh);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fw[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fw[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fw[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        };
+        // ---- DW tiles: the whole 32-k slice in ra goes to LDS stage s; fragments of k-step ks come from there and from wf[ks]
+        auto stage2 = [&](int s, int k0) {
+            _Float16* base = lds + s * TL::STAGE + a_row * PITCH2;
+            if constexpr (AS) {
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part) *reinterpret_cast<f16x8*>(base + part * BM * PITCH2 + 8 * a_q) = ra2[part];
+            }
+#pragma unroll
+            for (int h = 0; h < (AS ? 0 : 2); ++h)
+#pragma unroll
+                for (int i = 0; i < CPH_A; ++i) {
+                    const int c = a_q + TPR_A * i;
+                    f16x4 ph, pl;
+                    prep(ra[h][i], k0 + 16 * h + 4 * c, ph, pl);
+                    const int o = 16 * h + 4 * c;
+                    *reinterpret_cast<f16x4*>(base + o) = ph;
+                    *reinterpret_cast<f16x4*>(base + BM * PITCH2 + o) = pl;
+                }
+        };
+        auto mma2 = [&](int s, int ks) {
+            f16x8 fa[TM][NPARTS];
+            const _Float16* base = lds + s * TL::STAGE + (wm * (32 * TM) + l31) * PITCH2 + 16 * ks + 8 * hh;
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i][part] = *reinterpret_cast<const f16x8*>(base + part * BM * PITCH2 + i * 32 * PITCH2);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], wf[ks][j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], wf[ks][j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], wf[ks][j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // slice 0 of this tile is in ra / rw (requested before the previous tile's epilogue)
+        lds_barrier();                            // every wave has finished the previous tile's last stage
+        if constexpr (DW) {
+            stage2(0, 0);
+            lds_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int st = kt & 1;
+                const bool more = kt + 1 < nk;
+                if (more) gload(bm0, bn0, (kt + 1) * 32);
+                mma2(st, 0);
+                if (more) wfrag(0, bn0, 2 * kt + 2);          // every B buffer is re-requested right after its last use
+                mma2(st, 1);
+                if (more) {
+                    wfrag(1, bn0, 2 * kt + 3);
+                    // the other stage was last read in the previous iteration, which every wave left through its barrier
+                    stage2(st ^ 1, (kt + 1) * 32);
+                    lds_barrier();
+                }
+            }
+        } else {
+            stage(0, 0);
+            stage(1, 0);
+            lds_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                const bool more = kt + 1 < nk;
+                if (more) gload(bm0, bn0, (kt + 1) * 32);
+                mma(0);
+                // every wave has read stage 0, and the stage-1 stores of the previous iteration (issued after ITS second
+                // barrier) become visible to the mma(1) below - so this barrier is needed in the last iteration too
+                if (nk > 1) lds_barrier();
+                if (more) stage(0, (kt + 1) * 32);
+                mma(1);
+                if (more) {
+                    lds_barrier();                    // stage 1 read by every wave; the stage-0 stores above are visible
+                    stage(1, (kt + 1) * 32);
+                }
+            }
+        }
+        const int cur_bm0 = bm0, cur_bn0 = bn0;
+        if (tile + t_step < t_end) {
+            coords(tile + t_step, bm0, bn0);
+            gload(bm0, bn0, 0);
+            if constexpr (DW) { wfrag(0, bn0, 0); wfrag(1, bn0, 1); }
+        }
+        // back to the units of A . W^T (exact: powers of two), then the shared epilogues
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= cs[j];
+        epilogue<EPI, TM, TN>(p, acc, c0, c1, cur_bm0, cur_bn0, wm, wn, l31, hh);
+    }
+}
+
+template <int PRO, int EPI, class TL>
+int run_f16(int op, const pd_gemm_args* p, hipStream_t s) {
+    auto k = gemm_f16_kernel<PRO, EPI, TL>;
+    constexpr int lds = TL::LDS_BYTES;
+    if (op == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    const long long ntiles = (long long)(p->M / TL::BM) * (p->N / TL::BN);
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < TL::GRID ? ntiles : TL::GRID)), dim3(TL::NT), lds, s, *p);
+    return pd_check_launch();
+}
+
+using F128 = FTile<128, 128, 2, 8, true>;    // 2 x 4 waves of 64 x 32, direct W
+using F128G = FTile<128, 128, 4, 8, false>;  // 4 x 2 waves of 32 x 64 (GLU: a wave owns both columns of a pair), W through LDS
+#ifdef PD_F16_GLU_DW
+using F128GD = FTile<128, 128, 4, 8, true>;  // ... direct W: with two parts and a pre-split A the fragment buffers fit (124 VGPRs)
+#else
+using F128GD = F128G;
+#endif
+
+int dispatch_f16(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s) {
+#define PD_FCASE(P, E, TL) if (pro == P && epi == E) return run_f16<P, E, TL>(op, p, s);
+    PD_FCASE(0, EPI_PLAIN, F128) PD_FCASE(1, EPI_PLAIN, F128) PD_FCASE(3, EPI_PLAIN, F128)
+    PD_FCASE(1, EPI_HN, F128) PD_FCASE(2, EPI_HN, F128) PD_FCASE(3, EPI_HN, F128)
+    PD_FCASE(1, EPI_GLU, F128G) PD_FCASE(2, EPI_GLU, F128G) PD_FCASE(3, EPI_GLU, F128GD)
+    PD_FCASE(0, EPI_GATERES, F128)
+#undef PD_FCASE
+    return PD_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// Same contract as pd_gemm_split_try (gemm_split.hip); needs the fp16-split weights with their row scales (args->W2, w_inv) and
+// the magnitude bound of A (args->a_amax).  init_only: 0 launch, 1 raise the LDS limits, 2 query (returns the EPI kind).
+extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void* stream, int init_only) {
+    if (init_only == 1) {
+        int rc = PD_OK;
+        for (int P = 0; P < 4; ++P)
+            for (int E = 0; E < 6; ++E) {
+                const int r = dispatch_f16(1, P, E, nullptr, nullptr);
+                if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
+            }
+        return rc;
+    }
+    const pd_gemm_args& p = *args;
+    if (!p.W2 || !p.w_inv || !p.a_amax || p.K % 4 != 0 || tile != 128) return PD_ERR_UNSUPPORTED;
+    if (p.A2) {                                  // pre-split A: whole 32-k slices, 16-byte aligned, prologue and scale already applied
+        if (pro != 0 || p.pro_act != PD_ACT_NONE || p.K % 32 != 0 || ((uintptr_t)p.A2 & 15)) return PD_ERR_UNSUPPORTED;
+        pro = 3;
+    }
+    if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
+    if (((uintptr_t)p.W2 & 15) != 0 || p.N % 128 != 0 || p.M % 128 != 0) return PD_ERR_UNSUPPORTED;
+    if ((long long)(p.M / 128) * (p.N / 128) < PD_F16_MIN_TILES) return PD_ERR_UNSUPPORTED;       // small launches: latency-bound
+    if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
+    int epi;
+    if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
+    else if (p.hn_w) epi = (p.mul || p.res || p.act) ? -1 : EPI_HN;
+    else if (p.res) {
+        epi = (p.mul && p.mul_rows_per_group <= 0) ? -1 : EPI_GATERES;
+        if (p.act || p.res_row_mod > 0) epi = -1;
+        if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group % 64 != 0) epi = -1;
+    } else epi = p.mul ? -1 : EPI_PLAIN;
+    if (epi < 0) return PD_ERR_UNSUPPORTED;
+    if (init_only == 2) {
+        const int r = dispatch_f16(1, pro, epi, nullptr, nullptr);
+        return r == PD_OK ? epi : r;
+    }
+    return dispatch_f16(0, pro, epi, &p, (hipStream_t)stream);
+}

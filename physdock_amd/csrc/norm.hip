@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
                                                      float* __restrict__ y, const float* __restrict__ res,
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      int M, int C, int ldx, int mode, float eps, int act,
-                                                     int rows_per_group = 0, int gstride = 0) {
+                                                     int rows_per_group = 0, int gstride = 0, const float* __restrict__ amax = nullptr) {
     constexpr int RPB = 256 / LPR;
     const int sub = threadIdx.x % LPR;
     const long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
@@ -60,6 +60,31 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     if (!ok) return;
     if constexpr (WRITE == 0) {
         if (sub == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    } else if constexpr (WRITE == 3) {
+        // the same rows times the power of two that brings the bound *amax below 2^14, as TWO fp16 parts (hi, lo): the
+        // pre-split A operand of csrc/gemm_f16.hip (out2 = [2][M][C])
+        const long long goff = rows_per_group > 0 ? (row / rows_per_group) * (long long)gstride : 0;
+        const float a_s = pd_pow2_scale(*amax);
+        unsigned short* out = reinterpret_cast<unsigned short*>(y);
+        const long long part = (long long)M * C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = sub + i * LPR;
+            if (c >= nchunk) continue;
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                t[e] = (v[i][e] - mean) * rstd;
+                if (w) t[e] = t[e] * w[goff + c * 4 + e];
+                if (b) t[e] = t[e] + b[goff + c * 4 + e];
+                t[e] *= a_s;
+            }
+            const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            unsigned short* o = out + row * (long long)C + c * 4;
+            *reinterpret_cast<u32x2*>(o) = u32x2{p0.h, p1.h};
+            *reinterpret_cast<u32x2*>(o + part) = u32x2{p0.l, p1.l};
+        }
     } else if constexpr (WRITE == 2) {
         // a' = (x - mean) rstd w[g][k] + b[g][k], g = row / rows_per_group: the GEMM prologue's expression, then the 3-way split
         // (8-byte stores per part; pairing chunks into 16-byte stores measured slower: 27 -> 43 us at [16384, 512])
@@ -126,7 +151,8 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
 
 template <int WRITE>
 int dispatch(const float* x, float* stats, float* y, const float* res, const float* w, const float* b,
-             int M, int C, int ldx, int mode, float eps, int act, hipStream_t s, int rows_per_group = 0, int gstride = 0) {
+             int M, int C, int ldx, int mode, float eps, int act, hipStream_t s, int rows_per_group = 0, int gstride = 0,
+             const float* amax = nullptr) {
     if (C % 4 != 0 || ldx % 4 != 0 || ((uintptr_t)x & 15)) return PD_ERR_UNSUPPORTED;
     const int nchunk = C / 4;
     // lanes per row = min(64, pow2 >= C/4): one float4 per lane while the row fits a wave
@@ -137,7 +163,7 @@ int dispatch(const float* x, float* stats, float* y, const float* res, const flo
     {                                                                                              \
         const int rpb = 256 / L;                                                                   \
         hipLaunchKernelGGL((rownorm_kernel<L, WRITE>), dim3((M + rpb - 1) / rpb), dim3(256), 0, s, \
-                           x, stats, y, res, w, b, M, C, ldx, mode, eps, act, rows_per_group, gstride); \
+                           x, stats, y, res, w, b, M, C, ldx, mode, eps, act, rows_per_group, gstride, amax); \
     }
     switch (lpr) {
         case 4: PD_LAUNCH(4) break;
@@ -176,4 +202,12 @@ PD_EXPORT int pd_norm_split(const float* x, int ldx, int M, int C, int mode, flo
     if (C % 32 != 0 || ((uintptr_t)out3 & 15)) return PD_ERR_UNSUPPORTED;      // rows of whole 32-k slices, 16-byte aligned
     return dispatch<2>(x, nullptr, reinterpret_cast<float*>(out3), nullptr, w, b, M, C, ldx, mode, eps, 0, (hipStream_t)stream,
                        rows_per_group, gstride);
+}
+
+PD_EXPORT int pd_norm_split2(const float* x, int ldx, int M, int C, int mode, float eps, const float* w, const float* b,
+                             int rows_per_group, int gstride, const float* a_amax, void* out2, void* stream) {
+    if (!x || !out2 || !a_amax || M <= 0 || C <= 0) return PD_ERR_ARG;
+    if (C % 32 != 0 || ((uintptr_t)out2 & 15)) return PD_ERR_UNSUPPORTED;
+    return dispatch<3>(x, nullptr, reinterpret_cast<float*>(out2), nullptr, w, b, M, C, ldx, mode, eps, 0, (hipStream_t)stream,
+                       rows_per_group, gstride, a_amax);
 }

@@ -585,6 +585,51 @@ PD_EXPORT int pd_ligand_scatter(float* dst, const float* src, const float* lig, 
     return pd_check_launch();
 }
 
+// ---- magnitude bounds for the two-part fp16 operand format of the DiT kernels, from the AdaLN table alone ----------------
+// A DiT block's activations are products of bounded things: x^ = LayerNorm(x) without affine has |x^_k| <= sqrt(C - 1) and
+// ||x^||_2 <= sqrt(C) for ANY input; AdaLN-Zero then gives y = (1 + scale) x^ + shift with (shift, 1 + scale) rows of the
+// per-call table (adaptive_layer_norm_zero.py:16-21).  Hence, rigorously and without looking at a single activation:
+//   |y_k|  <= wmax sqrt(C) + bmax,          ||y||_2 <= wmax sqrt(C) + ||shift||_2,
+//   |v_n|  <= ||Wv_n||_2 ||y||_2            (Cauchy-Schwarz; the DiT's q|k|v projection has no bias),   |o| <= max |v|,
+//   |q_k|, |k_k| <= sqrt(32) max|head-norm gain|   (per-head RMS norm),
+//   |h_n| = |silu(a_n) b_n| <= |a_n| |b_n| <= ||W1_n||_2 ||W3_n||_2 ||y'||_2^2      (transition SwiGLU, y' = second AdaLN).
+// out[(row * nblocks + b) * 8 + ..] = [q, k, v (= o), y, y', h, 0, 0]; consts[b * 4 + ..] = [q bound, k bound,
+// max_n ||Wv_n||, max_n ||W1_n|| * max_n ||W3_n||] come from the weights once (packing.py).  One block per (DiT block, row).
+__global__ __launch_bounds__(256) void dit_bounds_kernel(const float* __restrict__ tab, int ld, int nblocks, int C,
+                                                          const float* __restrict__ consts, float* __restrict__ out) {
+    const int b = blockIdx.x, row = blockIdx.y;
+    const float* base = tab + (long long)row * ld + (long long)b * 6 * C;
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // bmax1, wmax1, bsq1, bmax2, wmax2, bsq2
+    for (int k = threadIdx.x; k < C; k += 256) {
+        const float s1 = base[k], w1 = base[C + k], s2 = base[3 * C + k], w2 = base[4 * C + k];
+        v[0] = fmaxf(v[0], fabsf(s1)); v[1] = fmaxf(v[1], fabsf(w1)); v[2] += s1 * s1;
+        v[3] = fmaxf(v[3], fabsf(s2)); v[4] = fmaxf(v[4], fabsf(w2)); v[5] += s2 * s2;
+    }
+    __shared__ float red[4][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = (i % 3 == 2) ? wave_sum(v[i]) : wave_max(v[i]);
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 6; ++i) red[threadIdx.x >> 6][i] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 6; ++i)
+            for (int w = 1; w < 4; ++w) v[i] = (i % 3 == 2) ? v[i] + red[w][i] : fmaxf(v[i], red[w][i]);
+        const float rc = sqrtf((float)C) * 1.0001f;       // (a hair above the exact bound: the table itself is rounded fp32)
+        const float y1 = v[1] * rc + v[0], y1l2 = v[1] * rc + sqrtf(v[2]) * 1.0001f;
+        const float y2 = v[4] * rc + v[3], y2l2 = v[4] * rc + sqrtf(v[5]) * 1.0001f;
+        const float* c = consts + 4 * b;
+        float* o = out + ((long long)row * nblocks + b) * 8;
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2] * y1l2 * 1.0001f; o[3] = y1; o[4] = y2; o[5] = c[3] * y2l2 * y2l2 * 1.0001f;
+        o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
+PD_EXPORT int pd_dit_bounds(const float* tab, int nrows, int ld, int nblocks, int C, const float* consts, float* out, void* stream) {
+    if (!tab || !consts || !out || nrows <= 0 || nblocks <= 0 || C <= 0 || ld < nblocks * 6 * C) return PD_ERR_ARG;
+    hipLaunchKernelGGL(dit_bounds_kernel, dim3(nblocks, nrows), dim3(256), 0, (hipStream_t)stream, tab, ld, nblocks, C, consts, out);
+    return pd_check_launch();
+}
+
 PD_EXPORT int pd_timestep_embed(const float* tau, float* emb, int n, void* stream) {
     if (!tau || !emb || n <= 0) return PD_ERR_ARG;
     hipLaunchKernelGGL(timestep_embed_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, tau, emb, n);

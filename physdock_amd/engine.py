@@ -67,6 +67,13 @@ class Engine:
                 and not kw.get("a_kmajor") and not kw.get("w_kmajor") and N % 64 == 0 \
                 and (kw.get("out_mode", 0) == 0 or (kw.get("out_mode") == OUT_TRANSPOSED and kw.get("glu"))):
             w3 = self.P.w3(W, K)
+        if kw.get("a_amax") is not None and w3 is not None and ops.F16_GEMM and kw.get("out_mode", 0) == 0:
+            # the caller knows an upper bound of |A'|: two-part fp16 operands (three MFMA products instead of six)
+            kw["W2"] = self.P.w2(W, K)
+        else:
+            kw.pop("a_amax", None)
+            if kw.pop("A2", None) is not None:
+                raise RuntimeError("a pre-split fp16 A operand was prepared for a launch that cannot take it")
         ksw = None
         if kw.get("batch", 1) == 1 and kw.get("out_mode", 0) == 0 and M <= 8192 and K >= 256 and not kw.get("a_kmajor"):
             # few rows x long K (token-level projections at a handful of samples): scratch that lets pd_gemm cut K
@@ -408,7 +415,7 @@ class Engine:
         ops.rownorm(raw, z, T * T, Cz, res=z, w=P[prefix + ".norm_out.weight"], mode=RMS, eps=self.eps)
 
     # ------------------------------------------------------------------ denoiser
-    def prepare_dit(self, a, ap, s, z, batch, tau):
+    def prepare_dit(self, a, ap, s, z, batch, tau, per_sample=False):
         """Per-call, step-invariant preparation: hoisted pair biases (attentions.py:246,254 executed once
         instead of 18 x steps times) and the AdaLN tables of every step (adaptive_layer_norm_zero.py:19)."""
         P, ws = self.P, self.ws
@@ -442,9 +449,20 @@ class Engine:
         tab_t = ws.get("adaln_token", n, Wtt.shape[0])
         self.gemm(t, Wta, tab_a, n, Wta.shape[0], 256, bias=bta, pro_act=ACT_SILU)
         self.gemm(t, Wtt, tab_t, n, Wtt.shape[0], 256, bias=btt, pro_act=ACT_SILU)
-        return {"atom_bias": fa, "token_bias": ft, "tab_atom": tab_a, "tab_token": tab_t}
+        # --- magnitude bounds of every block's activations at every step, from the tables alone (two-part fp16 operand format)
+        bnd = {}
+        for kind, tab, C in (("atom", tab_a, Ca), ("token", tab_t, Cs)):
+            consts = P.dit_bound_consts(kind)
+            nb = consts.shape[0]
+            out = ws.get("dit_bounds_" + kind, n, nb, 8)
+            ops.check(L.pd_dit_bounds(ops.ptr(tab), n, tab.shape[1], nb, C, ops.ptr(consts), ops.ptr(out), ops.stream()), "dit_bounds")
+            if per_sample:                  # rows = samples of ONE launch (training-time forward): the launch needs the largest
+                out.copy_(out.amax(0, keepdim=True).expand_as(out))
+            bnd[kind] = out
+        return {"atom_bias": fa, "token_bias": ft, "tab_atom": tab_a, "tab_token": tab_t, "bnd_atom": bnd["atom"],
+                "bnd_token": bnd["token"]}
 
-    def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample, nk):
+    def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample, nk, bnd=None):
         """DiTBlock (transformers.py:155-159; attentions.py:241-265; transitions.py:27-30).
         tab: AdaLN table row(s) [shift | 1+scale | gate] x (attention, transition) for this block."""
         P, eps = self.P, self.eps
@@ -455,37 +473,53 @@ class Engine:
         # wide rows (token DiT, C = 512) in chip-filling launches: AdaLN-normalise and split the activations ONCE
         # (pd_norm_split) instead of in every column block of the projection that consumes them (12 / 22 of them)
         W13, hidden = P.glu(prefix + ".transition.feed_forward")
+        # magnitude bounds of this block's GEMM operands (pd_dit_bounds: [q, k, v = o, y, y', h]) -> two-part fp16 operands
+        f16 = ops.SPLIT_GEMM and ops.F16_GEMM and bnd is not None
+        b_o, b_y, b_y2, b_h = (bnd + 8, bnd + 12, bnd + 16, bnd + 20) if f16 else (None,) * 4
+        # wide rows (token DiT, C = 512) in chip-filling launches: AdaLN-normalise and split the activations ONCE
+        # (pd_norm_split / pd_norm_split2) instead of in every column block of the projection that consumes them (12 / 22 of them)
         presplit = ops.SPLIT_GEMM and ops.PRESPLIT_GEMM and C >= 256 and C % 32 == 0 \
-            and ops.presplit_supported(rows, 3 * C, C, hn=True) and ops.presplit_supported(rows, 2 * hidden, C, glu=1)
-        a3 = self.lws("dit_a3", 3, rows, C, dtype=torch.bfloat16) if presplit else None
+            and ops.presplit_supported(rows, 3 * C, C, hn=True, f16=f16) and ops.presplit_supported(rows, 2 * hidden, C, glu=1, f16=f16)
+        a3 = a2 = None
+        if presplit and f16:
+            a2 = self.lws("dit_a2", 2, rows, C, dtype=torch.float16)
+        elif presplit:
+            a3 = self.lws("dit_a3", 3, rows, C, dtype=torch.bfloat16)
         ng = dict(rows_per_group=N if per_sample else 0, gstride=tab_ld if per_sample else 0)
+
+        def norm_split(w_off, amax):
+            kw_ = dict(mode=LN, eps=eps, b=off(tab, w_off), w=off(tab, w_off + C), **ng)
+            if a2 is not None:
+                ops.norm_split2(x, a2, rows, C, amax, **kw_)
+                return dict(A2=a2)
+            ops.norm_split(x, a3, rows, C, **kw_)
+            return dict(A3=a3)
         qkv = self.lws("dit_qkv", rows, 3 * C)
+        hn = dict(hn_w=P.headnorm(prefix + ".attention"), hn_cols=2 * C, hn_split=C, hn_eps=eps)
         if presplit and ops.PRESPLIT_QKV:
-            ops.norm_split(x, a3, rows, C, mode=LN, eps=eps, b=off(tab, tab_off), w=off(tab, tab_off + C), **ng)
-            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, A3=a3, hn_w=P.headnorm(prefix + ".attention"),
-                      hn_cols=2 * C, hn_split=C, hn_eps=eps)
+            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, a_amax=b_y, **norm_split(tab_off, b_y), **hn)
         else:
             st = self.stats(x, rows, C, LN, eps)
             self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
-                      pro_w=off(tab, tab_off + C), hn_w=P.headnorm(prefix + ".attention"), hn_cols=2 * C, hn_split=C,
-                      hn_eps=eps, **grp)
+                      pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
         o = self.lws("dit_o", rows, C)
         st3 = (N * 3 * C, 3 * C)
+        # bnd: device address of this (step, block)'s magnitude bounds: chip-filling attention launches then take the two-part
+        # fp16 operand format too
         ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, nq=N, nk=nk, nbatch=B, nheads=H,
                       q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias, bias_nk=N,
-                      ws=self.attn_ws(B, N, nk, H))
+                      ws=self.attn_ws(B, N, nk, H), f16_amax=bnd)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
-        self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, **mgrp)
+        self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, a_amax=b_o, **mgrp)
         h = self.lws("dit_h", rows, hidden)
         o2 = tab_off + 3 * C
         if presplit:
-            ops.norm_split(x, a3, rows, C, mode=LN, eps=eps, b=off(tab, o2), w=off(tab, o2 + C), **ng)
-            self.gemm(x, W13, h, rows, 2 * hidden, C, A3=a3, glu=1)
+            self.gemm(x, W13, h, rows, 2 * hidden, C, glu=1, a_amax=b_y2, **norm_split(o2, b_y2))
         else:
             st = self.stats(x, rows, C, LN, eps)
-            self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, o2), pro_w=off(tab, o2 + C), glu=1, **grp)
+            self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, o2), pro_w=off(tab, o2 + C), glu=1, a_amax=b_y2, **grp)
         W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
-        self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, o2 + 2 * C), res=x, **mgrp)
+        self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, o2 + 2 * C), res=x, a_amax=b_h, **mgrp)
 
     def af3_dit(self, batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=False):
         """AF3DiT.forward (transformers.py:235-262) for one noise level.
@@ -507,23 +541,24 @@ class Engine:
         fa_stride = ops.bias_frag_numel(Ha, A, A)
         ft_stride = ops.bias_frag_numel(Hs, T, T)
         nb_a, nb_t = dt.no_blocks_atom, dt.no_blocks_dit
+        bnd_a, bnd_t = prep["bnd_atom"], prep["bnd_token"]
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_encoder.blocks.{b}", ba, B, A, Ca, off(prep["atom_bias"], b * fa_stride),
-                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar)
+                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + b) * 8))
         u = self.lws("dit_u", B * A, Cs)
         self.lin(ba, "dit.linear_downscale", B * A, out=u, act=ACT_SILU)
         bs = self.lws("dit_bs", B * T, Cs)
         ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs), B, A, T, Cs, sp), "pool")
         for b in range(nb_t):
             self.dit_block(f"dit.token_dit.blocks.{b}", bs, B, T, Cs, off(prep["token_bias"], b * ft_stride),
-                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr)
+                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr, bnd=off(bnd_t, (row * nb_t + b) * 8))
         us = self.lws("dit_us", B * T, Ca)
         self.lin(bs, "dit.linear_upscale", B * T, out=us)
         ops.check(L.pd_unpool_add(ops.ptr(ba), ops.ptr(us), ops.ptr(batch["atom_id_to_token_id"]), B, A, T, Ca, sp), "unpool")
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_decoder.blocks.{b}", ba, B, A, Ca,
                            off(prep["atom_bias"], (nb_a + b) * fa_stride), tab_a, row * lda_ + (nb_a + b) * 6 * Ca, lda_,
-                           per_sample, Ar)
+                           per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + nb_a + b) * 8))
         cs_b = ops.ptr(scal["c_skip"]) if per_sample else None
         co_b = ops.ptr(scal["c_out"]) if per_sample else None
         ops.check(L.pd_denoise(ops.ptr(ba), ops.ptr(x_hat), ops.ptr(P["dit.norm_r.weight"]), ops.ptr(P["dit.norm_r.bias"]),

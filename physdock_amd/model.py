@@ -466,7 +466,7 @@ class PhysDock(nn.Module):
         scal = {"c_in": (1 / torch.sqrt(th ** 2 + sd ** 2)).to(device), "c_skip": (sd ** 2 / (sd ** 2 + th ** 2)).to(device),
                 "c_out": (sd * th / torch.sqrt(sd ** 2 + th ** 2)).to(device)}
         tau = (th * (torch.log(th / sd) / 4.0)).to(device)
-        prep = eng.prepare_dit(a, ap, s, z, batch, tau)
+        prep = eng.prepare_dit(a, ap, s, z, batch, tau, per_sample=True)
         x_den = ws.get("fw_xden", B, A, 3)
         eng.af3_dit(batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=True)
         pd = eng.lin(z, "linear_distogram", T * T).reshape(T, T, -1)[:T_real, :T_real]

@@ -40,21 +40,26 @@ def const_vec(val, n):
 _PRESPLIT_OK = {}
 
 
-def presplit_supported(M, N, K, *, glu=0, hn=False):
-    """Does the library take a [3][M][K] pre-split A operand (pd_gemm_args.A3) for this projection?  Asked of the
-    library itself (pd_gemm_variant: tile-count threshold, alignment and epilogue rules live in csrc/gemm_split.hip),
-    so a differently tuned build changes the answer here, not an error in pd_gemm."""
-    key = (M, N, K, int(glu), bool(hn))
+def presplit_supported(M, N, K, *, glu=0, hn=False, f16=False):
+    """Does the library take a pre-split A operand for this projection - [3][M][K] bf16 (pd_gemm_args.A3), or with f16=True
+    [2][M][K] fp16 (A2, csrc/gemm_f16.hip)?  Asked of the library itself (pd_gemm_variant: tile-count threshold, alignment and
+    epilogue rules live in csrc/gemm_split.hip / gemm_f16.hip), so a differently tuned build changes the answer here, not an
+    error in pd_gemm."""
+    key = (M, N, K, int(glu), bool(hn), bool(f16))
     r = _PRESPLIT_OK.get(key)
     if r is None:
         a = GemmArgs()
-        a.A = a.W = a.Y = a.W3 = a.A3 = 1 << 20          # never dereferenced by the query: aligned placeholders
+        a.A = a.W = a.Y = 1 << 20                        # never dereferenced by the query: aligned placeholders
+        if f16:
+            a.W2 = a.w_inv = a.a_amax = a.A2 = 1 << 20
+        else:
+            a.W3 = a.A3 = 1 << 20
         a.M, a.N, a.K = M, N, K
         a.lda, a.ldw, a.ldy = K, K, (N // 2 if glu else N)
         a.batch, a.glu, a.out_scale = 1, int(glu), 1.0
         if hn:
             a.hn_w, a.hn_cols, a.hn_split = 1 << 20, 0, 32
-        r = _lib.init().pd_gemm_variant(C.byref(a)) >= 1000000
+        r = _lib.init().pd_gemm_variant(C.byref(a)) >= (2000000 if f16 else 1000000)
         _PRESPLIT_OK[key] = r
     return r
 
@@ -64,7 +69,8 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
          pro_gstride=0, pro_act=ACT_NONE, rowscale_acc=None, bias=None, sBias=0, hn_w=None, hn_cols=0,
          hn_split=32, hn_eps=0.0, act=ACT_NONE, glu=0, rowscale=None, maskadd=None, maskval=0.0,
          mul=None, ldmul=0, mul_rows_per_group=0, mul_gstride=0, out_scale=1.0, res=None, ldres=0,
-         res_row_mod=0, sRes=0, out_mode=OUT_ROWMAJOR, T1=0, T2=0, frag_transpose=False, W3=None, ksplit_ws=None, A3=None):
+         res_row_mod=0, sRes=0, out_mode=OUT_ROWMAJOR, T1=0, T2=0, frag_transpose=False, W3=None, ksplit_ws=None, A3=None,
+         W2=None, a_amax=None, A2=None):
     """Y = epilogue(prologue(A) @ W^T); see include/physdock_hip.h pd_gemm_args.
     A/W/Y and the optional operands may be tensors or raw device addresses (ints)."""
     def P(x):
@@ -79,6 +85,13 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
     a.A, a.W, a.Y = P(A), P(W), P(Y)
     a.W3 = W3.data_ptr() if (W3 is not None and SPLIT_GEMM) else None
     a.A3 = A3.data_ptr() if A3 is not None else None
+    if W2 is not None and a_amax is not None and F16_GEMM and SPLIT_GEMM:
+        # two-part fp16 operands (csrc/gemm_f16.hip): W2 = (parts, w_inv) of packing.split2_f16, a_amax = device scalar bound of |A'|
+        a.W2, a.w_inv = W2[0].data_ptr(), W2[1].data_ptr()
+        a.a_amax = a_amax if isinstance(a_amax, int) else ptr(a_amax)
+        a.A2 = A2.data_ptr() if A2 is not None else None
+    elif A2 is not None:
+        raise ValueError("A2 (pre-split fp16 A) needs W2 and a_amax")
     a.M, a.N, a.K = M, N, K
     a.lda = lda if lda is not None else (M if a_kmajor else K)
     a.ldw = ldw if ldw is not None else (N if w_kmajor else K)
@@ -129,6 +142,8 @@ SPLIT_ATTN = True
 
 #: two-part fp16 operands (three partial products) for attention launches whose caller supplies magnitude bounds (f16_amax=)
 F16_ATTN = True
+#: the same for GEMM launches that carry fp16-split weights and a bound of |A| (W2=, a_amax=)
+F16_GEMM = True
 
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None
@@ -147,6 +162,15 @@ def norm_split(x, out3, M, Cdim, *, ldx=None, mode=RMS, eps=1e-8, w=None, b=None
         return t if (t is None or isinstance(t, int)) else ptr(t)
     check(_lib.init().pd_norm_split(P(x), ldx if ldx is not None else Cdim, M, Cdim, mode, eps, P(w), P(b), rows_per_group, gstride,
                                     ptr(out3), stream()), "pd_norm_split")
+
+
+def norm_split2(x, out2, M, Cdim, a_amax, *, ldx=None, mode=RMS, eps=1e-8, w=None, b=None, rows_per_group=0, gstride=0):
+    """out2 [2, M, C] fp16 = (hi, lo) split of ((x - mean) rstd w[g] + b[g]) 2^e, e from the device scalar bound a_amax
+    (pd_norm_split2): the pre-split A operand of gemm(A2=)"""
+    def P(t):
+        return t if (t is None or isinstance(t, int)) else ptr(t)
+    check(_lib.init().pd_norm_split2(P(x), ldx if ldx is not None else Cdim, M, Cdim, mode, eps, P(w), P(b), rows_per_group, gstride,
+                                     P(a_amax), ptr(out2), stream()), "pd_norm_split2")
 
 
 def rownorm(x, y, M, Cdim, *, res=None, w=None, b=None, mode=RMS, eps=1e-8, act=ACT_NONE):
@@ -203,6 +227,8 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
         a.f16x3 = 1
         if isinstance(f16_amax, torch.Tensor):
             a.f16_amax = ptr(f16_amax)
+        elif isinstance(f16_amax, int):          # raw device address of three floats
+            a.f16_amax = f16_amax
         else:
             a.f16_q_amax, a.f16_k_amax, a.f16_v_amax = (float(v) for v in f16_amax)
     if ws is not None:

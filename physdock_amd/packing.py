@@ -3,6 +3,8 @@ affine / the AdaLN "+1" into the projection that follows them).  Runs on whateve
 the parameters live on; results are cached until the parameters change."""
 from __future__ import annotations
 
+import math
+
 import torch
 
 
@@ -59,6 +61,29 @@ def split3_bf16(W):
     return v.contiguous()
 
 
+def split2_f16(W):
+    """The B operand of csrc/gemm_f16.hip: W [N,K] times a per-row power of two (max_k |W[n,k]| w_scale[n] in [2^13, 2^14)),
+    split into two fp16 parts (hi = fp16(w'), lo = fp16(w' - hi): 22 significand bits), stored FRAGMENT-MAJOR like split3_bf16:
+    [2][ceil(N/32)][Kp/16][64][8].  Returns (parts, w_inv [N] fp32 = 1 / w_scale).  Rows of zeros get scale 1."""
+    W = W.float()
+    N, K = W.shape
+    Kp = (K + 31) // 32 * 32
+    amax = W.abs().amax(1)
+    # w_scale = 2^(13 - floor(log2(amax))): frexp gives amax = m 2^e with m in [0.5, 1) -> floor(log2) = e - 1
+    e = torch.frexp(amax)[1]
+    w_scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), 14 - e), torch.ones_like(amax))
+    Ws = W * w_scale[:, None]
+    hi = Ws.to(torch.float16)
+    lo = (Ws - hi.float()).to(torch.float16)
+    rows = torch.zeros(2, N, Kp, dtype=torch.float16, device=W.device)
+    rows[0, :, :K], rows[1, :, :K] = hi, lo
+    Np = (N + 31) // 32 * 32
+    if Np != N:
+        rows = torch.cat([rows, torch.zeros(2, Np - N, Kp, dtype=rows.dtype, device=rows.device)], 1)
+    v = rows.reshape(2, Np // 32, 32, Kp // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)
+    return v.contiguous(), (1.0 / w_scale).contiguous()
+
+
 class PackedWeights:
     """Device-resident fp32 views of a reference-named state dict + cached packed forms."""
 
@@ -80,6 +105,17 @@ class PackedWeights:
             v = (W, split3_bf16(W if K is None else W[:, :K]))       # holding W keeps its address from being reused
             self.cache[key] = v
         return v[1]
+
+    def w2(self, W, K=None):
+        """cached two-part fp16 split (+ inverse row scales) of a packed weight matrix, see split2_f16"""
+        if not isinstance(W, torch.Tensor) or W.dim() != 2:
+            return None
+        key = ("w2", W.data_ptr(), tuple(W.shape), K)
+        v = self.cache.get(key)
+        if v is None:
+            v = (W,) + split2_f16(W if K is None else W[:, :K])
+            self.cache[key] = v
+        return v[1], v[2]
 
     def _c(self, key, fn):
         v = self.cache.get(key)
@@ -157,6 +193,23 @@ class PackedWeights:
             W = pad_k(torch.cat(Ws, 0))
             return (W, torch.cat(bs).contiguous(), W.shape[0])
         return self._c(("ditbias", kind), mk)
+
+    def dit_bound_consts(self, kind):
+        """[blocks][4] = (q bound, k bound, max_n ||Wv_n||_2, max_n ||W1_n||_2 * max_n ||W3_n||_2): the weight-dependent factors of
+        the activation bounds pd_dit_bounds derives for the two-part fp16 operand format (csrc/sampler.hip)"""
+        def mk():
+            rows = []
+            for blk in self._dit_blocks(kind):
+                hn = self.headnorm(blk + ".attention")                         # [2][32]: per-head RMS norm gains of q and k
+                wv = self.p[blk + ".attention.linear_v.weight"]
+                w1 = self.p[blk + ".transition.feed_forward.w1.weight"]
+                w3 = self.p[blk + ".transition.feed_forward.w3.weight"]
+                up = 1.0001                                                     # the norms themselves are rounded fp32
+                rows.append([math.sqrt(32.0) * float(hn[0].abs().max()) * up, math.sqrt(32.0) * float(hn[1].abs().max()) * up,
+                             float(wv.double().norm(dim=1).max()) * up,
+                             float(w1.double().norm(dim=1).max()) * float(w3.double().norm(dim=1).max()) * up])
+            return torch.tensor(rows, dtype=torch.float32, device=self.p[self._dit_blocks(kind)[0] + ".attention.linear_v.weight"].device)
+        return self._c(("ditbound", kind), mk)
 
     def adaln(self, kind):
         """All AdaLN-Zero projections of one DiT family stacked: per block

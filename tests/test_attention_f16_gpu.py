@@ -35,7 +35,9 @@ def ref64(q, k, v, bias):
     h = lambda x: x.double().reshape(B, -1, H, 32).transpose(1, 2)
     s = h(q) @ h(k).transpose(-1, -2) / math.sqrt(32)
     if bias is not None:
-        s = s + bias.double()[None]
+        # the -1e9 mask entries absorb the logit in fp32 (ulp(1e9) = 64): that rounding is the semantics of the reference's
+        # fp32 `s + attn_mask` (a fully masked row is a uniform softmax), so the float64 reference applies it too
+        s = torch.where(bias[None] <= -1e8, torch.full_like(s, -1e9), s + bias.double()[None])
     return (torch.softmax(s, -1) @ h(v)).transpose(1, 2).reshape(B, nq, C)
 
 

@@ -1,0 +1,194 @@
+"""csrc/gemm_f16.hip: the fp32-accurate contraction on the fp16 matrix pipe (two-part operand split with power-of-two scales,
+three partial products, fp32 accumulation).  Every epilogue / prologue kind the DiT blocks use is re-run with the fp16-split
+weights and a magnitude bound attached and compared with the fp32-MFMA kernel family; the accuracy claim (error against
+float64 not above the fp32 MFMA's) is checked for narrow and wide operand ranges and loose bounds; pd_norm_split2 and
+pd_dit_bounds are checked against their definitions.  GPU only."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def variant(ops, seen):
+    L = ops._lib.init()
+    ops.GEMM_HOOK = lambda a, launch: (seen.append(L.pd_gemm_variant(C.byref(a))), launch())
+
+
+@pytest.mark.parametrize("K", [128, 512, 1408])
+@pytest.mark.parametrize("wide,slack", [(0.0, 1.0), (1.5, 1.0), (1.5, 300.0)])
+def test_f16_accuracy_is_at_least_fp32_mfma(K, wide, slack):
+    """error against float64, normalised by sum |a b|: not above the fp32 MFMA path - also for operands with a wide dynamic
+    range and for a bound that is 300 x larger than the largest element (a bound is all the caller has)"""
+    from physdock_amd import ops
+    from physdock_amd.packing import split2_f16
+    M, N = 128 * 16, 128 * 16
+    A = torch.randn(M, K, generator=g(K)) * torch.exp(wide * torch.randn(M, K, generator=g(K + 1)))
+    W = torch.randn(N, K, generator=g(K + 2)) * torch.exp(wide * torch.randn(N, 1, generator=g(K + 3)))     # rows of very different size
+    Ad, Wd = A.cuda(), W.cuda()
+    ref = Ad.double() @ Wd.double().T
+    mag = Ad.double().abs() @ Wd.double().abs().T
+    Y32, Y3 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.gemm(Ad, Wd, Y32, M, N, K)
+    seen = []
+    variant(ops, seen)
+    try:
+        ops.gemm(Ad, Wd, Y3, M, N, K, W2=split2_f16(Wd), a_amax=torch.tensor([float(A.abs().max()) * slack], device="cuda"))
+    finally:
+        ops.GEMM_HOOK = None
+    assert seen[-1] >= 2000000, seen                     # gemm_f16_kernel took it
+    e32 = (Y32.double() - ref).abs() / mag
+    e3 = (Y3.double() - ref).abs() / mag
+    print(f"K={K} wide={wide} bound x{slack:g}: fp32 MFMA max {float(e32.max()):.2e} rms {float(e32.pow(2).mean().sqrt()):.2e} | "
+          f"f16x3 max {float(e3.max()):.2e} rms {float(e3.pow(2).mean().sqrt()):.2e}")
+    assert torch.isfinite(Y3).all()
+    assert float(e3.pow(2).mean().sqrt()) <= 1.1 * float(e32.pow(2).mean().sqrt())
+    assert float(e3.max()) <= 1.5 * float(e32.max())
+
+
+def test_f16_weights_decomposition_and_layout():
+    from physdock_amd.packing import split2_f16
+    W = torch.randn(96, 77) * torch.exp(3 * torch.randn(96, 1))
+    W[5] = 0.0
+    f, w_inv = split2_f16(W)
+    assert f.shape == (2, 3, 6, 2, 32, 8) and f.dtype == torch.float16 and w_inv.shape == (96,)
+    scale = 1.0 / w_inv
+    assert torch.equal(scale, torch.exp2(torch.log2(scale).round()))               # powers of two
+    mx = (W.abs().amax(1) * scale)
+    assert bool(((mx >= 2 ** 13) & (mx < 2 ** 14))[W.abs().amax(1) > 0].all()) and float(scale[5]) == 1.0
+    rows = f.permute(0, 1, 4, 2, 3, 5).reshape(2, 96, 96).float()                   # undo the fragment-major order
+    rec = rows.sum(0)[:, :77] * w_inv[:, None]
+    assert float(((rec - W).abs() / W.abs().amax(1, keepdim=True).clamp_min(1e-30)).max()) <= 2.0 ** -22
+    assert float(rows[:, :, 77:].abs().max()) == 0.0
+    for (n, k) in [(0, 0), (31, 15), (32, 16), (95, 76), (40, 9)]:
+        assert torch.equal(f[:, n // 32, k // 16, (k % 16) // 8, n % 32, k % 8].float(), rows[:, n, k])
+
+
+@pytest.mark.parametrize("per_sample", [False, True])
+def test_f16_dit_block_gemms_vs_fp32_kernels(per_sample):
+    """the four projections of a DiT block (AdaLN prologue + head norm; SwiGLU; gate + residual twice) on the fp16 kernels -
+    in-kernel prologue and pre-split A2 forms - against the fp32-MFMA kernels on the same inputs"""
+    from physdock_amd import ops
+    from physdock_amd.packing import pack_glu, split2_f16
+    B, N_, Cd, hidden = 64, 256, 512, 1408
+    rows = B * N_
+    x = (torch.randn(rows, Cd, generator=g(1)) * 3 + 1).cuda()
+    ngrp = B if per_sample else 1
+    tab = torch.randn(ngrp, 3 * Cd, generator=g(2)).cuda() * 0.5
+    tab[:, Cd:2 * Cd] += 1.0                                                         # (shift | 1 + scale | gate)
+    Wq = (torch.randn(3 * Cd, Cd, generator=g(3)) / math.sqrt(Cd)).cuda()
+    hnw = (1 + 0.1 * torch.randn(2, 32, generator=g(4))).cuda()
+    W1 = torch.randn(hidden, Cd, generator=g(5)) / math.sqrt(Cd); W3 = torch.randn(hidden, Cd, generator=g(6)) / math.sqrt(Cd)
+    W13 = pack_glu(W1, W3)[0].cuda()
+    Wo = (torch.randn(Cd, Cd, generator=g(7)) / math.sqrt(Cd)).cuda()
+    bo = torch.randn(Cd, generator=g(8)).cuda()
+    st = torch.empty(rows, 2, device="cuda")
+    ops.rowstats(x, st, rows, Cd, mode=ops.LN, eps=1e-5)
+    grp = dict(pro_rows_per_group=N_, pro_gstride=3 * Cd) if per_sample else {}
+    mgrp = dict(mul_rows_per_group=N_ if per_sample else rows, mul_gstride=3 * Cd if per_sample else 0)
+    # bound of the AdaLN output: wmax sqrt(C) + bmax over every group
+    ymax = torch.tensor([float(tab[:, Cd:2 * Cd].abs().max()) * math.sqrt(Cd) + float(tab[:, :Cd].abs().max())], device="cuda")
+    pro = dict(stats=st, pro_b=tab, pro_w=tab.data_ptr() + 4 * Cd, **grp)
+    hn = dict(hn_w=hnw, hn_cols=2 * Cd, hn_split=Cd, hn_eps=1e-5)
+    seen = []
+
+    def both(call, **f16kw):
+        y32 = call()
+        variant(ops, seen)
+        try:
+            y16 = call(**f16kw)
+        finally:
+            ops.GEMM_HOOK = None
+        assert seen[-1] >= 2000000, seen
+        return y32, y16
+
+    def qkv(**kw):
+        y = torch.empty(rows, 3 * Cd, device="cuda")
+        ops.gemm(x, Wq, y, rows, 3 * Cd, Cd, **hn, **(kw if "A2" in kw else dict(pro, **kw)))
+        return y
+    a2 = torch.empty(2, rows, Cd, dtype=torch.float16, device="cuda")
+    ops.norm_split2(x, a2, rows, Cd, ymax, mode=ops.LN, eps=1e-5, b=tab, w=tab.data_ptr() + 4 * Cd,
+                    rows_per_group=N_ if per_sample else 0, gstride=3 * Cd if per_sample else 0)
+    w2q = split2_f16(Wq)
+    y32, y16 = both(qkv, W2=w2q, a_amax=ymax)
+    torch.testing.assert_close(y16, y32, atol=3e-5, rtol=2e-5)
+    _, y16p = both(qkv, W2=w2q, a_amax=ymax, A2=a2)
+    torch.testing.assert_close(y16p, y32, atol=3e-5, rtol=2e-5)
+
+    def glu(**kw):
+        y = torch.empty(rows, hidden, device="cuda")
+        ops.gemm(x, W13, y, rows, 2 * hidden, Cd, glu=1, **(kw if "A2" in kw else dict(pro, **kw)))
+        return y
+    w2g = split2_f16(W13)
+    h32, h16 = both(glu, W2=w2g, a_amax=ymax)
+    torch.testing.assert_close(h16, h32, atol=1e-4, rtol=3e-5)
+    _, h16p = both(glu, W2=w2g, a_amax=ymax, A2=a2)
+    torch.testing.assert_close(h16p, h32, atol=1e-4, rtol=3e-5)
+
+    o = torch.randn(rows, Cd, generator=g(9)).cuda() * 2
+    res = torch.randn(rows, Cd, generator=g(10)).cuda()
+
+    def gate(**kw):
+        y = res.clone()
+        ops.gemm(o, Wo, y, rows, Cd, Cd, bias=bo, mul=tab.data_ptr() + 8 * Cd, res=y, **mgrp, **kw)
+        return y
+    g32, g16 = both(gate, W2=split2_f16(Wo), a_amax=torch.tensor([float(o.abs().max()) * 7], device="cuda"))
+    torch.testing.assert_close(g16, g32, atol=5e-5, rtol=2e-5)
+
+
+def test_norm_split2_is_the_scaled_two_part_split():
+    from physdock_amd import ops
+    M, Cd = 1024, 512
+    x = (torch.randn(M, Cd, generator=g(1)) * 2 - 0.5).cuda()
+    w = (1 + 0.3 * torch.randn(Cd, generator=g(2))).cuda(); b = (0.2 * torch.randn(Cd, generator=g(3))).cuda()
+    amax = torch.tensor([40.0], device="cuda")                                      # > |y| everywhere
+    out = torch.empty(2, M, Cd, dtype=torch.float16, device="cuda")
+    ops.norm_split2(x, out, M, Cd, amax, mode=ops.LN, eps=1e-5, w=w, b=b)
+    y = torch.nn.functional.layer_norm(x.double(), (Cd,), w.double(), b.double(), 1e-5)
+    assert float(y.abs().max()) < 40.0
+    scale = 2.0 ** (13 - math.floor(math.log2(40.0)))                                # 40 * scale in [2^13, 2^14)
+    rec = out.double().sum(0) / scale
+    assert float((rec - y).abs().max()) < 3e-6                                       # fp32 evaluation of the norm dominates
+    assert float(out[0].float().abs().max()) < 2 ** 14
+    yf = ((x - x.mean(-1, keepdim=True)) * torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5) * w + b) * scale
+    hi = yf.to(torch.float16)
+    assert float((out[0].float() - hi.float()).abs().max()) <= float(hi.float().abs().max()) * 2 ** -10    # same rounding up to fp32 noise
+
+
+def test_dit_bounds_hold_and_are_not_wild(medium_block_inputs=None):
+    """pd_dit_bounds: the bounds really bound (LayerNorm + AdaLN algebra) and are within ~2^7 of the observed maxima"""
+    from physdock_amd import ops
+    nrows, nb, Cd = 5, 3, 128
+    tab = (0.4 * torch.randn(nrows, nb * 6 * Cd, generator=g(1))).cuda()
+    for b in range(nb):
+        tab[:, b * 6 * Cd + Cd:b * 6 * Cd + 2 * Cd] += 1.0
+        tab[:, b * 6 * Cd + 4 * Cd:b * 6 * Cd + 5 * Cd] += 1.0
+    Wv = torch.randn(nb, Cd, Cd, generator=g(2)) / math.sqrt(Cd)
+    W1 = torch.randn(nb, 256, Cd, generator=g(3)) / math.sqrt(Cd); W3 = torch.randn(nb, 256, Cd, generator=g(4)) / math.sqrt(Cd)
+    consts = torch.tensor([[7.0, 6.0, float(Wv[b].norm(dim=1).max()), float(W1[b].norm(dim=1).max() * W3[b].norm(dim=1).max())]
+                           for b in range(nb)]).cuda()
+    out = torch.empty(nrows, nb, 8, device="cuda")
+    ops.check(ops._lib.init().pd_dit_bounds(ops.ptr(tab), nrows, tab.shape[1], nb, Cd, ops.ptr(consts), ops.ptr(out), ops.stream()), "b")
+    out = out.cpu()
+    x = torch.randn(4096, Cd, generator=g(5)) * torch.exp(torch.randn(4096, 1, generator=g(6)))     # arbitrary activations
+    xh = torch.nn.functional.layer_norm(x, (Cd,))
+    t = tab.cpu()
+    for r in range(nrows):
+        for b in range(nb):
+            base = b * 6 * Cd
+            y1 = xh * t[r, base + Cd:base + 2 * Cd] + t[r, base:base + Cd]
+            y2 = xh * t[r, base + 4 * Cd:base + 5 * Cd] + t[r, base + 3 * Cd:base + 4 * Cd]
+            v = y1 @ Wv[b].T
+            h = torch.nn.functional.silu(y2 @ W1[b].T) * (y2 @ W3[b].T)
+            got = out[r, b]
+            assert float(got[0]) == 7.0 and float(got[1]) == 6.0
+            for val, bound, name in ((y1, got[3], "y"), (y2, got[4], "y'"), (v, got[2], "v"), (h, got[5], "h")):
+                m = float(val.abs().max())
+                assert m <= float(bound), (name, m, float(bound))
+                assert float(bound) <= m * (2 ** 7 if name != "h" else 2 ** 12), (name, m, float(bound))

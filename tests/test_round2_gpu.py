@@ -122,7 +122,7 @@ def test_b64_matches_small_batches_and_takes_the_wide_attention(medium):
         x64 = medium.sample_diffusion(dbatch, num_sample=B, noise=noise, use_graph=False, **kw)
     finally:
         ops.ATTN_HOOK = None
-    assert variants & {8, 1008}, variants          # the 8-wave kernels (fp32 MFMA / bf16 split) only B >= 32 selects
+    assert variants & {8, 1008, 2008}, variants    # the 8-wave kernels (fp32 MFMA / bf16 split / fp16 split) only B >= 32 selects
     x64g = medium.sample_diffusion(dbatch, num_sample=B, noise=noise, use_graph=True, **kw)
     x64g = medium.sample_diffusion(dbatch, num_sample=B, noise=noise, use_graph=True, **kw)      # replay
     assert torch.equal(x64, x64g)

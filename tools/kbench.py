@@ -36,8 +36,12 @@ def main():
         from physdock_amd.packing import split3_bf16
         W3 = split3_bf16(W)
         t6 = timeit(lambda: ops.gemm(A, W, Y, M, N, K, glu=glu, W3=W3, **kw))
+        from physdock_amd.packing import split2_f16
+        W2 = split2_f16(W)
+        amax = torch.tensor([float(A.abs().max())], device="cuda")
+        t3 = timeit(lambda: ops.gemm(A, W, Y, M, N, K, glu=glu, W3=W3, W2=W2, a_amax=amax, **kw))
         print(f"gemm {tag:14s} M={M:7d} N={N:5d} K={K:5d}: fp32 MFMA {t*1e6:9.1f} us {2*M*N*K/t/1e12:7.1f} TF | "
-              f"bf16x6 {t6*1e6:9.1f} us {2*M*N*K/t6/1e12:7.1f} TF")
+              f"bf16x6 {t6*1e6:9.1f} us {2*M*N*K/t6/1e12:7.1f} TF | f16x3 {t3*1e6:9.1f} us {2*M*N*K/t3/1e12:7.1f} TF")
     for (nb, H, n, tag) in [(B, 4, 2048, "dit atom"), (B, 16, 256, "dit token"), (256, 4, 256, "triangle"),
                             (1, 4, 2048, "trunk atom"), (128, 8, 256, "msa row")]:
         C = H * 32
