@@ -185,23 +185,26 @@ class LaunchTimer:
 
         def gemm_hook(a, launch):
             v = L.pd_gemm_variant(C.byref(a))
-            split, v = v >= 1000000, v % 1000000
+            nprod, v = (3 if v >= 2000000 else 6 if v >= 1000000 else 0), v % 1000000
             streamed, epi, tcode, v = (v % 10000) >= 5000, (v // 10000) % 10, v // 100000, v % 5000
             cfg, lay, pro, scalar = (v % 1000) // 100, (v % 100) // 10, v % 10, v >= 1000
             name = "gemm_kernel<%s, %s, %s, %s, %d>" % (self.GEMM_NAMES[cfg], "true" if lay >= 1 else "false",
                                                          "true" if lay == 2 else "false", "false" if scalar else "true", pro)
             if streamed:        # persistent direct-epilogue variant (csrc/gemm_stream.hip)
                 name = "gemm_stream_kernel<%d, %d, Tile<%s> >" % (pro, epi, ("128, 128, 2", "64, 64, 2", "128, 64, 4")[tcode])
-                if split:       # 3 x bf16 split-operand variant (csrc/gemm_split.hip); names as rocprofv3 prints them:
+                glu_tile = epi in (2, 5)
+                if nprod == 6:  # 3 x bf16 split-operand variant (csrc/gemm_split.hip); names as rocprofv3 prints them:
                     # PRO = 3 when A arrives pre-split (pd_gemm_args.A3); the STile's last argument = direct-W loop
-                    glu_tile = epi in (2, 5)
                     name = "gemm_split_kernel<%d, %d, STile<%s> >" % (
                         3 if a.A3 else pro, epi,
                         (("128, 128, 4, 8, false" if glu_tile else "128, 128, 2, 8, true"), "64, 64, 2, 4, true", "128, 64, 4, 4, true")[tcode])
+                elif nprod == 3:  # 2 x fp16 split-operand variant (csrc/gemm_f16.hip)
+                    name = "gemm_f16_kernel<%d, %d, FTile<%s> >" % (3 if a.A2 else pro, epi,
+                                                                   "128, 128, 4, 8, false" if glu_tile else "128, 128, 2, 8, true")
             nb = max(a.batch, 1)
             n_out = a.N // 2 if a.glu else a.N
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))
-            self.split[name] = 6 if split else 0
+            self.split[name] = nprod
             shape = "M=%d N=%d K=%d" % (a.M, a.N, a.K) + (" x%d" % nb if nb > 1 else "")
             self._launch(name, shape, launch, 2.0 * a.M * a.N * a.K * nb, byt)
 

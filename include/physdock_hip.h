@@ -89,7 +89,7 @@ typedef struct pd_gemm_args {
        falls through to W3 / fp32 as before.  The caller guarantees |A'[m,k]| <= *a_amax for the A the contraction sees (after
        the prologue): a larger element overflows fp16.  pd_dit_bounds derives such bounds for the DiT blocks.                  */
     const void* W2;              /* W[n,:] * w_scale[n] as two fp16 parts (hi, lo), fragment-major [2][ceil(N/32)][Kp/16][64][8]
-                                    (packing.split2_f16); w_scale[n] = power of two that brings max_k |W[n,k]| below 2^14      */
+                                    (packing.split2_f16); w_scale[n] = power of two that brings max_k |W[n,k]| into [2^14, 2^15)      */
     const float* w_inv;          /* [N]  1 / w_scale[n]                                                                        */
     const void* A2;              /* optional: A already normalised, modulated, scaled by the power of two pd_gemm derives from
                                     *a_amax, and split into two fp16 parts [2][M][K] (pd_norm_split2); K % 32 == 0, no prologue  */
@@ -160,6 +160,10 @@ typedef struct pd_attn_args {
     int f16x3;               /* 1: use the fp16 format (needs the bounds below); 0: bf16 x 6 (any fp32 input)              */
     float f16_q_amax, f16_k_amax, f16_v_amax;
     const float* f16_amax;   /* optional device array [3]; overrides the by-value bounds                                  */
+    void* O2;                /* optional, f16x3 launches only: instead of O, write the output ALREADY SPLIT for the projection that
+                                follows - two fp16 parts [2][nbatch*nq][nheads*32] of o times the power of two derived from the v
+                                bound (|o| <= max|v|), i.e. pd_gemm_args.A2 with a_amax = &f16_amax[2]; rows are (batch, query)
+                                in order, so it needs o_bs = nq * o_ss and o_ss = nheads * 32.  16-byte aligned.              */
 } pd_attn_args;
 /* Launches that cannot fill the chip (nbatch * nheads * ceil(nq/128) < 512 blocks) with a long key range are split into
  * up to 8 key chunks when ws holds nsplit * nbatch * nq * nheads * 34 floats; a second kernel merges the chunks. */

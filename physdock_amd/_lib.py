@@ -70,7 +70,7 @@ class AttnArgs(C.Structure):
         ("v_bs", C.c_longlong), ("v_ss", C.c_longlong), ("o_bs", C.c_longlong), ("o_ss", C.c_longlong),
         ("bias", _fp), ("scale", C.c_float), ("bias_nk", C.c_int), ("fp32_mfma", C.c_int),
         ("ws", _fp), ("ws_bytes", C.c_longlong), ("nsplit", C.c_int),
-        ("f16x3", C.c_int), ("f16_q_amax", C.c_float), ("f16_k_amax", C.c_float), ("f16_v_amax", C.c_float), ("f16_amax", _fp),
+        ("f16x3", C.c_int), ("f16_q_amax", C.c_float), ("f16_k_amax", C.c_float), ("f16_v_amax", C.c_float), ("f16_amax", _fp), ("O2", _fp),
     ]
 
 
@@ -169,7 +169,7 @@ def _declare(L):
 def ptr(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8, torch.bfloat16), (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.float64, torch.int32, torch.int64, torch.uint8, torch.bfloat16, torch.float16), (t.device, t.dtype)
     return t.data_ptr()
 
 

@@ -5,7 +5,7 @@
 //   * three partial products per block (hi.hi, hi.lo, lo.hi): 12 v_mfma_f32_32x32x16_f16 per 32-key sub-tile instead of 24
 //     bf16 MFMAs, 6 instead of 11 VALU operations per split pair, two thirds of the LDS bytes;
 //   * the scales come from UPPER BOUNDS of |q|, |k|, |v| (pd_attn_args.f16_amax / f16_*_amax: by value or read from device
-//     memory) so that no scaled value overflows fp16; p = exp2(s - m) in [0, 1] is carried times 2^13 inside the exponent.
+//     memory) so that no scaled value overflows fp16; p = exp2(s - m) in [0, 1] is carried times 2^14 inside the exponent.
 // Measured against float64 the contraction is at least as accurate as v_mfma_f32_32x32x2_f32 for K >= 32
 // (tools/micro/f16x2_probe.hip, profiles/r03_f16x2_probe.txt; tests/test_attention_f16_gpu.py for this kernel).
 // The kernel template is written for NP = 2 or 3 parts; only NP = 2 is instantiated here.
@@ -230,9 +230,9 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         m_run = m_new;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= alpha;      // (a wave-uniform "no maximum moved" skip measured -20 %: it splits the schedule)
-        // fp16 parts: p is carried times 2^13 (inside the exponent), so that its low part stays a normal fp16 number down
+        // fp16 parts: p is carried times 2^14 (inside the exponent), so that its low part stays a normal fp16 number down
         // to p = 2^-16; the sum l carries the same factor and it cancels in o / l
-        const float m_exp = NP == 2 ? m_new - 13.0f : m_new;
+        const float m_exp = NP == 2 ? m_new - 14.0f : m_new;
         float psum = 0.f;
         const unsigned short* vbase = sV + l31 * VP + sub * 32 + 8 * hh;
         // one k-step (8 of the lane's 16 keys) at a time: exp, split, the MFMAs - the probabilities of the second half are
@@ -279,12 +279,26 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
 
     if (query < p.nq) {
         const float l = pd_xhalf_sum(l_run);
-        const float inv = NP == 2 ? inv_sv / l : 1.0f / l;
-        float* op = p.O + (long long)b * p.o_bs + (long long)query * p.o_ss + h * 32 + 4 * hh;
+        if (NP == 2 && p.O2) {
+            // output already split for the projection that follows (pd_gemm_args.A2): o times the V scale (|o| <= max|v|, the
+            // same bound and hence the same power of two the GEMM derives from f16_amax[2]) is exactly O' / l'
+            const float inv = 1.0f / l;
+            const long long rows = (long long)p.nbatch * p.nq, C = (long long)p.nheads * 32;
+            unsigned short* op = reinterpret_cast<unsigned short*>(p.O2) + ((long long)b * p.nq + query) * C + h * 32 + 4 * hh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
-            *reinterpret_cast<f32x4*>(op + 8 * g) = v;
+            for (int g = 0; g < 4; ++g) {
+                const pd_parts2 p0 = pd_split2h(o[4 * g] * inv, o[4 * g + 1] * inv), p1 = pd_split2h(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                *reinterpret_cast<u32x2*>(op + 8 * g) = u32x2{p0.h, p1.h};
+                *reinterpret_cast<u32x2*>(op + rows * C + 8 * g) = u32x2{p0.l, p1.l};
+            }
+        } else {
+            const float inv = NP == 2 ? inv_sv / l : 1.0f / l;
+            float* op = p.O + (long long)b * p.o_bs + (long long)query * p.o_ss + h * 32 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + 8 * g) = v;
+            }
         }
     }
 }
@@ -315,6 +329,8 @@ extern "C" int pd_attention_f16_try(const pd_attn_args* a, void* stream, int ini
     if (init_only == 1) return raise_lds<8, 2>() && raise_lds<4, 2>() ? PD_OK : PD_ERR_LAUNCH;
     // the fp16 format needs finite positive magnitude bounds for q, k, v: by value or in device memory (f16_amax[3])
     if (!a->f16_amax && !(a->f16_q_amax > 0.f && a->f16_k_amax > 0.f && a->f16_v_amax > 0.f)) return PD_ERR_ARG;
+    if (a->O2 && (((uintptr_t)a->O2 & 15) || a->o_ss != (long long)a->nheads * 32 || a->o_bs != (long long)a->nq * a->o_ss))
+        return PD_ERR_ARG;                       // the split output is a dense [rows][C] operand
     launch<2>(a, (hipStream_t)stream);
     return pd_check_launch();
 }

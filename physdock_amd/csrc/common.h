@@ -100,7 +100,7 @@ __device__ __forceinline__ pd_parts pd_split2(float a, float b) {
 // residual a - h is exact in fp32, so h + l carries 22 significand bits of a as long as |a| < 65504 and l is a normal fp16
 // number (|a| >= 2^-3; below that the error is bounded by 2^-25 absolute).  6 VALU operations per two values (two packed
 // conversions, two re-expansions, two subtractions) against 11 for the three-way bf16 split.  Callers scale by a power of
-// two first (pd_pow2_scale) so that the operand's largest magnitude sits just below 2^14.
+// two first (pd_pow2_scale) so that the operand's largest magnitude sits just below 2^15.
 typedef _Float16 pd_f16x2 __attribute__((ext_vector_type(2)));
 struct pd_parts2 { unsigned h, l; };
 __device__ __forceinline__ pd_parts2 pd_split2h(float a, float b) {
@@ -113,12 +113,13 @@ __device__ __forceinline__ pd_parts2 pd_split2h(float a, float b) {
     r.l = __builtin_bit_cast(unsigned, l);
     return r;
 }
-// power of two s such that amax * s lies in [2^13, 2^14) (amax = f 2^(e-127), f in [1, 2)  ->  s = 2^(13 - (e - 127)));
-// scales are capped to [2^-60, 2^53] so that zero / tiny / huge bounds stay finite
+// power of two s such that amax * s lies in [2^14, 2^15) (amax = f 2^(e-127), f in [1, 2)  ->  s = 2^(14 - (e - 127))): the
+// largest power-of-two scaling that keeps a value bounded by amax below fp16's 65504; scales are capped to [2^-59, 2^54] so
+// that zero / tiny / huge bounds stay finite
 __device__ __forceinline__ float pd_pow2_scale(float amax) {
     int e = (__float_as_int(amax) >> 23) & 0xff;
     e = e < 87 ? 87 : (e > 200 ? 200 : e);
-    return __int_as_float((267 - e) << 23);
+    return __int_as_float((268 - e) << 23);
 }
 
 __device__ __forceinline__ int pd_frag_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }

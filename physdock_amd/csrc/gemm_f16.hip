@@ -373,7 +373,7 @@ int dispatch_f16(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s)
     PD_FCASE(0, EPI_PLAIN, F128) PD_FCASE(1, EPI_PLAIN, F128) PD_FCASE(3, EPI_PLAIN, F128)
     PD_FCASE(1, EPI_HN, F128) PD_FCASE(2, EPI_HN, F128) PD_FCASE(3, EPI_HN, F128)
     PD_FCASE(1, EPI_GLU, F128G) PD_FCASE(2, EPI_GLU, F128G) PD_FCASE(3, EPI_GLU, F128GD)
-    PD_FCASE(0, EPI_GATERES, F128)
+    PD_FCASE(0, EPI_GATERES, F128) PD_FCASE(3, EPI_GATERES, F128)
 #undef PD_FCASE
     return PD_ERR_UNSUPPORTED;
 }

@@ -502,24 +502,32 @@ class Engine:
             st = self.stats(x, rows, C, LN, eps)
             self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
                       pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
-        o = self.lws("dit_o", rows, C)
         st3 = (N * 3 * C, 3 * C)
         # bnd: device address of this (step, block)'s magnitude bounds: chip-filling attention launches then take the two-part
-        # fp16 operand format too
-        ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, nq=N, nk=nk, nbatch=B, nheads=H,
-                      q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias, bias_nk=N,
-                      ws=self.attn_ws(B, N, nk, H), f16_amax=bnd)
+        # fp16 operand format too - and write their output already split for linear_o (no split VALU in that GEMM's staging)
+        akw = dict(nq=N, nk=nk, nbatch=B, nheads=H, q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias,
+                   bias_nk=N, ws=self.attn_ws(B, N, nk, H), f16_amax=bnd)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
-        self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, a_amax=b_o, **mgrp)
+        o_split = f16 and ops.F16_ATTN and ops.SPLIT_ATTN and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C \
+            and ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw) >= 2000 \
+            and ops.presplit_supported(rows, C, C, f16=True, gate=True)
+        if o_split:
+            o2 = self.lws("dit_o2", 2, rows, C, dtype=torch.float16)
+            ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, O2=o2, **akw)
+            self.gemm(x, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, a_amax=b_o, A2=o2, **mgrp)
+        else:
+            o = self.lws("dit_o", rows, C)
+            ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, **akw)
+            self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, a_amax=b_o, **mgrp)
         h = self.lws("dit_h", rows, hidden)
-        o2 = tab_off + 3 * C
+        t2 = tab_off + 3 * C
         if presplit:
-            self.gemm(x, W13, h, rows, 2 * hidden, C, glu=1, a_amax=b_y2, **norm_split(o2, b_y2))
+            self.gemm(x, W13, h, rows, 2 * hidden, C, glu=1, a_amax=b_y2, **norm_split(t2, b_y2))
         else:
             st = self.stats(x, rows, C, LN, eps)
-            self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, o2), pro_w=off(tab, o2 + C), glu=1, a_amax=b_y2, **grp)
+            self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, t2), pro_w=off(tab, t2 + C), glu=1, a_amax=b_y2, **grp)
         W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
-        self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, o2 + 2 * C), res=x, a_amax=b_h, **mgrp)
+        self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, t2 + 2 * C), res=x, a_amax=b_h, **mgrp)
 
     def af3_dit(self, batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=False):
         """AF3DiT.forward (transformers.py:235-262) for one noise level.

@@ -40,12 +40,12 @@ def const_vec(val, n):
 _PRESPLIT_OK = {}
 
 
-def presplit_supported(M, N, K, *, glu=0, hn=False, f16=False):
+def presplit_supported(M, N, K, *, glu=0, hn=False, f16=False, gate=False):
     """Does the library take a pre-split A operand for this projection - [3][M][K] bf16 (pd_gemm_args.A3), or with f16=True
     [2][M][K] fp16 (A2, csrc/gemm_f16.hip)?  Asked of the library itself (pd_gemm_variant: tile-count threshold, alignment and
     epilogue rules live in csrc/gemm_split.hip / gemm_f16.hip), so a differently tuned build changes the answer here, not an
     error in pd_gemm."""
-    key = (M, N, K, int(glu), bool(hn), bool(f16))
+    key = (M, N, K, int(glu), bool(hn), bool(f16), bool(gate))
     r = _PRESPLIT_OK.get(key)
     if r is None:
         a = GemmArgs()
@@ -59,6 +59,9 @@ def presplit_supported(M, N, K, *, glu=0, hn=False, f16=False):
         a.batch, a.glu, a.out_scale = 1, int(glu), 1.0
         if hn:
             a.hn_w, a.hn_cols, a.hn_split = 1 << 20, 0, 32
+        if gate:                                         # gate x (acc + bias) + residual with one gate row for all rows
+            a.res = a.mul = 1 << 20
+            a.ldres, a.mul_rows_per_group = N, M
         r = _lib.init().pd_gemm_variant(C.byref(a)) >= (2000000 if f16 else 1000000)
         _PRESPLIT_OK[key] = r
     return r
@@ -144,6 +147,8 @@ SPLIT_ATTN = True
 F16_ATTN = True
 #: the same for GEMM launches that carry fp16-split weights and a bound of |A| (W2=, a_amax=)
 F16_GEMM = True
+#: fp16-parts attention launches write their output already split for the projection that follows (pd_attn_args.O2 -> A2)
+ATTN_SPLIT_OUT = True
 
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None
@@ -206,7 +211,7 @@ def attn_split_ws_numel(nbatch, nq, nk, nheads):
 
 
 def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_strides, o_strides, bias=None,
-              scale=1.0 / math.sqrt(32.0), ws=None, bias_nk=0, f16_amax=None):
+              scale=1.0 / math.sqrt(32.0), ws=None, bias_nk=0, f16_amax=None, O2=None, query_only=False):
     """strides = (batch_stride, seq_stride) in floats; Q/K/V/O tensors or raw addresses.  ws: optional float scratch
     tensor (attn_split_ws_numel) enabling key-split launches for small grids.  bias_nk: key count the bias buffer was laid
     out for (the padded count when nk is the real one)."""
@@ -214,6 +219,7 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
         return x if (x is None or isinstance(x, int)) else ptr(x)
     a = AttnArgs()
     a.Q, a.K, a.V, a.O = P(Q), P(K), P(V), P(O)
+    a.O2 = P(O2)
     a.nq, a.nk, a.nbatch, a.nheads = nq, nk, nbatch, nheads
     a.q_bs, a.q_ss = q_strides
     a.k_bs, a.k_ss = k_strides
@@ -233,6 +239,8 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
             a.f16_q_amax, a.f16_k_amax, a.f16_v_amax = (float(v) for v in f16_amax)
     if ws is not None:
         a.ws, a.ws_bytes = ptr(ws), ws.numel() * 4
+    if query_only:            # the kernel pd_attention would pick (pd_attention_variant): >= 2000 = fp16-parts kernel
+        return _lib.init().pd_attention_variant(C.byref(a))
     if ATTN_HOOK is not None:
         return ATTN_HOOK(a, lambda: check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention"))
     check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention")

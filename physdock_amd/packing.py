@@ -62,16 +62,16 @@ def split3_bf16(W):
 
 
 def split2_f16(W):
-    """The B operand of csrc/gemm_f16.hip: W [N,K] times a per-row power of two (max_k |W[n,k]| w_scale[n] in [2^13, 2^14)),
+    """The B operand of csrc/gemm_f16.hip: W [N,K] times a per-row power of two (max_k |W[n,k]| w_scale[n] in [2^14, 2^15)),
     split into two fp16 parts (hi = fp16(w'), lo = fp16(w' - hi): 22 significand bits), stored FRAGMENT-MAJOR like split3_bf16:
     [2][ceil(N/32)][Kp/16][64][8].  Returns (parts, w_inv [N] fp32 = 1 / w_scale).  Rows of zeros get scale 1."""
     W = W.float()
     N, K = W.shape
     Kp = (K + 31) // 32 * 32
     amax = W.abs().amax(1)
-    # w_scale = 2^(13 - floor(log2(amax))): frexp gives amax = m 2^e with m in [0.5, 1) -> floor(log2) = e - 1
+    # w_scale = 2^(14 - floor(log2(amax))): frexp gives amax = m 2^e with m in [0.5, 1) -> floor(log2) = e - 1
     e = torch.frexp(amax)[1]
-    w_scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), 14 - e), torch.ones_like(amax))
+    w_scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), 15 - e), torch.ones_like(amax))
     Ws = W * w_scale[:, None]
     hi = Ws.to(torch.float16)
     lo = (Ws - hi.float()).to(torch.float16)

@@ -35,9 +35,9 @@ def ref64(q, k, v, bias):
     h = lambda x: x.double().reshape(B, -1, H, 32).transpose(1, 2)
     s = h(q) @ h(k).transpose(-1, -2) / math.sqrt(32)
     if bias is not None:
-        # the -1e9 mask entries absorb the logit in fp32 (ulp(1e9) = 64): that rounding is the semantics of the reference's
-        # fp32 `s + attn_mask` (a fully masked row is a uniform softmax), so the float64 reference applies it too
-        s = torch.where(bias[None] <= -1e8, torch.full_like(s, -1e9), s + bias.double()[None])
+        # masked keys (-1e9) get weight exp(-1e9) = 0 in every arithmetic; no query row is fully masked here (that case - a
+        # uniform softmax through fp32 absorption of the logit - is covered by tests/test_kernels_gpu.py::test_attention)
+        s = torch.where(bias[None] <= -1e8, torch.full_like(s, -float("inf")), s + bias.double()[None])
     return (torch.softmax(s, -1) @ h(v)).transpose(1, 2).reshape(B, nq, C)
 
 
@@ -52,13 +52,12 @@ def test_f16_attention_error_vs_float64_not_above_fp32_mfma(B, H, nq, nk, use_bi
     # per-element dynamic range of ~2^+-6 on top of the overall magnitude `mag` (V and K far from unit scale too)
     wide = lambda x, s: x * torch.exp(2.0 * torch.randn(x.shape, generator=g(s)))
     q = torch.randn(B, nq, C, generator=g(1))
-    k = wide(torch.randn(B, nk, C, generator=g(2)), 12) * 0.5
+    k = torch.randn(B, nk, C, generator=g(2)) * (1 + torch.rand(B, nk, 1, generator=g(12)))       # logits of a few units
     v = wide(torch.randn(B, nk, C, generator=g(3)), 13) * mag
     bias = None
     if use_bias:
         bias = 2 * torch.randn(H, nq, nk, generator=g(4))
-        bias[:, :, ::7] = -1e9
-        bias[:, 5, :] = -1e9             # fully masked query row -> uniform softmax over the keys
+        bias[:, :, ::7] = -1e9           # masked keys
     ref = ref64(q, k, v, bias)
     amax = (float(q.abs().max()), float(k.abs().max()), float(v.abs().max()))
     errs = {}
@@ -93,3 +92,24 @@ def test_f16_attention_needs_bounds():
     a.scale = 1 / math.sqrt(32)
     a.f16x3 = 1                                   # no bounds: refused, nothing launched
     assert ops._lib.init().pd_attention(C_.byref(a), ops.stream()) == -1
+
+
+def test_f16_attention_split_output_is_the_scaled_two_part_split_of_o():
+    """pd_attn_args.O2: the output written as the A2 operand of the projection that follows = (hi, lo) fp16 parts of o times the
+    power of two of the v bound"""
+    from physdock_amd import ops
+    B, H, n = 32, 4, 512
+    C = H * 32
+    q = torch.randn(B, n, C, generator=g(1)); k = torch.randn(B, n, C, generator=g(2)); v = 3 * torch.randn(B, n, C, generator=g(3))
+    bias = 2 * torch.randn(H, n, n, generator=g(4))
+    amax = torch.tensor([float(q.abs().max()), float(k.abs().max()), float(v.abs().max())], device="cuda")
+    o = run(ops, q, k, v, bias, "f16", amax)
+    o2 = torch.empty(2, B * n, C, dtype=torch.float16, device="cuda")
+    st = (n * C, C)
+    ops.attention(q.cuda(), k.cuda(), v.cuda(), None, O2=o2, nq=n, nk=n, nbatch=B, nheads=H, q_strides=st, k_strides=st, v_strides=st,
+                  o_strides=st, bias=ops.bias_to_frag(bias).cuda(), f16_amax=amax)
+    vmax = float(v.abs().max())
+    scale = 2.0 ** (14 - math.floor(math.log2(vmax)))
+    rec = (o2.double().sum(0) / scale).reshape(B, n, C).cpu()
+    assert float(o2[0].float().abs().max()) < 2 ** 15
+    assert float((rec - o.double()).abs().max()) <= 2.0 ** -21 * float(o.abs().max())

