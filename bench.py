@@ -265,6 +265,11 @@ def main():
     device = torch.device("cuda", local if dist else 0)
     torch.cuda.set_device(device)
 
+    if os.environ.get("PD_BENCH_TWEAK"):          # lab A/B runs (tools/ab_f16.sh): "NAME=value,..." sets physdock_amd.ops switches
+        from physdock_amd import ops as _o
+        for kv in os.environ["PD_BENCH_TWEAK"].split(","):
+            k_, v_ = kv.split("=")
+            setattr(_o, k_, {"True": True, "False": False}.get(v_, int(v_) if v_.isdigit() else v_))
     cfg, P, batch, dbatch, confs, model = build_inputs(args, device)
     B, nsteps = args.samples, args.diffusion_steps
     A = batch["ref_pos"].shape[0]

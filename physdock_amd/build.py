@@ -45,6 +45,8 @@ def compile_cmd(src, out, mode=("-c",)):
            "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, *mode, src, "-o", out]
     if os.environ.get("PD_NO_EXTRA_FLAGS") != "1":
         cmd[1:1] = NO_PACKED_F32
+    if os.environ.get("PD_SPLIT2H_PLAIN"):   # lab: the two-part split without v_fma_mix (A/B of the instruction count)
+        cmd[1:1] = ["-DPD_SPLIT2H_PLAIN=1"]
     if os.environ.get("PD_LAB"):          # lab build: in-kernel phase traces + getenv tuning overrides (never shipped)
         cmd[1:1] = ["-DPD_LAB=1"]
     if os.environ.get("PD_BK") and base == "gemm.hip":
@@ -62,7 +64,7 @@ def compile_cmd(src, out, mode=("-c",)):
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_KSPLIT_MAX_BYTES") and base == "gemm_stream.hip":
         cmd[1:1] = ["-DPD_KSPLIT_MAX_BYTES=" + os.environ["PD_KSPLIT_MAX_BYTES"]]
-    for knob in ("PD_F16_GLU_DW", "PD_F16_MIN_TILES"):
+    for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES"):
         if os.environ.get(knob) and base == "gemm_f16.hip":
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     for knob in ("PD_SPLIT_MIN_TILES", "PD_SPLIT_MIN_TILES_SMALL"):

@@ -98,19 +98,28 @@ __device__ __forceinline__ pd_parts pd_split2(float a, float b) {
 
 // Two-way fp16 split of TWO floats at a time: a = h + l with h = fp16(a) (round to nearest even) and l = fp16(a - h); the
 // residual a - h is exact in fp32, so h + l carries 22 significand bits of a as long as |a| < 65504 and l is a normal fp16
-// number (|a| >= 2^-3; below that the error is bounded by 2^-25 absolute).  6 VALU operations per two values (two packed
-// conversions, two re-expansions, two subtractions) against 11 for the three-way bf16 split.  Callers scale by a power of
+// number (|a| >= 2^-3; below that the error is bounded by 2^-25 absolute).  3 VALU operations per two values (one packed
+// conversion + two mixed-precision fma) against 11 for the three-way bf16 split.  Callers scale by a power of
 // two first (pd_pow2_scale) so that the operand's largest magnitude sits just below 2^15.
 typedef _Float16 pd_f16x2 __attribute__((ext_vector_type(2)));
 struct pd_parts2 { unsigned h, l; };
 __device__ __forceinline__ pd_parts2 pd_split2h(float a, float b) {
     pd_parts2 r;
     const pd_f32x2 v = {a, b};
-    const pd_f16x2 h = __builtin_convertvector(v, pd_f16x2);
+    const pd_f16x2 h = __builtin_convertvector(v, pd_f16x2);          // v_cvt_pk_f16_f32
     r.h = __builtin_bit_cast(unsigned, h);
+#ifndef PD_SPLIT2H_PLAIN
+    // residual and its conversion in ONE instruction per value: v_fma_mix{lo,hi}_f16 reads the fp16 half as an fp32 operand,
+    // computes fma(h, -1, a) = a - h (exact in fp32) and rounds it to fp16 into the low / high half of the destination -
+    // three instructions per pair instead of six (two re-expansions, a subtraction pair, a packed conversion).  hipcc has no
+    // pattern that forms these from C (it re-expands and subtracts), hence the asm; plain VALU, no memory, no extra hazards.
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(r.l) : "v"(r.h), "v"(a), "v"(b));
+#else
     const pd_f32x2 res = {a - (float)h[0], b - (float)h[1]};
     const pd_f16x2 l = __builtin_convertvector(res, pd_f16x2);
     r.l = __builtin_bit_cast(unsigned, l);
+#endif
     return r;
 }
 // power of two s such that amax * s lies in [2^14, 2^15) (amax = f 2^(e-127), f in [1, 2)  ->  s = 2^(14 - (e - 127))): the

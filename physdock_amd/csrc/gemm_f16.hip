@@ -362,10 +362,12 @@ int run_f16(int op, const pd_gemm_args* p, hipStream_t s) {
 
 using F128 = FTile<128, 128, 2, 8, true>;    // 2 x 4 waves of 64 x 32, direct W
 using F128G = FTile<128, 128, 4, 8, false>;  // 4 x 2 waves of 32 x 64 (GLU: a wave owns both columns of a pair), W through LDS
-#ifdef PD_F16_GLU_DW
-using F128GD = FTile<128, 128, 4, 8, true>;  // ... direct W: with two parts and a pre-split A the fragment buffers fit (124 VGPRs)
-#else
+#ifdef PD_F16_GLU_LDSW
 using F128GD = F128G;
+#else
+// ... direct W: with two parts and a pre-split A the two B fragment buffers fit (124 VGPRs, no spill; with the in-kernel norm
+// prologue they spill 4-8 registers, so those cases keep W in LDS): token SwiGLU projection 196 -> 190 us
+using F128GD = FTile<128, 128, 4, 8, true>;
 #endif
 
 int dispatch_f16(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s) {

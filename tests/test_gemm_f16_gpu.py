@@ -238,8 +238,9 @@ def test_bounds_on_the_medium_model():
     finally:
         ops.ATTN_SPLIT_OUT = old
         ops.GEMM_HOOK = None
-    # 18 blocks x 4 projections x 3 steps on the fp16 kernels (the trunk's GEMMs carry no bounds and stay on bf16 x 6 / fp32)
-    assert sum(v >= 2000000 for v in seen) >= 18 * 4 * steps - 6 * steps, "the DiT GEMMs did not take the fp16 kernels"
+    # 18 blocks x 4 projections per step, minus the two narrow token projections (128 tiles at 16 samples), on the fp16 kernels
+    # (the trunk's GEMMs carry no bounds and stay on bf16 x 6 / fp32)
+    assert sum(v >= 2000000 for v in seen) >= (18 * 4 - 12 * 2) * steps, "the DiT GEMMs did not take the fp16 kernels"
     bufs = model._engine.ws.bufs
 
     def buf(name, ncols):
