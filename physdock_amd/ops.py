@@ -148,6 +148,8 @@ SPLIT_ATTN = True
 F16_ATTN = True
 #: the same for GEMM launches that carry fp16-split weights and a bound of |A| (W2=, a_amax=)
 F16_GEMM = True
+#: GEMMs with a norm prologue and a static gain / shift derive the bound themselves (sqrt(K) max|w| + max|b|): the trunk
+F16_NORM_BOUND = True
 #: fp16-parts attention launches write their output already split for the projection that follows (pd_attn_args.O2 -> A2)
 ATTN_SPLIT_OUT = True
 

@@ -106,6 +106,17 @@ class PackedWeights:
             self.cache[key] = v
         return v[1]
 
+    def norm_bound(self, w, b, K):
+        """device scalar sqrt(K) max|w| + max|b| (w / b None: 1 / 0): upper bound of a normalised row times a static affine"""
+        key = ("normbound", None if w is None else w.data_ptr(), None if b is None else b.data_ptr(), K)
+
+        def mk():
+            wm = 1.0 if w is None else float(w[:K].abs().max())
+            bm = 0.0 if b is None else float(b[:K].abs().max())
+            dev = (w if w is not None else b).device if (w is not None or b is not None) else next(iter(self.p.values())).device
+            return (w, b, torch.tensor([(math.sqrt(K) * wm + bm) * 1.0001], dtype=torch.float32, device=dev))
+        return self._c(key, mk)[2]
+
     def w2(self, W, K=None):
         """cached two-part fp16 split (+ inverse row scales) of a packed weight matrix, see split2_f16"""
         if not isinstance(W, torch.Tensor) or W.dim() != 2:

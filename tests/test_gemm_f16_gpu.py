@@ -218,8 +218,9 @@ def test_dit_bounds_hold_and_are_not_wild(medium_block_inputs=None):
 
 def test_bounds_on_the_medium_model():
     """the bounds pd_dit_bounds hands the fp16 kernels, against what a real call of the medium model at the benchmark crop
-    produces (last token block and last atom block of the last step): they hold, and they are tight enough for the format's
-    validity domain (bound / largest element <= 2^7, bound / median element <= 2^12)"""
+    produces (last token block and last atom block of the last step): they hold, they are within 2^9 of the largest element,
+    and - the point of it all - the projections that consume the two widest-ranged operands (attention output, SwiGLU hidden)
+    are, on these real operands with these real bounds, at least as close to float64 as the fp32-MFMA kernel"""
     from physdock_amd import PhysDock, PhysDockConfig, ops, param_shapes, seeded_state_dict
     from physdock_amd.synthetic import cfg1_batch
     cfg = PhysDockConfig(model_name="medium")
@@ -258,8 +259,32 @@ def test_bounds_on_the_medium_model():
                            ("h", h, bnd[5])):
             m, med = float(t.abs().max()), float(t.abs().median())
             rows.append((name, m, med, float(b)))
-            assert m <= float(b), (kind, name, m, float(b))
-            assert float(b) <= m * 2 ** 7, (kind, name, m, float(b))
-            assert float(b) <= max(med, 1e-30) * 2 ** 12, (kind, name, med, float(b))
+            assert m <= float(b), (kind, name, m, float(b))                      # the bound holds
+            assert float(b) <= m * 2 ** 9, (kind, name, m, float(b))             # ... and is not wild
         print(f"{kind} DiT last block: " + "; ".join(f"{n}: max {m:.3g} median {md:.3g} bound {b:.3g} (x{b / m:.1f})" for n, m, md, b in rows))
+        # the projections that consume o and h, on the REAL operands and weights with the REAL bounds: error against float64 of
+        # the fp16 kernel vs the fp32-MFMA kernel (rows repeated so that the launch fills the chip)
+        from physdock_amd.packing import split2_f16
+        prefix = f"dit.token_dit.blocks.{blk}" if kind == "token" else f"dit.atom_dit_decoder.blocks.{blk - dt.no_blocks_atom}"
+        sd = model.state_dict()
+        for name, A_, W_, b_ in (("linear_o", o, sd[prefix + ".attention.linear_o.weight"], bnd[2]),
+                                 ("w2", h, sd[prefix + ".transition.feed_forward.w2.weight"], bnd[5])):
+            reps = max(1, (256 * 128 * 128) // (A_.shape[0] * W_.shape[0]) + 1)
+            A_ = A_.repeat(reps, 1)[: (A_.shape[0] * reps) // 128 * 128].contiguous()
+            M_, K_, N_ = A_.shape[0], A_.shape[1], W_.shape[0]
+            ref = A_[:4096].double() @ W_.double().T
+            mag = A_[:4096].double().abs() @ W_.double().abs().T
+            y32, y16 = torch.empty(M_, N_, device="cuda"), torch.empty(M_, N_, device="cuda")
+            ops.gemm(A_, W_.contiguous(), y32, M_, N_, K_)
+            seen2 = []
+            variant(ops, seen2)
+            try:
+                ops.gemm(A_, W_.contiguous(), y16, M_, N_, K_, W2=split2_f16(W_), a_amax=b_.reshape(1).cuda())
+            finally:
+                ops.GEMM_HOOK = None
+            assert seen2[-1] >= 2000000, seen2
+            e32 = float(((y32[:4096].double() - ref).abs() / mag).pow(2).mean().sqrt())
+            e16 = float(((y16[:4096].double() - ref).abs() / mag).pow(2).mean().sqrt())
+            print(f"   {kind} {name} on the model's operands (K={K_}): err / sum|a w| rms  fp32 MFMA {e32:.2e} | f16x3 {e16:.2e}")
+            assert e16 <= 1.1 * e32, (kind, name, e16, e32)
     model.release_workspace()

@@ -32,5 +32,8 @@ for tag, B, H, n in (("atom DiT", 64, 4, 2048), ("token DiT", 64, 16, 256), ("tr
         ops.attention(qkv.data_ptr(), qkv.data_ptr() + 4 * C, qkv.data_ptr() + 8 * C, o, nq=n, nk=n, nbatch=B, nheads=H,
                       q_strides=st, k_strides=st, v_strides=st, o_strides=(n * C, C), bias=bias, f16_amax=amax if mode == "f16" else None)
     res = {m: timeit(lambda: go(m)) for m in ("fp32", "bf16", "f16")}
+    keep, bias = bias, None
+    res["f16 no bias"] = timeit(lambda: go("f16"))
+    bias = keep
     print(f"attn {tag:10s} B={B:3d} H={H:2d} n={n:5d}: " + " | ".join(f"{m} {t * 1e6:8.1f} us {fl / t / 1e12:6.1f} TF" for m, t in res.items()))
 ops.SPLIT_ATTN = True
