@@ -67,11 +67,7 @@ __device__ __forceinline__ int vpos(int k) {
 }
 
 template <int NW, int NP>
-#ifdef PD_ATTN_BIAS_PREFETCH      // lab: without the second launch-bounds argument the 4-waves-per-SIMD budget is enforced (128 VGPRs, 13 spilled)
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2, 4))) void attn_parts_kernel(const pd_attn_args p) {
-#else
 __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2, 4))) void attn_parts_kernel(const pd_attn_args p) {
-#endif
     typedef Parts<NP> PT;
     typedef typename PT::frag frag;
     constexpr int STAGE = NP * (K_PART + V_PART);      // 16-bit elements per stage
@@ -186,28 +182,17 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     gload(0);
     sstore(0);
     __syncthreads();
-#ifdef PD_ATTN_BIAS_PREFETCH
-    f32x4 bf[4];
-    const int nkt_all = (p.nk + 31) >> 5;
-    auto load_bias = [&](int kt32) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bf[g] = *reinterpret_cast<const f32x4*>(bias_wave + (long long)kt32 * 1024 + g * 256);
-    };
-    if (bias_wave) load_bias(0);
-#endif
 
     auto subtile = [&](auto ragged_tag, int cur, int sub, int kt32) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         const unsigned short* sK = lds + cur * STAGE;
         const unsigned short* sV = sK + NP * K_PART;
-#ifndef PD_ATTN_BIAS_PREFETCH
         f32x4 bf[4];
         if (bias_wave) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 bf[g] = *reinterpret_cast<const f32x4*>(bias_wave + (long long)kt32 * 1024 + g * 256);
         }
-#endif
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -273,12 +258,6 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
             }
             o = contract<NP>(vf, pf, o);
         }
-#ifdef PD_ATTN_BIAS_PREFETCH
-        // the second sub-tile's bias tile is requested here, where the score registers have just died (no extra pressure): its
-        // L2 latency passes under the P.V products in flight and the next sub-tile's K.Q^T instead of in front of its first use
-        // (the first sub-tile of the next tile gets its request after the staging stores, see the main loop)
-        if (sub == 0 && bias_wave) load_bias(kt32 + 1 < nkt_all ? kt32 + 1 : kt32);
-#endif
         l_run = l_run * alpha + psum;
     };
     const int nfull32 = p.nk >> 5;
@@ -295,9 +274,6 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
             }
         }
         if (it + 1 < nit) sstore(cur ^ 1);
-#ifdef PD_ATTN_BIAS_PREFETCH
-        if (bias_wave && it + 1 < nit) load_bias(2 * (it + 1));
-#endif
         __syncthreads();
     }
 
