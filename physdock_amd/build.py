@@ -64,8 +64,6 @@ def compile_cmd(src, out, mode=("-c",)):
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_KSPLIT_MAX_BYTES") and base == "gemm_stream.hip":
         cmd[1:1] = ["-DPD_KSPLIT_MAX_BYTES=" + os.environ["PD_KSPLIT_MAX_BYTES"]]
-    if os.environ.get("PD_ATTN_BIAS_PREFETCH") and base == "attn_f16.hip":
-        cmd[1:1] = ["-DPD_ATTN_BIAS_PREFETCH=1"]
     for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES"):
         if os.environ.get(knob) and base == "gemm_f16.hip":
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
