@@ -199,8 +199,10 @@ class LaunchTimer:
                         3 if a.A3 else pro, epi,
                         (("128, 128, 4, 8, false" if glu_tile else "128, 128, 2, 8, true"), "64, 64, 2, 4, true", "128, 64, 4, 4, true")[tcode])
                 elif nprod == 3:  # 2 x fp16 split-operand variant (csrc/gemm_f16.hip)
-                    name = "gemm_f16_kernel<%d, %d, FTile<%s> >" % (3 if a.A2 else pro, epi,
-                                                                   "128, 128, 4, 8, false" if glu_tile else "128, 128, 2, 8, true")
+                    # (the GLU tile takes direct-W loads - last argument true - when A arrives pre-split)
+                    name = "gemm_f16_kernel<%d, %d, FTile<%s> >" % (
+                        3 if a.A2 else pro, epi,
+                        ("128, 128, 4, 8, true" if a.A2 else "128, 128, 4, 8, false") if glu_tile else "128, 128, 2, 8, true")
             nb = max(a.batch, 1)
             n_out = a.N // 2 if a.glu else a.N
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))

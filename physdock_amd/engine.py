@@ -485,8 +485,7 @@ class Engine:
         b_o, b_y, b_y2, b_h = (bnd + 8, bnd + 12, bnd + 16, bnd + 20) if f16 else (None,) * 4
         # wide rows (token DiT, C = 512) in chip-filling launches: AdaLN-normalise and split the activations ONCE
         # (pd_norm_split / pd_norm_split2) instead of in every column block of the projection that consumes them (12 / 22 of them)
-        # (with two fp16 parts the pre-split operand is 4 bytes per element - what the statistics pass reads anyway - so narrow
-        #  atom rows, C = 128, take this path too: SwiGLU 136 + 25 us against 166 + 14 us with the in-kernel prologue)
+        # (narrow atom rows, C = 128, keep the in-kernel prologue: ops.PRESPLIT_MIN_C_F16)
         presplit = ops.SPLIT_GEMM and ops.PRESPLIT_GEMM and C >= (ops.PRESPLIT_MIN_C_F16 if f16 else 256) and C % 32 == 0 \
             and ops.presplit_supported(rows, 3 * C, C, hn=True, f16=f16) and ops.presplit_supported(rows, 2 * hidden, C, glu=1, f16=f16)
         a3 = a2 = None

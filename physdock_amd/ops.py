@@ -136,7 +136,8 @@ SPLIT_GEMM = True
 #: normalise + split the activations of wide-row projections once (pd_norm_split -> pd_gemm_args.A3) instead of in the GEMM's staging
 PRESPLIT_GEMM = True
 PRESPLIT_QKV = True       # also for q|k|v (12 column blocks): +0.4 % on top of the SwiGLU projection's +1.0 %
-PRESPLIT_MIN_C_F16 = 128  # narrowest rows that take the pre-split path when the operand format is two fp16 parts
+PRESPLIT_MIN_C_F16 = 256  # narrowest rows that take the pre-split path when the operand format is two fp16 parts (atom rows,
+                          # C = 128: the split pass costs 43 us per launch against 16 us of statistics - measured -0.8 % end to end)
 
 #: K-split of launches that cannot fill the chip (few samples) when the caller hands pd_gemm a scratch buffer
 KSPLIT_GEMM = True
