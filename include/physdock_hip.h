@@ -124,6 +124,25 @@ int pd_norm_split(const float* x, int ldx, int M, int C, int mode, float eps, co
 int pd_norm_split2(const float* x, int ldx, int M, int C, int mode, float eps, const float* w, const float* b,
                    int rows_per_group, int gstride, const float* a_amax, void* out2, void* stream);
 
+/* ---- pd_transition_f16 (ABI 5): the atom-level DiT transition in one launch --------------------------------------------------
+ * x[m,:] += gate[g] * W2 . ( silu(W1 y) * (W3 y) ),  y = scale1p[g] * LayerNorm(x[m,:]) + shift[g],  g = m / rows_per_group
+ * (transitions.py:27-30 with adaptive_layer_norm_zero.py:16-21 and feed_forward.py:30-31): row statistics, SwiGLU projection
+ * and down-projection of 128 whole rows per block, the hidden activations stay in LDS.  C = 128 and hidden = 384 only, M % 128
+ * == 0 and M / 128 >= 256 (PD_ERR_UNSUPPORTED otherwise: run pd_rowstats + two pd_gemm).  W13 / W2 are the two-part fp16
+ * fragment-major forms of the packed [a(32) | b(32)] SwiGLU weights [2 hidden][C] and of W2 [C][hidden] with their inverse row
+ * scales (packing.split2_f16); y_amax / h_amax are device scalars bounding |y| and |silu(a) b| (pd_dit_bounds).
+ * args == NULL: one-time set-up (dynamic LDS limit), called by pd_init.                                                        */
+typedef struct pd_transition_args {
+    float* x;                    /* [M][C], updated in place */
+    int M, C, hidden;
+    const float* shift; const float* scale1p; const float* gate;      /* [C] each (+ g * gstride)                      */
+    int rows_per_group, gstride; /* 0: one row of shift / scale / gate for all rows                                        */
+    float eps;
+    const void* W13; const float* w13_inv; const void* W2; const float* w2_inv;
+    const float* y_amax; const float* h_amax;
+} pd_transition_args;
+int pd_transition_f16(const pd_transition_args* args, void* stream);
+
 /* ---- pd_pair_bias: attention pair bias in one streaming pass (pairbias.hip) -------------------
  * frag = fragment layout of [ (norm(x) . Wf^T + c2 + maskadd ? 0 : maskval) * out_scale ] for x [T1*T2, C] (C = 16 or 128),
  * Wf [H][C] = projection weights with the norm gain folded in (Wf[h][k] = w[k] W[h][k]), c2 [H] = projection of the norm

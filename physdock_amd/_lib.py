@@ -74,6 +74,13 @@ class AttnArgs(C.Structure):
     ]
 
 
+class TransitionArgs(C.Structure):
+    """mirror of pd_transition_args"""
+    _fields_ = [("x", _fp), ("M", C.c_int), ("C", C.c_int), ("hidden", C.c_int),
+                ("shift", _fp), ("scale1p", _fp), ("gate", _fp), ("rows_per_group", C.c_int), ("gstride", C.c_int),
+                ("eps", C.c_float), ("W13", _fp), ("w13_inv", _fp), ("W2", _fp), ("w2_inv", _fp), ("y_amax", _fp), ("h_amax", _fp)]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -159,6 +166,7 @@ def _declare(L):
     sig("pd_timestep_embed", p, p, i, p)
     sig("pd_dit_bounds", p, i, i, i, i, p, p, p)
     sig("pd_norm_split2", p, i, i, i, i, f, p, p, i, i, p, p, p)
+    sig("pd_transition_f16", C.POINTER(TransitionArgs), p)
     sig("pd_mmff_energy_grad", p, p, p, p, i, p)
     sig("pd_mmff_relax", p, p, p, p, p, ll, i, i, i, p)
     sig("pd_chirality", p, p, p, p, p, i, i, i, p)

@@ -1,0 +1,221 @@
+// Atom-level DiT transition in ONE kernel (reference primitives/transitions.py:27-30 = AdaLN-Zero + SwiGLU feed-forward + gate +
+// residual; C = 128 channels, hidden = 384):      x += gate * W2 . ( silu(W1 y) * (W3 y) ),   y = (1 + scale) LayerNorm(x) + shift.
+//
+// As three launches (row statistics, SwiGLU up-projection, down-projection) this step moves the hidden tensor through HBM
+// twice - 201 MB out and 201 MB back in at 64 samples - around two K = 128 / K = 384 GEMMs whose tiles are prologue / epilogue
+// bound (MfmaUtil 0.2).  Here a block owns 128 whole rows: it normalises them itself (a row is 128 values: four threads), keeps
+// the two-part fp16 operand in LDS for the whole tile, and walks the hidden dimension in three chunks of 128: GLU chunk ->
+// split -> LDS -> accumulated into the 128 x 128 output tile.  The hidden activations never leave the CU; HBM sees x in, x out.
+// Operand format, scales and accuracy: gemm_f16.hip (two fp16 parts, three products; bounds from pd_dit_bounds).
+// One block per CU (139 KB of LDS: the A tile and one hidden chunk, both as two fp16 parts with 272-byte rows = conflict-free
+// ds_read_b128 fragments), eight waves with up to 256 VGPRs: the weights come straight from global memory in fragment-major
+// order (packing.split2_f16), one 16-k step ahead.
+#include "gemm_tile_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int C_ = 128;                 // channels = K of the up-projection = N of the down-projection
+constexpr int BM = 128;                 // rows per block tile
+constexpr int CH = 128;                 // hidden columns per chunk
+constexpr int LP = 136;                 // LDS row pitch in fp16 (272 bytes: 17 x 16)
+constexpr int PART = BM * LP;           // fp16 elements per part of a tile
+constexpr int LDS_BYTES = 2 * 2 * PART * 2;      // (A tile + hidden chunk) x 2 parts
+
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int NCH>                      // hidden = 128 * NCH
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void transition_f16_kernel(const pd_transition_args p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    _Float16* sA = lds;                          // [2][128][LP]   y, scaled and split
+    _Float16* sH = lds + 2 * PART;               // [2][128][LP]   hidden chunk, scaled and split
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const f16x8* __restrict__ W13 = reinterpret_cast<const f16x8*>(p.W13);
+    const f16x8* __restrict__ W2 = reinterpret_cast<const f16x8*>(p.W2);
+    constexpr int NKS1 = C_ / 16;                // 16-k steps of the up-projection (8)
+    constexpr int NKS2 = CH * NCH / 16;          // ... of the down-projection (24)
+    const long long w13part = (long long)(2 * CH * NCH / 32) * NKS1 * 64;     // 16-byte units per part
+    const long long w2part = (long long)(C_ / 32) * NKS2 * 64;
+    const float y_s = pd_pow2_scale(*p.y_amax), h_s = pd_pow2_scale(*p.h_amax);
+    const float inv_y_s = 1.0f / y_s, inv_h_s = 1.0f / h_s;
+    // up-projection: 4 x 2 waves, 32 rows x 128 packed columns (two GLU pairs = 64 hidden) each
+    const int wm1 = wave >> 1, wn1 = wave & 1;
+    // down-projection: 2 x 4 waves, 64 rows x 32 output columns each
+    const int wm2 = wave >> 2, wn2 = wave & 3;
+    const int ntiles = p.M / BM;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = (long long)tile * BM;
+        // ---- phase 0: LayerNorm + AdaLN + scale + split of the tile's 128 rows into LDS (four threads per row)
+        {
+            const int r = tid >> 2, q = tid & 3;
+            const float* xr = p.x + (row0 + r) * C_;
+            f32x4 v[8];
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (q + 4 * i));
+                s1 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+            s1 += __shfl_xor(s1, 1);
+            s1 += __shfl_xor(s1, 2);
+            const float mean = s1 * (1.0f / C_);
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+            sq += __shfl_xor(sq, 1);
+            sq += __shfl_xor(sq, 2);
+            const float rstd = rsqrtf(sq * (1.0f / C_) + p.eps) * y_s;      // the operand scale rides on rstd ...
+            const long long goff = p.rows_per_group > 0 ? ((row0 + r) / p.rows_per_group) * (long long)p.gstride : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 4 * (q + 4 * i);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(p.scale1p + goff + c);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.shift + goff + c);
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (v[i][e] - mean) * rstd * w[e] + b[e] * y_s;      // ... and on the shift
+                const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]);
+                *reinterpret_cast<u32x2*>(sA + r * LP + c) = u32x2{p0.h, p1.h};
+                *reinterpret_cast<u32x2*>(sA + PART + r * LP + c) = u32x2{p0.l, p1.l};
+            }
+        }
+        block_barrier();
+
+        f32x16 acc2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            // ---- phase 1: packed GLU columns [256 c + 128 wn1, +128) of W13 against the A tile
+            f32x16 acc1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+            const int nb = 2 * CH * c + 128 * wn1;                 // first packed column of this wave
+            f16x8 wf[2][4][2];
+            auto wload = [&](int buf, int ks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f16x8* base = W13 + ((long long)((nb + 32 * j) >> 5) * NKS1 + ks) * 64 + lane;
+                    wf[buf][j][0] = base[0];
+                    wf[buf][j][1] = base[w13part];
+                }
+            };
+            wload(0, 0);
+            const _Float16* abase = sA + (32 * wm1 + l31) * LP + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < NKS1; ++ks) {
+                if (ks + 1 < NKS1) wload((ks + 1) & 1, ks + 1);
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 16 * ks);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x16 t = acc1[j];
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks & 1][j][1], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[ks & 1][j][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks & 1][j][0], t, 0, 0, 0);
+                    acc1[j] = t;
+                }
+            }
+            // GLU in registers, then scale + split into the hidden chunk tile: lane = hidden column, register = row; a register
+            // pair (two adjacent rows) shares one split, its halves go to the two rows
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const float ca = p.w13_inv[nb + 64 * pr + l31] * inv_y_s, cb = p.w13_inv[nb + 64 * pr + 32 + l31] * inv_y_s;
+                const int hid = 64 * wn1 + 32 * pr + l31;          // column inside the chunk
+                unsigned short* hs = reinterpret_cast<unsigned short*>(sH) + (32 * wm1 + 4 * hh) * LP + hid;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float h0 = pd_silu(acc1[2 * pr][r] * ca) * (acc1[2 * pr + 1][r] * cb) * h_s;
+                    const float h1 = pd_silu(acc1[2 * pr][r + 1] * ca) * (acc1[2 * pr + 1][r + 1] * cb) * h_s;
+                    const pd_parts2 s2 = pd_split2h(h0, h1);
+                    const int ro = ((r & 3) + 8 * (r >> 2)) * LP;          // row of register r (the lane half's 4 hh is in hs)
+                    hs[ro] = (unsigned short)s2.h;
+                    hs[ro + LP] = (unsigned short)(s2.h >> 16);
+                    hs[PART + ro] = (unsigned short)s2.l;
+                    hs[PART + ro + LP] = (unsigned short)(s2.l >> 16);
+                }
+            }
+            block_barrier();
+            // ---- phase 2: output tile += hidden chunk . W2[:, 128 c .. +128]^T
+            {
+                f16x8 vf[2][2];
+                auto vload = [&](int buf, int ks) {
+                    const f16x8* base = W2 + ((long long)wn2 * NKS2 + (CH / 16) * c + ks) * 64 + lane;
+                    vf[buf][0] = base[0];
+                    vf[buf][1] = base[w2part];
+                };
+                vload(0, 0);
+                const _Float16* hbase = sH + (64 * wm2 + l31) * LP + 8 * hh;
+#pragma unroll
+                for (int ks = 0; ks < CH / 16; ++ks) {
+                    if (ks + 1 < CH / 16) vload((ks + 1) & 1, ks + 1);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f16x8 a0 = *reinterpret_cast<const f16x8*>(hbase + 32 * i * LP + 16 * ks);
+                        const f16x8 a1 = *reinterpret_cast<const f16x8*>(hbase + PART + 32 * i * LP + 16 * ks);
+                        f32x16 t = acc2[i];
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, vf[ks & 1][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vf[ks & 1][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, vf[ks & 1][0], t, 0, 0, 0);
+                        acc2[i] = t;
+                    }
+                }
+            }
+            block_barrier();                          // the chunk tile is free for the next chunk (and sA for the next tile)
+        }
+        // ---- epilogue: x = x + gate * (acc / scales)
+        {
+            const int n = 32 * wn2 + l31;
+            const float cs = p.w2_inv[n] * inv_h_s;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const long long rb = row0 + 64 * wm2 + 32 * i + 4 * hh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = rb + (r & 3) + 8 * (r >> 2);
+                    const long long goff = p.rows_per_group > 0 ? (row / p.rows_per_group) * (long long)p.gstride : 0;
+                    float* xp = p.x + row * C_ + n;
+                    *xp = *xp + acc2[i][r] * cs * p.gate[goff + n];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// x [M][128] updated in place; see include/physdock_hip.h pd_transition_args.  PD_ERR_UNSUPPORTED for other shapes (the caller
+// then runs the three-launch form).  init: M <= 0 with args == nullptr raises the dynamic-LDS limit.
+PD_EXPORT int pd_transition_f16(const pd_transition_args* a, void* stream) {
+    auto k = transition_f16_kernel<3>;
+    if (!a) {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    }
+    if (!a->x || !a->shift || !a->scale1p || !a->gate || !a->W13 || !a->w13_inv || !a->W2 || !a->w2_inv || !a->y_amax || !a->h_amax)
+        return PD_ERR_ARG;
+    if (a->C != C_ || a->hidden != 3 * CH || a->M <= 0 || a->M % BM != 0) return PD_ERR_UNSUPPORTED;
+    if (a->M / BM < 256) return PD_ERR_UNSUPPORTED;                     // fewer tiles than CUs: the three-launch form fills the chip better
+    if (a->rows_per_group > 0 && a->gstride % 4 != 0) return PD_ERR_UNSUPPORTED;
+    if (((uintptr_t)a->x | (uintptr_t)a->shift | (uintptr_t)a->scale1p | (uintptr_t)a->W13 | (uintptr_t)a->W2) & 15) return PD_ERR_UNSUPPORTED;
+    const int ntiles = a->M / BM;
+    hipLaunchKernelGGL(k, dim3(ntiles < 256 ? ntiles : 256), dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
+    return pd_check_launch();
+}

@@ -527,14 +527,19 @@ class Engine:
             o = self.lws("dit_o", rows, C)
             ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, **akw)
             self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, a_amax=b_o, **mgrp)
-        h = self.lws("dit_h", rows, hidden)
         t2 = tab_off + 3 * C
+        W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
+        if f16 and ops.FUSED_TRANSITION and not presplit and W13.shape[1] == C and ldw == hidden \
+                and ops.transition_f16(x, rows, C, hidden, shift=off(tab, t2), scale1p=off(tab, t2 + C), gate=off(tab, t2 + 2 * C),
+                                       W13=P.w2(W13, C), W2=P.w2(W2, hidden), y_amax=b_y2, h_amax=b_h, eps=eps,
+                                       rows_per_group=N if per_sample else 0, gstride=tab_ld if per_sample else 0):
+            return                       # atom rows: statistics + SwiGLU + down-projection + gate + residual in one launch
+        h = self.lws("dit_h", rows, hidden)
         if presplit:
             self.gemm(x, W13, h, rows, 2 * hidden, C, glu=1, a_amax=b_y2, **norm_split(t2, b_y2))
         else:
             st = self.stats(x, rows, C, LN, eps)
             self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, t2), pro_w=off(tab, t2 + C), glu=1, a_amax=b_y2, **grp)
-        W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
         self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, t2 + 2 * C), res=x, a_amax=b_h, **mgrp)
 
     def af3_dit(self, batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=False):

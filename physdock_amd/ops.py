@@ -151,6 +151,9 @@ F16_ATTN = True
 F16_GEMM = True
 #: GEMMs with a norm prologue and a static gain / shift derive the bound themselves (sqrt(K) max|w| + max|b|): the trunk
 F16_NORM_BOUND = True
+#: the atom-level DiT transition (C = 128, hidden = 384) as one kernel with the hidden activations in LDS
+FUSED_TRANSITION = True
+TRANSITION_HOOK = None
 #: fp16-parts attention launches write their output already split for the projection that follows (pd_attn_args.O2 -> A2)
 ATTN_SPLIT_OUT = True
 
@@ -180,6 +183,27 @@ def norm_split2(x, out2, M, Cdim, a_amax, *, ldx=None, mode=RMS, eps=1e-8, w=Non
         return t if (t is None or isinstance(t, int)) else ptr(t)
     check(_lib.init().pd_norm_split2(P(x), ldx if ldx is not None else Cdim, M, Cdim, mode, eps, P(w), P(b), rows_per_group, gstride,
                                      P(a_amax), ptr(out2), stream()), "pd_norm_split2")
+
+
+def transition_f16(x, M, Cdim, hidden, *, shift, scale1p, gate, W13, W2, y_amax, h_amax, eps, rows_per_group=0, gstride=0):
+    """fused atom-level DiT transition (pd_transition_f16); returns False when the library does not cover the shape.
+    shift / scale1p / gate / y_amax / h_amax: device addresses or tensors; W13 / W2: (parts, w_inv) of packing.split2_f16"""
+    def P(t):
+        return t if (t is None or isinstance(t, int)) else ptr(t)
+    a = _lib.TransitionArgs()
+    a.x, a.M, a.C, a.hidden = ptr(x), M, Cdim, hidden
+    a.shift, a.scale1p, a.gate = P(shift), P(scale1p), P(gate)
+    a.rows_per_group, a.gstride, a.eps = rows_per_group, gstride, eps
+    a.W13, a.w13_inv, a.W2, a.w2_inv = W13[0].data_ptr(), W13[1].data_ptr(), W2[0].data_ptr(), W2[1].data_ptr()
+    a.y_amax, a.h_amax = P(y_amax), P(h_amax)
+    def launch():
+        rc = _lib.init().pd_transition_f16(C.byref(a), stream())
+        if rc != -3:
+            check(rc, "pd_transition_f16")
+        return rc != -3
+    if TRANSITION_HOOK is not None:          # profiling hook (bench.py): brackets the launch
+        return TRANSITION_HOOK(a, launch)
+    return launch()
 
 
 def rownorm(x, y, M, Cdim, *, res=None, w=None, b=None, mode=RMS, eps=1e-8, act=ACT_NONE):

@@ -288,3 +288,54 @@ def test_bounds_on_the_medium_model():
             print(f"   {kind} {name} on the model's operands (K={K_}): err / sum|a w| rms  fp32 MFMA {e32:.2e} | f16x3 {e16:.2e}")
             assert e16 <= 1.1 * e32, (kind, name, e16, e32)
     model.release_workspace()
+
+
+@pytest.mark.parametrize("per_sample", [False, True])
+def test_fused_atom_transition_vs_three_launches_and_float64(per_sample):
+    """pd_transition_f16 (row statistics + SwiGLU + down-projection + gate + residual in one kernel, hidden activations in LDS)
+    against the same step as pd_rowstats + two pd_gemm on the fp32-MFMA kernels, and both against float64"""
+    from physdock_amd import ops
+    from physdock_amd.packing import pack_glu, split2_f16
+    B, N_, Cd, hidden = 32, 1024, 128, 384
+    rows = B * N_
+    x0 = (torch.randn(rows, Cd, generator=g(1)) * 2 + 0.3)
+    ngrp = B if per_sample else 1
+    tab = (0.4 * torch.randn(ngrp, 3 * Cd, generator=g(2)))
+    tab[:, Cd:2 * Cd] += 1.0                                                         # (shift | 1 + scale | gate)
+    W1 = torch.randn(hidden, Cd, generator=g(3)) / math.sqrt(Cd); W3 = torch.randn(hidden, Cd, generator=g(4)) / math.sqrt(Cd)
+    W2 = torch.randn(Cd, hidden, generator=g(5)) / math.sqrt(hidden)
+    W13 = pack_glu(W1, W3)[0].cuda()
+    tabd, W2d = tab.cuda(), W2.cuda().contiguous()
+    # float64 reference
+    grp = torch.arange(rows) // N_ if per_sample else torch.zeros(rows, dtype=torch.long)
+    xd = x0.double()
+    y = torch.nn.functional.layer_norm(xd, (Cd,), eps=1e-5) * tab[grp, Cd:2 * Cd].double() + tab[grp, :Cd].double()
+    hcpu = torch.nn.functional.silu(y @ W1.double().T) * (y @ W3.double().T)
+    ref = xd + tab[grp, 2 * Cd:].double() * (hcpu @ W2.double().T)
+    ymax = torch.tensor([float(y.abs().max()) * 3], device="cuda")                   # bounds with some slack, as in the model
+    hmax = torch.tensor([float(hcpu.abs().max()) * 40], device="cuda")
+    # three launches on the fp32-MFMA kernels
+    x3 = x0.cuda().clone()
+    st = torch.empty(rows, 2, device="cuda")
+    ops.rowstats(x3, st, rows, Cd, mode=ops.LN, eps=1e-5)
+    h = torch.empty(rows, hidden, device="cuda")
+    pg = dict(pro_rows_per_group=N_, pro_gstride=3 * Cd) if per_sample else {}
+    ops.gemm(x3, W13, h, rows, 2 * hidden, Cd, glu=1, stats=st, pro_b=tabd, pro_w=tabd.data_ptr() + 4 * Cd, **pg)
+    ops.gemm(h, W2d, x3, rows, Cd, hidden, mul=tabd.data_ptr() + 8 * Cd, res=x3, mul_rows_per_group=N_ if per_sample else rows,
+             mul_gstride=3 * Cd if per_sample else 0)
+    # one launch
+    x1 = x0.cuda().clone()
+    ok = ops.transition_f16(x1, rows, Cd, hidden, shift=tabd, scale1p=tabd.data_ptr() + 4 * Cd, gate=tabd.data_ptr() + 8 * Cd,
+                            W13=split2_f16(W13), W2=split2_f16(W2d), y_amax=ymax, h_amax=hmax, eps=1e-5,
+                            rows_per_group=N_ if per_sample else 0, gstride=3 * Cd if per_sample else 0)
+    assert ok
+    assert torch.isfinite(x1).all()
+    d = ref - xd                                         # the update itself (the residual dominates x)
+    e3 = float(((x3.double().cpu() - ref).abs()).pow(2).mean().sqrt() / d.abs().mean())
+    e1 = float(((x1.double().cpu() - ref).abs()).pow(2).mean().sqrt() / d.abs().mean())
+    print(f"transition per_sample={per_sample}: rms error / mean|update|  three launches (fp32 MFMA) {e3:.2e} | fused fp16-parts {e1:.2e}")
+    torch.testing.assert_close(x1, x3, atol=3e-5, rtol=2e-5)
+    assert e1 <= 1.2 * e3 + 1e-9
+    # shapes the kernel does not cover are declined, not mangled
+    assert ops.transition_f16(x1, 128 * 100, Cd, hidden, shift=tabd, scale1p=tabd, gate=tabd, W13=split2_f16(W13), W2=split2_f16(W2d),
+                              y_amax=ymax, h_amax=hmax, eps=1e-5) is False
