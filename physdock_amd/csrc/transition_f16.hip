@@ -39,16 +39,27 @@ void transition_f16_kernel(const pd_transition_args p) {
     _Float16* sH = lds + 2 * PART;               // [2][128][LP]   hidden chunk, scaled and split
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const f16x8* __restrict__ W13 = reinterpret_cast<const f16x8*>(p.W13);
-    const f16x8* __restrict__ W2 = reinterpret_cast<const f16x8*>(p.W2);
     constexpr int NKS1 = C_ / 16;                // 16-k steps of the up-projection (8)
     constexpr int NKS2 = CH * NCH / 16;          // ... of the down-projection (24)
-    const long long w13part = (long long)(2 * CH * NCH / 32) * NKS1 * 64;     // 16-byte units per part
-    const long long w2part = (long long)(C_ / 32) * NKS2 * 64;
+    constexpr int W13PART = (2 * CH * NCH / 32) * NKS1 * 1024;       // bytes per part (1 KB fragment blocks)
+    constexpr int W2PART = (C_ / 32) * NKS2 * 1024;
+    constexpr int PF = 3;                        // weight fragments are requested PF 16-k steps ahead (L2 latency >> one step's MFMAs)
+    // Weight fragments through buffer loads: descriptor in SGPRs, ONE shared VGPR offset (lane * 16), the fragment block as a
+    // scalar offset (with flat 64-bit per-lane addresses hipcc hoists ~30 of them out of the chunk loop and spills them).
+    const auto rs13 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W13), 0, 2 * W13PART, 0x00020000);
+    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W2), 0, 2 * W2PART, 0x00020000);
+    const int loff = lane * 16;
+    auto wfrag13 = [&](int block, int part) {
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs13, loff, block * 1024 + part * W13PART, 0));
+    };
+    auto wfrag2 = [&](int block, int part) {
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs2, loff, block * 1024 + part * W2PART, 0));
+    };
     const float y_s = pd_pow2_scale(*p.y_amax), h_s = pd_pow2_scale(*p.h_amax);
     const float inv_y_s = 1.0f / y_s, inv_h_s = 1.0f / h_s;
-    // up-projection: 4 x 2 waves, 32 rows x 128 packed columns (two GLU pairs = 64 hidden) each
-    const int wm1 = wave >> 1, wn1 = wave & 1;
+    // up-projection: 2 x 4 waves, 64 rows x 64 packed columns (one GLU pair = 32 hidden) each: a weight fragment feeds two row
+    // fragments (half the weight loads per MFMA of the 32 x 128 layout)
+    const int wm1 = wave >> 2, wn1 = wave & 3;
     // down-projection: 2 x 4 waves, 64 rows x 32 output columns each
     const int wm2 = wave >> 2, wn2 = wave & 3;
     const int ntiles = p.M / BM;
@@ -101,79 +112,88 @@ void transition_f16_kernel(const pd_transition_args p) {
 
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
-            // ---- phase 1: packed GLU columns [256 c + 128 wn1, +128) of W13 against the A tile
-            f32x16 acc1[4];
+            // ---- phase 1: packed GLU columns [256 c + 64 wn1, +64) of W13 against rows [64 wm1, +64) of the A tile
+            f32x16 acc1[2][2];                                     // [row fragment][a | b]
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
-            const int nb = 2 * CH * c + 128 * wn1;                 // first packed column of this wave
-            f16x8 wf[2][4][2];
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+            const int nb = 2 * CH * c + 64 * wn1;                  // first packed column of this wave
+            f16x8 wf[PF + 1][2][2];
             auto wload = [&](int buf, int ks) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f16x8* base = W13 + ((long long)((nb + 32 * j) >> 5) * NKS1 + ks) * 64 + lane;
-                    wf[buf][j][0] = base[0];
-                    wf[buf][j][1] = base[w13part];
+                for (int j = 0; j < 2; ++j) {
+                    const int block = ((nb + 32 * j) >> 5) * NKS1 + ks;
+                    wf[buf][j][0] = wfrag13(block, 0);
+                    wf[buf][j][1] = wfrag13(block, 1);
                 }
             };
-            wload(0, 0);
-            const _Float16* abase = sA + (32 * wm1 + l31) * LP + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < PF; ++ks) wload(ks, ks);
+            const _Float16* abase = sA + (64 * wm1 + l31) * LP + 8 * hh;
 #pragma unroll
             for (int ks = 0; ks < NKS1; ++ks) {
-                if (ks + 1 < NKS1) wload((ks + 1) & 1, ks + 1);
-                const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 16 * ks);
-                const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART + 16 * ks);
+                if (ks + PF < NKS1) wload((ks + PF) % (PF + 1), ks + PF);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x16 t = acc1[j];
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks & 1][j][1], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[ks & 1][j][0], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks & 1][j][0], t, 0, 0, 0);
-                    acc1[j] = t;
+                for (int i = 0; i < 2; ++i) {
+                    const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 32 * i * LP + 16 * ks);
+                    const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART + 32 * i * LP + 16 * ks);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x16 t = acc1[i][j];
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][j][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[ks % (PF + 1)][j][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][j][0], t, 0, 0, 0);
+                        acc1[i][j] = t;
+                    }
                 }
             }
             // GLU in registers, then scale + split into the hidden chunk tile: lane = hidden column, register = row; a register
             // pair (two adjacent rows) shares one split, its halves go to the two rows
+            {
+                const float ca = p.w13_inv[nb + l31] * inv_y_s, cb = p.w13_inv[nb + 32 + l31] * inv_y_s;
+                const int hid = 32 * wn1 + l31;                    // column inside the chunk
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const float ca = p.w13_inv[nb + 64 * pr + l31] * inv_y_s, cb = p.w13_inv[nb + 64 * pr + 32 + l31] * inv_y_s;
-                const int hid = 64 * wn1 + 32 * pr + l31;          // column inside the chunk
-                unsigned short* hs = reinterpret_cast<unsigned short*>(sH) + (32 * wm1 + 4 * hh) * LP + hid;
+                for (int i = 0; i < 2; ++i) {
+                    unsigned short* hs = reinterpret_cast<unsigned short*>(sH) + (64 * wm1 + 32 * i + 4 * hh) * LP + hid;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float h0 = pd_silu(acc1[2 * pr][r] * ca) * (acc1[2 * pr + 1][r] * cb) * h_s;
-                    const float h1 = pd_silu(acc1[2 * pr][r + 1] * ca) * (acc1[2 * pr + 1][r + 1] * cb) * h_s;
-                    const pd_parts2 s2 = pd_split2h(h0, h1);
-                    const int ro = ((r & 3) + 8 * (r >> 2)) * LP;          // row of register r (the lane half's 4 hh is in hs)
-                    hs[ro] = (unsigned short)s2.h;
-                    hs[ro + LP] = (unsigned short)(s2.h >> 16);
-                    hs[PART + ro] = (unsigned short)s2.l;
-                    hs[PART + ro + LP] = (unsigned short)(s2.l >> 16);
+                    for (int r = 0; r < 16; r += 2) {
+                        const float h0 = pd_silu(acc1[i][0][r] * ca) * (acc1[i][1][r] * cb) * h_s;
+                        const float h1 = pd_silu(acc1[i][0][r + 1] * ca) * (acc1[i][1][r + 1] * cb) * h_s;
+                        const pd_parts2 s2 = pd_split2h(h0, h1);
+                        const int ro = ((r & 3) + 8 * (r >> 2)) * LP;      // row of register r (the lane half's 4 hh is in hs)
+                        hs[ro] = (unsigned short)s2.h;
+                        hs[ro + LP] = (unsigned short)(s2.h >> 16);
+                        hs[PART + ro] = (unsigned short)s2.l;
+                        hs[PART + ro + LP] = (unsigned short)(s2.l >> 16);
+                    }
                 }
             }
             block_barrier();
             // ---- phase 2: output tile += hidden chunk . W2[:, 128 c .. +128]^T
             {
-                f16x8 vf[2][2];
+                f16x8 vf[PF + 1][2];
                 auto vload = [&](int buf, int ks) {
-                    const f16x8* base = W2 + ((long long)wn2 * NKS2 + (CH / 16) * c + ks) * 64 + lane;
-                    vf[buf][0] = base[0];
-                    vf[buf][1] = base[w2part];
+                    const int block = wn2 * NKS2 + (CH / 16) * c + ks;
+                    vf[buf][0] = wfrag2(block, 0);
+                    vf[buf][1] = wfrag2(block, 1);
                 };
-                vload(0, 0);
+#pragma unroll
+                for (int ks = 0; ks < PF; ++ks) vload(ks, ks);
                 const _Float16* hbase = sH + (64 * wm2 + l31) * LP + 8 * hh;
 #pragma unroll
                 for (int ks = 0; ks < CH / 16; ++ks) {
-                    if (ks + 1 < CH / 16) vload((ks + 1) & 1, ks + 1);
+                    if (ks + PF < CH / 16) vload((ks + PF) % (PF + 1), ks + PF);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const f16x8 a0 = *reinterpret_cast<const f16x8*>(hbase + 32 * i * LP + 16 * ks);
                         const f16x8 a1 = *reinterpret_cast<const f16x8*>(hbase + PART + 32 * i * LP + 16 * ks);
                         f32x16 t = acc2[i];
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, vf[ks & 1][1], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vf[ks & 1][0], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, vf[ks & 1][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, vf[ks % (PF + 1)][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, vf[ks % (PF + 1)][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, vf[ks % (PF + 1)][0], t, 0, 0, 0);
                         acc2[i] = t;
                     }
                 }
