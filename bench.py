@@ -347,9 +347,11 @@ def main():
         "value": value, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "arithmetic": "fp32 results; the dense contractions of chip-filling launches run as six bf16 MFMAs per block on 3-way "
-                      "error-free split operands with fp32 accumulation (at least fp32-MFMA accuracy, measured), everything "
-                      "else on the fp32 MFMA / fp32 VALU; MMFF94 relaxation in fp64",
+        "arithmetic": "fp32 results; chip-filling contractions run on split operands with fp32 accumulation: where a rigorous "
+                      "bound of |A| is known before the launch (the DiT blocks: LayerNorm + AdaLN table, pd_dit_bounds) as two "
+                      "fp16 parts of the power-of-two scaled value / three MFMAs per block (22 significand bits), elsewhere as "
+                      "three bf16 parts / six MFMAs (error free); both measured at least as accurate as the fp32 MFMA against "
+                      "float64; everything else on the fp32 MFMA / fp32 VALU; MMFF94 relaxation in fp64",
         "config": {"workload": f"{args.cfg}: one sample_diffusion call = conditioning trunk + {nsteps} reverse-diffusion steps, "
                                f"{B} samples per call per GPU, "
                                + ("template-projection physics correction (40 synthetic conformers, factor 6)"

@@ -18,6 +18,7 @@
 // A arrives as fp32 (split while it is staged, after the norm prologue and the scale) or pre-split by pd_norm_split2
 // ([2][M][K] fp16, PRO == 3: the staging is a 16-byte copy).
 #include <stdlib.h>
+#include <type_traits>
 #include "gemm_tile_common.h"
 
 namespace {
@@ -28,6 +29,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef PD_F16_MIN_TILES
 #define PD_F16_MIN_TILES 256
+#endif
+#ifdef PD_LAB      // lab build only (tools/gemm_f16_trace.py): in-kernel phase trace of the direct-W main loop
+__device__ unsigned long long* g_f16_trace = nullptr;
+#define PD_F16_TRACE_PTR g_f16_trace
+#else
+#define PD_F16_TRACE_PTR ((unsigned long long*)nullptr)
 #endif
 constexpr int NPARTS = 2;            // operand parts: (hi, lo) fp16
 constexpr int PITCH = 24;            // LDS-W tiles: 16 k per row, 48 bytes apart
@@ -71,7 +78,8 @@ void gemm_f16_kernel(const pd_gemm_args p) {
     constexpr int NW = 4 / TPR_W;                // W chunks per thread per part per slice
     constexpr bool DW = TL::DW;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the fragment addresses become SGPR base + lane offset
     const int wm = wave / TL::WN, wn = wave % TL::WN;
     const int l31 = lane & 31, hh = lane >> 5;
     const int nMb = p.M / BM, nNb = p.N / BN;
@@ -296,22 +304,41 @@ void gemm_f16_kernel(const pd_gemm_args p) {
         // slice 0 of this tile is in ra / rw (requested before the previous tile's epilogue)
         lds_barrier();                            // every wave has finished the previous tile's last stage
         if constexpr (DW) {
+            unsigned long long* dbg = nullptr;
+            if (PD_F16_TRACE_PTR && lane == 0 && blockIdx.x < 64 && tile < t_step)
+                dbg = PD_F16_TRACE_PTR + ((long long)blockIdx.x * 8 + wave) * (6 * 64);
+#define PD_STAMP(slot) if (dbg && kt < 64) dbg[kt * 6 + slot] = __builtin_amdgcn_s_memtime()
             stage2(0, 0);
             lds_barrier();
-            for (int kt = 0; kt < nk; ++kt) {
+            // one 32-k slice; `more` is a compile-time flag and the last slice is peeled off the loop: with the requests inside
+            // run-time conditionals the compiler's s_waitcnt insertion falls back to vmcnt(0) at the first MFMA of every slice -
+            // every wave then sat out the full latency of the A loads it had just issued (phase trace: tools/gemm_f16_trace.py)
+            auto slice = [&](int kt, auto more_c) {
+                constexpr bool more = decltype(more_c)::value;
                 const int st = kt & 1;
-                const bool more = kt + 1 < nk;
-                if (more) gload(bm0, bn0, (kt + 1) * 32);
+                PD_STAMP(0);
+                if constexpr (more) { gload(bm0, bn0, (kt + 1) * 32); __builtin_amdgcn_sched_barrier(0); }   // requests stay where they are written
                 mma2(st, 0);
-                if (more) wfrag(0, bn0, 2 * kt + 2);          // every B buffer is re-requested right after its last use
+                PD_STAMP(1);
+                // every B buffer is re-requested right after its last use
+                if constexpr (more) { __builtin_amdgcn_sched_barrier(0); wfrag(0, bn0, 2 * kt + 2); __builtin_amdgcn_sched_barrier(0); }
                 mma2(st, 1);
-                if (more) {
+                PD_STAMP(2);
+                if constexpr (more) {
+                    __builtin_amdgcn_sched_barrier(0);
                     wfrag(1, bn0, 2 * kt + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    PD_STAMP(3);
                     // the other stage was last read in the previous iteration, which every wave left through its barrier
                     stage2(st ^ 1, (kt + 1) * 32);
+                    PD_STAMP(4);
                     lds_barrier();
+                    PD_STAMP(5);
                 }
-            }
+            };
+            for (int kt = 0; kt + 1 < nk; ++kt) slice(kt, std::true_type{});
+            slice(nk - 1, std::false_type{});
+#undef PD_STAMP
         } else {
             stage(0, 0);
             stage(1, 0);
@@ -347,6 +374,15 @@ void gemm_f16_kernel(const pd_gemm_args p) {
         epilogue<EPI, TM, TN>(p, acc, c0, c1, cur_bm0, cur_bn0, wm, wn, l31, hh);
     }
 }
+
+#ifdef PD_LAB
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int pd_lab_set_f16_trace(void* buf) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_f16_trace), &q, sizeof(q)) == hipSuccess ? PD_OK : PD_ERR_LAUNCH;
+}
+namespace {
+#endif
 
 template <int PRO, int EPI, class TL>
 int run_f16(int op, const pd_gemm_args* p, hipStream_t s) {

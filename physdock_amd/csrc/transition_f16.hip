@@ -37,7 +37,10 @@ void transition_f16_kernel(const pd_transition_args p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     _Float16* sA = lds;                          // [2][128][LP]   y, scaled and split
     _Float16* sH = lds + 2 * PART;               // [2][128][LP]   hidden chunk, scaled and split
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index as a scalar: the fragment block offsets derived from it must be SGPR operands of the buffer loads (from the
+    // VGPR tid >> 6 hipcc wraps every load in a v_readfirstlane waterfall loop)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     constexpr int NKS1 = C_ / 16;                // 16-k steps of the up-projection (8)
     constexpr int NKS2 = CH * NCH / 16;          // ... of the down-projection (24)
