@@ -202,6 +202,7 @@ class LaunchTimer:
                     # (the GLU tile takes direct-W loads - last argument true - when A arrives pre-split)
                     name = "gemm_f16_kernel<%d, %d, FTile<%s> >" % (
                         3 if a.A2 else pro, epi,
+                        "64, 128, 1, 4, true" if tcode == 1 else
                         ("128, 128, 4, 8, true" if a.A2 else "128, 128, 4, 8, false") if glu_tile else "128, 128, 2, 8, true")
             nb = max(a.batch, 1)
             n_out = a.N // 2 if a.glu else a.N

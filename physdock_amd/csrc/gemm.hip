@@ -672,15 +672,16 @@ PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v >= 0 && (p.A3 || p.A2)) {  // pre-split A: exactly pd_gemm's rule - a split-operand kernel on the whole problem, or nothing
         int split = 0;
-        const int epi = persistent_try(&p, pro, 128, nullptr, 2, &split);
-        return epi >= 0 && split ? v + 5000 + 10000 * epi + 1000000 * split : v;
+        const int q = persistent_try(&p, pro, 128, nullptr, 2, &split);
+        return q >= 0 && split ? v + 5000 + 10000 * (q & 0xff) + 100000 * (q >> 8) + 1000000 * split : v;
     }
     if (v >= 0 && use_stream() && stream_tile(cfg, p)) {
         pd_gemm_args head, tail;
         const int tile = stream_tile(cfg, p);
         int split = 0;
-        const int epi = persistent_try(split_rows(p, pro, tile, head, tail) ? &head : &p, pro, tile, nullptr, 2, &split);
-        if (epi >= 0) return v + 5000 + 10000 * epi + 100000 * (tile == 128 ? 0 : tile == 64 ? 1 : 2) + 1000000 * split;
+        const int q = persistent_try(split_rows(p, pro, tile, head, tail) ? &head : &p, pro, tile, nullptr, 2, &split);
+        // (the fp16 kernel picks its own tile: bit 8 of its answer = 64 x 128)
+        if (q >= 0) return v + 5000 + 10000 * (q & 0xff) + 100000 * (split == 2 ? q >> 8 : tile == 128 ? 0 : tile == 64 ? 1 : 2) + 1000000 * split;
     }
     return v;
 }

@@ -30,6 +30,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef PD_F16_MIN_TILES
 #define PD_F16_MIN_TILES 256
 #endif
+#ifndef PD_F16_MIN_TILES_SMALL
+#define PD_F16_MIN_TILES_SMALL 160
+#endif
 #ifdef PD_LAB      // lab build only (tools/gemm_f16_trace.py): in-kernel phase trace of the direct-W main loop
 __device__ unsigned long long* g_f16_trace = nullptr;
 #define PD_F16_TRACE_PTR g_f16_trace
@@ -47,7 +50,7 @@ struct FTile {
     static constexpr bool DW = DW_;      // direct W: the B fragments go from global memory straight into MFMA registers
     static constexpr int STAGE = DW ? NPARTS * BM * PITCH2 : NPARTS * (BM + BN) * PITCH;      // fp16 elements per stage
     static constexpr int LDS_BYTES = 2 * STAGE * 2;
-    static constexpr int BLOCKS_PER_CU = 2;
+    static constexpr int BLOCKS_PER_CU = NWAVES_ == 8 ? 2 : 4;
     static constexpr int WAVES_PER_SIMD = NWAVES_ * BLOCKS_PER_CU / 4;
     static constexpr int GRID = 256 * BLOCKS_PER_CU;
 };
@@ -406,8 +409,18 @@ using F128GD = F128G;
 using F128GD = FTile<128, 128, 4, 8, true>;
 #endif
 
-int dispatch_f16(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s) {
+// 64 x 128 tiles on four waves (1 x 4, 64 x 32 each: the register profile of the 128 x 128 tile), four blocks per CU: launches whose 128 x 128 tile count leaves CUs idle (the
+// token projections at ~8-30 samples: w2 / linear_o at 20 samples = 160 tiles of 128 x 128, 320 of these)
+using F64 = FTile<64, 128, 1, 4, true>;
+
+int dispatch_f16(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s, bool small) {
 #define PD_FCASE(P, E, TL) if (pro == P && epi == E) return run_f16<P, E, TL>(op, p, s);
+    if (small) {
+        PD_FCASE(0, EPI_PLAIN, F64) PD_FCASE(1, EPI_PLAIN, F64) PD_FCASE(3, EPI_PLAIN, F64)
+        PD_FCASE(1, EPI_HN, F64) PD_FCASE(2, EPI_HN, F64) PD_FCASE(3, EPI_HN, F64)
+        PD_FCASE(0, EPI_GATERES, F64) PD_FCASE(3, EPI_GATERES, F64)
+        return PD_ERR_UNSUPPORTED;
+    }
     PD_FCASE(0, EPI_PLAIN, F128) PD_FCASE(1, EPI_PLAIN, F128) PD_FCASE(3, EPI_PLAIN, F128)
     PD_FCASE(1, EPI_HN, F128) PD_FCASE(2, EPI_HN, F128) PD_FCASE(3, EPI_HN, F128)
     PD_FCASE(1, EPI_GLU, F128G) PD_FCASE(2, EPI_GLU, F128G) PD_FCASE(3, EPI_GLU, F128GD)
@@ -425,20 +438,26 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
         int rc = PD_OK;
         for (int P = 0; P < 4; ++P)
             for (int E = 0; E < 6; ++E) {
-                const int r = dispatch_f16(1, P, E, nullptr, nullptr);
-                if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
+                for (int small = 0; small < 2; ++small) {
+                    const int r = dispatch_f16(1, P, E, nullptr, nullptr, small != 0);
+                    if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
+                }
             }
         return rc;
     }
     const pd_gemm_args& p = *args;
-    if (!p.W2 || !p.w_inv || !p.a_amax || p.K % 4 != 0 || tile != 128) return PD_ERR_UNSUPPORTED;
+    if (!p.W2 || !p.w_inv || !p.a_amax || p.K % 4 != 0 || (tile != 128 && tile != 64)) return PD_ERR_UNSUPPORTED;
     if (p.A2) {                                  // pre-split A: whole 32-k slices, 16-byte aligned, prologue and scale already applied
         if (pro != 0 || p.pro_act != PD_ACT_NONE || p.K % 32 != 0 || ((uintptr_t)p.A2 & 15)) return PD_ERR_UNSUPPORTED;
         pro = 3;
     }
     if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
-    if (((uintptr_t)p.W2 & 15) != 0 || p.N % 128 != 0 || p.M % 128 != 0) return PD_ERR_UNSUPPORTED;
-    if ((long long)(p.M / 128) * (p.N / 128) < PD_F16_MIN_TILES) return PD_ERR_UNSUPPORTED;       // small launches: latency-bound
+    if (((uintptr_t)p.W2 & 15) != 0 || p.N % 128 != 0 || p.M % 64 != 0) return PD_ERR_UNSUPPORTED;
+    // 128 x 128 tiles when they fill the chip, else 64 x 128 tiles if there are enough of THOSE; smaller launches are latency-bound
+    // (k-split fp32 kernel).  The caller's tile (its 64 x 64 choice below 192 row/column blocks) only says the rows come in 64s.
+    const long long t128 = p.M % 128 == 0 ? (long long)(p.M / 128) * (p.N / 128) : 0, t64 = (long long)(p.M / 64) * (p.N / 128);
+    if (t128 < PD_F16_MIN_TILES && t64 < PD_F16_MIN_TILES_SMALL) return PD_ERR_UNSUPPORTED;
+    const bool small = t128 < PD_F16_MIN_TILES;
     if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
     if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
@@ -449,9 +468,9 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
         if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group % 64 != 0) epi = -1;
     } else epi = p.mul ? -1 : EPI_PLAIN;
     if (epi < 0) return PD_ERR_UNSUPPORTED;
-    if (init_only == 2) {
-        const int r = dispatch_f16(1, pro, epi, nullptr, nullptr);
-        return r == PD_OK ? epi : r;
+    if (init_only == 2) {        // query: the EPI kind, + 0x100 when the launch takes the 64 x 128 tile
+        const int r = dispatch_f16(1, pro, epi, nullptr, nullptr, small);
+        return r == PD_OK ? epi + (small ? 0x100 : 0) : r;
     }
-    return dispatch_f16(0, pro, epi, &p, (hipStream_t)stream);
+    return dispatch_f16(0, pro, epi, &p, (hipStream_t)stream, small);
 }

@@ -21,16 +21,21 @@ def variant(ops, seen):
     ops.GEMM_HOOK = lambda a, launch: (seen.append(L.pd_gemm_variant(C.byref(a))), launch())
 
 
+def tile_code(v):
+    """tile field of pd_gemm_variant: 0 = 128 x 128, 1 = 64 x 128 (fp16 kernel) / 64 x 64 (others)"""
+    return (v % 1000000) // 100000
+
+
 @pytest.mark.parametrize("K", [128, 512, 1408])
-@pytest.mark.parametrize("wide,slack", [(0.0, 1.0), (1.5, 1.0), (0.0, 300.0), (1.0, 30.0)])
-def test_f16_accuracy_is_at_least_fp32_mfma(K, wide, slack):
+@pytest.mark.parametrize("wide,slack,M", [(0.0, 1.0, 2048), (1.5, 1.0, 2048), (0.0, 300.0, 2048), (1.0, 30.0, 2048), (1.0, 30.0, 1280)])
+def test_f16_accuracy_is_at_least_fp32_mfma(K, wide, slack, M):
     """error against float64, normalised by sum |a b|: not above the fp32 MFMA path - also for operands with a wide dynamic
     range and for a bound that is much larger than the largest element (a bound is all the caller has).  Validity domain of
     the format: (bound / typical element of a row) up to ~2^12; beyond it the low parts go subnormal and the error grows
     gracefully (test_f16_error_beyond_the_validity_domain)"""
     from physdock_amd import ops
     from physdock_amd.packing import split2_f16
-    M, N = 128 * 16, 128 * 16
+    N = 128 * 16                                        # M = 1280: 160 tiles of 128 x 128 -> the 64 x 128 tile (320)
     A = torch.randn(M, K, generator=g(K)) * torch.exp(wide * torch.randn(M, K, generator=g(K + 1)))
     W = torch.randn(N, K, generator=g(K + 2)) * torch.exp(wide * torch.randn(N, 1, generator=g(K + 3)))     # rows of very different size
     Ad, Wd = A.cuda(), W.cuda()
@@ -45,6 +50,7 @@ def test_f16_accuracy_is_at_least_fp32_mfma(K, wide, slack):
     finally:
         ops.GEMM_HOOK = None
     assert seen[-1] >= 2000000, seen                     # gemm_f16_kernel took it
+    assert tile_code(seen[-1]) == (1 if M == 1280 else 0), seen
     e32 = (Y32.double() - ref).abs() / mag
     e3 = (Y3.double() - ref).abs() / mag
     print(f"K={K} wide={wide} bound x{slack:g}: fp32 MFMA max {float(e32.max()):.2e} rms {float(e32.pow(2).mean().sqrt()):.2e} | "
@@ -92,13 +98,14 @@ def test_f16_weights_decomposition_and_layout():
         assert torch.equal(f[:, n // 32, k // 16, (k % 16) // 8, n % 32, k % 8].float(), rows[:, n, k])
 
 
-@pytest.mark.parametrize("per_sample", [False, True])
-def test_f16_dit_block_gemms_vs_fp32_kernels(per_sample):
+@pytest.mark.parametrize("per_sample,B", [(False, 64), (True, 64), (False, 10), (True, 10)])
+def test_f16_dit_block_gemms_vs_fp32_kernels(per_sample, B):
     """the four projections of a DiT block (AdaLN prologue + head norm; SwiGLU; gate + residual twice) on the fp16 kernels -
-    in-kernel prologue and pre-split A2 forms - against the fp32-MFMA kernels on the same inputs"""
+    in-kernel prologue and pre-split A2 forms - against the fp32-MFMA kernels on the same inputs.  10 samples: the q|k|v and
+    the gated projections have too few 128 x 128 tiles to fill the chip and take the 64 x 128 tile"""
     from physdock_amd import ops
     from physdock_amd.packing import pack_glu, split2_f16
-    B, N_, Cd, hidden = 64, 256, 512, 1408
+    N_, Cd, hidden = 256, 512, 1408
     rows = B * N_
     x = (torch.randn(rows, Cd, generator=g(1)) * 3 + 1).cuda()
     ngrp = B if per_sample else 1
@@ -142,6 +149,7 @@ def test_f16_dit_block_gemms_vs_fp32_kernels(per_sample):
     torch.testing.assert_close(y16, y32, atol=3e-5, rtol=2e-5)
     _, y16p = both(qkv, W2=w2q, a_amax=ymax, A2=a2)
     torch.testing.assert_close(y16p, y32, atol=3e-5, rtol=2e-5)
+    assert [tile_code(v) for v in seen[-2:]] == [int(B == 10)] * 2, seen
 
     def glu(**kw):
         y = torch.empty(rows, hidden, device="cuda")
@@ -162,6 +170,7 @@ def test_f16_dit_block_gemms_vs_fp32_kernels(per_sample):
         return y
     g32, g16 = both(gate, W2=split2_f16(Wo), a_amax=torch.tensor([float(o.abs().max()) * 7], device="cuda"))
     torch.testing.assert_close(g16, g32, atol=5e-5, rtol=2e-5)
+    assert tile_code(seen[-1]) == int(B == 10), seen
 
 
 def test_norm_split2_is_the_scaled_two_part_split():
