@@ -224,7 +224,7 @@ class LaunchTimer:
             shape = "batch=%d heads=%d nq=%d nk=%d%s" % (a.nbatch, a.nheads, a.nq, a.nk, " bias" if a.bias else "")
             self._launch(name, shape, launch, 4.0 * a.nbatch * a.nheads * a.nq * a.nk * 32, byt)
         def transition_hook(a, launch):
-            name, shape = "transition_f16_kernel<3>", "M=%d C=%d hidden=%d" % (a.M, a.C, a.hidden)
+            name, shape = "transition_f16_kernel<3, %s>" % os.environ.get("PD_TRANSITION_BM", "64"), "M=%d C=%d hidden=%d" % (a.M, a.C, a.hidden)
             if not self.time_launches:
                 ok = launch()
                 if ok:

@@ -64,9 +64,11 @@ def compile_cmd(src, out, mode=("-c",)):
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_KSPLIT_MAX_BYTES") and base == "gemm_stream.hip":
         cmd[1:1] = ["-DPD_KSPLIT_MAX_BYTES=" + os.environ["PD_KSPLIT_MAX_BYTES"]]
-    for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES"):
+    for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES", "PD_F16_MIN_TILES_SMALL"):
         if os.environ.get(knob) and base == "gemm_f16.hip":
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
+    if os.environ.get("PD_TRANSITION_BM") and base == "transition_f16.hip":     # lab: 128-row tiles, one block per CU
+        cmd[1:1] = ["-DPD_TRANSITION_BM=" + os.environ["PD_TRANSITION_BM"]]
     for knob in ("PD_SPLIT_MIN_TILES", "PD_SPLIT_MIN_TILES_SMALL"):
         if os.environ.get(knob) and base == "gemm_split.hip":
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]

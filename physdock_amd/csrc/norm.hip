@@ -27,6 +27,23 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     const long long row = (long long)blockIdx.x * RPB + threadIdx.x / LPR;
     const bool ok = row < M;
     const int nchunk = C >> 2;                 // C % 4 == 0 checked by the launcher
+    // split-writing modes: the gain / shift rows of this row's group, requested BEFORE the x loads so that all of them are in flight
+    // together (as scalar loads after the reductions hipcc emitted eight dependent load round trips per
+    // chunk: 25 us for 16384 x 512 where the bytes need ~12)
+    f32x4 wv[MAXV], bv[MAXV];
+    if constexpr (WRITE == 2 || WRITE == 3) {
+        const long long goff = rows_per_group > 0 ? (row / rows_per_group) * (long long)gstride : 0;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = sub + i * LPR;
+            wv[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+            bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok && c < nchunk) {
+                if (w) wv[i] = *reinterpret_cast<const f32x4*>(w + goff + c * 4);
+                if (b) bv[i] = *reinterpret_cast<const f32x4*>(b + goff + c * 4);
+            }
+        }
+    }
     f32x4 v[MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -63,7 +80,6 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     } else if constexpr (WRITE == 3) {
         // the same rows times the power of two that brings the bound *amax below 2^14, as TWO fp16 parts (hi, lo): the
         // pre-split A operand of csrc/gemm_f16.hip (out2 = [2][M][C])
-        const long long goff = rows_per_group > 0 ? (row / rows_per_group) * (long long)gstride : 0;
         const float a_s = pd_pow2_scale(*amax);
         unsigned short* out = reinterpret_cast<unsigned short*>(y);
         const long long part = (long long)M * C;
@@ -73,12 +89,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
             if (c >= nchunk) continue;
             float t[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                t[e] = (v[i][e] - mean) * rstd;
-                if (w) t[e] = t[e] * w[goff + c * 4 + e];
-                if (b) t[e] = t[e] + b[goff + c * 4 + e];
-                t[e] *= a_s;
-            }
+            for (int e = 0; e < 4; ++e) t[e] = ((v[i][e] - mean) * rstd * wv[i][e] + bv[i][e]) * a_s;
             const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]);
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             unsigned short* o = out + row * (long long)C + c * 4;
@@ -88,7 +99,6 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     } else if constexpr (WRITE == 2) {
         // a' = (x - mean) rstd w[g][k] + b[g][k], g = row / rows_per_group: the GEMM prologue's expression, then the 3-way split
         // (8-byte stores per part; pairing chunks into 16-byte stores measured slower: 27 -> 43 us at [16384, 512])
-        const long long goff = rows_per_group > 0 ? (row / rows_per_group) * (long long)gstride : 0;
         unsigned short* out = reinterpret_cast<unsigned short*>(y);          // bf16 [3][M][C]
         const long long part = (long long)M * C;
 #pragma unroll
@@ -97,11 +107,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
             if (c >= nchunk) continue;
             float t[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                t[e] = (v[i][e] - mean) * rstd;
-                if (w) t[e] = t[e] * w[goff + c * 4 + e];
-                if (b) t[e] = t[e] + b[goff + c * 4 + e];
-            }
+            for (int e = 0; e < 4; ++e) t[e] = (v[i][e] - mean) * rstd * wv[i][e] + bv[i][e];
             const pd_parts p0 = pd_split2(t[0], t[1]), p1 = pd_split2(t[2], t[3]);
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             unsigned short* o = out + row * (long long)C + c * 4;
@@ -200,6 +206,7 @@ PD_EXPORT int pd_norm_split(const float* x, int ldx, int M, int C, int mode, flo
                             int rows_per_group, int gstride, void* out3, void* stream) {
     if (!x || !out3 || M <= 0 || C <= 0) return PD_ERR_ARG;
     if (C % 32 != 0 || ((uintptr_t)out3 & 15)) return PD_ERR_UNSUPPORTED;      // rows of whole 32-k slices, 16-byte aligned
+    if (((uintptr_t)w & 15) || ((uintptr_t)b & 15) || gstride % 4 != 0) return PD_ERR_UNSUPPORTED;      // gain / shift rows as 16-byte vectors
     return dispatch<2>(x, nullptr, reinterpret_cast<float*>(out3), nullptr, w, b, M, C, ldx, mode, eps, 0, (hipStream_t)stream,
                        rows_per_group, gstride);
 }
@@ -208,6 +215,7 @@ PD_EXPORT int pd_norm_split2(const float* x, int ldx, int M, int C, int mode, fl
                              int rows_per_group, int gstride, const float* a_amax, void* out2, void* stream) {
     if (!x || !out2 || !a_amax || M <= 0 || C <= 0) return PD_ERR_ARG;
     if (C % 32 != 0 || ((uintptr_t)out2 & 15)) return PD_ERR_UNSUPPORTED;
+    if (((uintptr_t)w & 15) || ((uintptr_t)b & 15) || gstride % 4 != 0) return PD_ERR_UNSUPPORTED;      // gain / shift rows as 16-byte vectors
     return dispatch<3>(x, nullptr, reinterpret_cast<float*>(out2), nullptr, w, b, M, C, ldx, mode, eps, 0, (hipStream_t)stream,
                        rows_per_group, gstride, a_amax);
 }

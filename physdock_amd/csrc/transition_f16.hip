@@ -18,11 +18,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int C_ = 128;                 // channels = K of the up-projection = N of the down-projection
-constexpr int BM = 128;                 // rows per block tile
+#ifndef PD_TRANSITION_BM
+#define PD_TRANSITION_BM 64
+#endif
 constexpr int CH = 128;                 // hidden columns per chunk
 constexpr int LP = 136;                 // LDS row pitch in fp16 (272 bytes: 17 x 16)
-constexpr int PART = BM * LP;           // fp16 elements per part of a tile
-constexpr int LDS_BYTES = 2 * 2 * PART * 2;      // (A tile + hidden chunk) x 2 parts
+// rows per block tile: 128 rows on eight waves, one block per CU - or 64 rows on four waves, TWO blocks per CU: the same wave
+// tiles and the same 139 KB of LDS per CU, but one block's LayerNorm / GLU epilogue / read-modify-write phases overlap the
+// other's matrix phases (the weights are streamed twice as often: 1.2 GB per launch through the L2s instead of 0.6)
+template <int BM> struct TT {
+    static constexpr int NT = 4 * BM;                       // threads: four per row in phase 0
+    static constexpr int PART = BM * LP;                    // fp16 elements per part of a tile
+    static constexpr int LDS_BYTES = 2 * 2 * PART * 2;      // (A tile + hidden chunk) x 2 parts
+    static constexpr int BLOCKS_PER_CU = 128 / BM;
+};
 
 __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
@@ -31,9 +40,10 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int NCH>                      // hidden = 128 * NCH
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <int NCH, int BM>              // hidden = 128 * NCH
+__global__ __launch_bounds__(4 * BM) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void transition_f16_kernel(const pd_transition_args p) {
+    constexpr int PART = TT<BM>::PART;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     _Float16* sA = lds;                          // [2][128][LP]   y, scaled and split
     _Float16* sH = lds + 2 * PART;               // [2][128][LP]   hidden chunk, scaled and split
@@ -73,7 +83,15 @@ void transition_f16_kernel(const pd_transition_args p) {
         {
             const int r = tid >> 2, q = tid & 3;
             const float* xr = p.x + (row0 + r) * C_;
-            f32x4 v[8];
+            // the AdaLN gain / shift rows of this row's group first: they do not depend on the statistics, so their latency
+            // overlaps the x loads and the two reductions
+            const long long goff = p.rows_per_group > 0 ? ((row0 + r) / p.rows_per_group) * (long long)p.gstride : 0;
+            f32x4 v[8], gw[8], gb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                gw[i] = *reinterpret_cast<const f32x4*>(p.scale1p + goff + 4 * (q + 4 * i));
+                gb[i] = *reinterpret_cast<const f32x4*>(p.shift + goff + 4 * (q + 4 * i));
+            }
             float s1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -91,12 +109,10 @@ void transition_f16_kernel(const pd_transition_args p) {
             sq += __shfl_xor(sq, 1);
             sq += __shfl_xor(sq, 2);
             const float rstd = rsqrtf(sq * (1.0f / C_) + p.eps) * y_s;      // the operand scale rides on rstd ...
-            const long long goff = p.rows_per_group > 0 ? ((row0 + r) / p.rows_per_group) * (long long)p.gstride : 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = 4 * (q + 4 * i);
-                const f32x4 w = *reinterpret_cast<const f32x4*>(p.scale1p + goff + c);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.shift + goff + c);
+                const f32x4 w = gw[i], b = gb[i];
                 float t[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = (v[i][e] - mean) * rstd * w[e] + b[e] * y_s;      // ... and on the shift
@@ -227,18 +243,20 @@ void transition_f16_kernel(const pd_transition_args p) {
 // x [M][128] updated in place; see include/physdock_hip.h pd_transition_args.  PD_ERR_UNSUPPORTED for other shapes (the caller
 // then runs the three-launch form).  init: M <= 0 with args == nullptr raises the dynamic-LDS limit.
 PD_EXPORT int pd_transition_f16(const pd_transition_args* a, void* stream) {
-    auto k = transition_f16_kernel<3>;
+    constexpr int BM = PD_TRANSITION_BM;
+    typedef TT<BM> T;
+    auto k = transition_f16_kernel<3, BM>;
     if (!a) {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
     }
     if (!a->x || !a->shift || !a->scale1p || !a->gate || !a->W13 || !a->w13_inv || !a->W2 || !a->w2_inv || !a->y_amax || !a->h_amax)
         return PD_ERR_ARG;
     if (a->C != C_ || a->hidden != 3 * CH || a->M <= 0 || a->M % BM != 0) return PD_ERR_UNSUPPORTED;
-    if (a->M / BM < 256) return PD_ERR_UNSUPPORTED;                     // fewer tiles than CUs: the three-launch form fills the chip better
+    if (a->M / 128 < 256) return PD_ERR_UNSUPPORTED;                    // fewer 128-row tiles than CUs: the three-launch form fills the chip better
     if (a->rows_per_group > 0 && a->gstride % 4 != 0) return PD_ERR_UNSUPPORTED;
     if (((uintptr_t)a->x | (uintptr_t)a->shift | (uintptr_t)a->scale1p | (uintptr_t)a->W13 | (uintptr_t)a->W2) & 15) return PD_ERR_UNSUPPORTED;
-    const int ntiles = a->M / BM;
-    hipLaunchKernelGGL(k, dim3(ntiles < 256 ? ntiles : 256), dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
+    const int ntiles = a->M / BM, grid = 256 * T::BLOCKS_PER_CU;
+    hipLaunchKernelGGL(k, dim3(ntiles < grid ? ntiles : grid), dim3(T::NT), T::LDS_BYTES, (hipStream_t)stream, *a);
     return pd_check_launch();
 }
