@@ -158,8 +158,13 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
             const int kr = srow + RPP * i;                         // key row inside the tile
             unsigned k0[NP], k1[NP], v0[NP], v1[NP];               // packed pairs: (e0, e1), (e2, e3)
             if constexpr (NP == 2) {
+#if defined(PD_ATTN_ABL) && PD_ATTN_ABL == 1      // lab ablation (wrong results): K / V staged without scale + split VALU work
+                k0[0] = __float_as_uint(rk[i][0]); k0[1] = __float_as_uint(rk[i][1]); k1[0] = __float_as_uint(rk[i][2]); k1[1] = __float_as_uint(rk[i][3]);
+                v0[0] = __float_as_uint(rv[i][0]); v0[1] = __float_as_uint(rv[i][1]); v1[0] = __float_as_uint(rv[i][2]); v1[1] = __float_as_uint(rv[i][3]);
+#else
                 PT::split(rk[i][0] * sk, rk[i][1] * sk, k0); PT::split(rk[i][2] * sk, rk[i][3] * sk, k1);
                 PT::split(rv[i][0] * sv, rv[i][1] * sv, v0); PT::split(rv[i][2] * sv, rv[i][3] * sv, v1);
+#endif
             } else {
                 PT::split(rk[i][0], rk[i][1], k0); PT::split(rk[i][2], rk[i][3], k1);
                 PT::split(rv[i][0], rv[i][1], v0); PT::split(rv[i][2], rv[i][3], v1);
@@ -229,7 +234,9 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
 #pragma unroll
+#if !(defined(PD_ATTN_ABL) && PD_ATTN_ABL == 2)   // lab ablation 2 (wrong results): no rescale of the accumulator
         for (int r = 0; r < 16; ++r) o[r] *= alpha;      // (a wave-uniform "no maximum moved" skip measured -20 %: it splits the schedule)
+#endif
         // fp16 parts: p is carried times 2^14 (inside the exponent), so that its low part stays a normal fp16 number down
         // to p = 2^-16; the sum l carries the same factor and it cancels in o / l
         const float m_exp = NP == 2 ? m_new - 14.0f : m_new;
