@@ -91,13 +91,16 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
            max_samples: int = 5, max_rounds: int = 10, num_samples_per_round: int = 5, steps: int = 40,
            mmff_gamma_0_factor_start: float = 6.0, karras_noise_schedule_power: float = 1000, use_pocket: bool = True,
            align_weights: Optional[torch.Tensor] = None, ranking: bool = True, seed: Optional[int] = None,
-           sampler_kwargs: Optional[dict] = None, infer_meta_data=None) -> dict:
+           sampler_kwargs: Optional[dict] = None, infer_meta_data=None, reuse_conditioning: bool = True) -> dict:
     """One system through the reference's round loop (defaults = redocking.py:33-59).  `batch` holds device tensors
     as for `model.sample_diffusion`; with physics correction it may hold `batch_msa_feat [rounds,S,T,34]`.
     Returns dict(poses [n,A,3] in the ground-truth frame, accepted (count before the top-up), rounds (per-round log),
     gamma_factor, ranking (ranking.rank_poses output or None)); with `infer_meta_data` (the loader's per-system naming
     tables) also `pdb_blocks` / `receptor_pdb_blocks`: the `write_pdb_block` text of every kept pose (redocking.py:342-345),
-    formatted on the device for the whole batch (pdbio.py)."""
+    formatted on the device for the whole batch (pdbio.py).
+    `reuse_conditioning`: rounds that see the SAME features (no `batch_msa_feat` re-sampling) share one run of the conditioning
+    trunk - the reference recomputes it in every `sample_diffusion` call (model.py:179) with identical inputs and hence identical
+    outputs; here round 0 returns its (a, ap, s, z) and later rounds take them through `conditioning=`.  Bit-identical poses."""
     if physics_correction and ref_mol_poses is None:
         raise ValueError("physics correction needs reference conformers (ref_mol_poses [C,L,3]); the reference generates "
                          "them with RDKit ETKDG (redocking.py:231-243), which this build does not include")
@@ -115,6 +118,8 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
     kw = dict(sampler_kwargs or {})
     n_mol = _mol_num_atoms(ref_mol) if ref_mol is not None else None
     ref_mol_num_error = ref_mol is None or (n_mol is not None and n_mol != int(is_lig.sum()))     # redocking.py:195-196
+    reuse = bool(reuse_conditioning and getattr(model, "supports_conditioning_reuse", False))
+    cond = None
     for rnd in range(max_rounds):
         if rnd > 0 and not physics_correction:
             break
@@ -123,6 +128,7 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
                 raise ValueError(f"batch_msa_feat holds {batch['batch_msa_feat'].shape[0]} re-sampled MSAs, round {rnd} needs "
                                  "its own (the reference loads num_recycles = max_rounds of them, redocking.py:83)")
             batch["msa_feat"] = batch["batch_msa_feat"][rnd]
+            cond = None                      # a re-sampled MSA: this round's trunk is its own
         templates = torch.stack(ligand_templates + reference_templates, 0) if rnd > 0 else None
         call = dict(num_sample=num_samples_per_round, steps=steps, mmff_gamma_0_factor=factor, align_ref_pos=rnd > 0,
                     ref_mol=None if ref_mol_num_error else ref_mol, ref_mol_poses=templates,
@@ -132,8 +138,15 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
         if seed is not None:
             call.update(seed=seed + rnd)
         call.update(kw)
+        if reuse and "conditioning" not in call and "return_conditioning" not in call:
+            if cond is not None:
+                call.update(conditioning=cond)
+            elif physics_correction and rnd + 1 < max_rounds and "batch_msa_feat" not in batch:
+                call.update(return_conditioning=True)
         with torch.no_grad():
             x_pred = model.sample_diffusion(batch, **call)
+        if isinstance(x_pred, tuple):
+            x_pred, cond = x_pred
         # accept / reject (redocking.py:303-317): on the device when a ChiralityReference is given (one kernel, one [B]
         # mask to the host), else through the injected per-pose callable (which needs the poses on the host)
         dev_ok = chirality.accept(x_pred).tolist() if (physics_correction and chirality is not None) else None

@@ -51,6 +51,8 @@ def karras_noise_schedule(num_steps=200, sigma_data=16, s_max=160, s_min=4 * 10e
 
 
 class PhysDock(nn.Module):
+    supports_conditioning_reuse = True      # sample_diffusion(conditioning=, return_conditioning=): driver.redock shares the trunk between rounds
+
     def __init__(self, config):
         super().__init__()
         self.config = config

@@ -322,6 +322,40 @@ def test_driver_uses_the_device_chirality_mask(small):
     assert [r["accepted"] for r in out2["rounds"]] == [0, 0] and out2["gamma_factor"] == pytest.approx(max(max(6.0 * 0.7, 1.0) * 0.7, 1.0))
 
 
+def test_redock_rounds_share_one_trunk_run_bit_identically(small):
+    """driver.redock(reuse_conditioning=True): rounds without MSA re-sampling take round 0's (a, ap, s, z) instead of
+    recomputing them (the reference recomputes identical values, model.py:179) - same poses to the bit, one trunk run"""
+    from physdock_amd import driver
+    from physdock_amd.synthetic import reference_conformers
+    model, cfg, P, batch, dbatch = small
+    confs = reference_conformers(batch, n_conf=6, seed=1).cuda()
+    kw = dict(ref_mol_poses=confs, physics_correction=True, accept_fn=lambda x: False, max_samples=3, max_rounds=3,
+              num_samples_per_round=3, steps=6, seed=4, ranking=False)
+    eng = model.engine(torch.device("cuda", 0))
+    runs = []
+    orig = eng.conditioning
+    eng.conditioning = lambda b: (runs.append(1), orig(b))[1]
+    try:
+        out_a = driver.redock(model, dbatch, reuse_conditioning=True, **kw)
+        n_shared = len(runs)
+        out_b = driver.redock(model, dbatch, reuse_conditioning=False, **kw)
+        n_plain = len(runs) - n_shared
+    finally:
+        eng.conditioning = orig
+    assert len(out_a["rounds"]) == 3 and (n_shared, n_plain) == (1, 3)
+    assert torch.equal(out_a["poses"], out_b["poses"])
+    # a re-sampled MSA per round switches the sharing off (every round has its own features)
+    db2 = dict(dbatch)
+    db2["batch_msa_feat"] = dbatch["msa_feat"][None].repeat(3, 1, 1, 1)
+    runs.clear()
+    eng.conditioning = lambda b: (runs.append(1), orig(b))[1]
+    try:
+        out_c = driver.redock(model, db2, **kw)
+    finally:
+        eng.conditioning = orig
+    assert len(runs) == 3 and torch.equal(out_c["poses"], out_b["poses"])
+
+
 # ------------------------------------------------------------------ pd_pair_bias: one-pass stats + projection + fragment store
 @pytest.mark.parametrize("C,H,T1,T2,transpose,mode", [(128, 4, 96, 96, False, 0), (128, 4, 96, 96, True, 0), (128, 8, 40, 72, False, 0),
                                                       (128, 16, 70, 68, False, 0), (16, 4, 200, 200, False, 0),
