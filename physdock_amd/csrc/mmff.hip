@@ -157,52 +157,74 @@ __device__ V3 bonded_term(const pd_mmff_terms& T, int kind, int t, int slot, con
     return dEdc * pick4(slot, dr1, gj, gk, dr4);
 }
 
+// threads that share one atom's terms: the largest power of two <= NT / L, at most 8 (lanes of one wave, adjacent)
+__device__ __forceinline__ int threads_per_atom(int L) {
+    int t = 8;
+    while (t > 1 && t * L > NT) t >>= 1;
+    return t;
+}
+
 // MMFF94 energy of the conformation p (LDS, [L][3]) - returned to every thread - and, if g != nullptr, its gradient
 // g[3 L] (any address space reachable by generic pointers).  Must be called by all NT threads.
+// An atom's incident bonded terms and its non-bonded row are dealt round-robin to `tpa` adjacent lanes, whose partial
+// gradients / energies are then added in a fixed xor-tree: no atomics, bit-reproducible, and a 32-atom ligand keeps all 256
+// threads busy instead of 32 (one evaluation 100 -> ~20 us; the relaxation is a chain of ~15 of them per sampler step).
 __device__ double energy_grad(const pd_mmff_terms& T, const double* p, double* g, double* red) {
     const int L = T.n_atoms;
+    const int tpa = threads_per_atom(L), sub = threadIdx.x & (tpa - 1);
     double e_own = 0.0;
-    for (int a = threadIdx.x; a < L; a += NT) {
+    const int a_step = NT / tpa;
+    const int a_end = (L + a_step - 1) / a_step * a_step;          // whole passes: every lane takes part in the shuffles below
+    for (int a = threadIdx.x / tpa; a < a_end; a += a_step) {
         V3 ga = {0.0, 0.0, 0.0};
-        for (int q = T.inc_ptr[a]; q < T.inc_ptr[a + 1]; ++q) {
-            const int code = T.inc[q];
-            const int kind = (code >> 28) & 7, slot = (code >> 24) & 15, t = code & 0xFFFFFF;
-            double e;
-            ga = ga + bonded_term(T, kind, t, slot, p, e);
-            if (slot == 0) e_own += e;
-        }
-        const V3 pa = ld(p, a);
-        const double* Rr = T.vdw_R + (long long)a * L;
-        const double* Er = T.vdw_eps + (long long)a * L;
-        const double* Qr = T.ele_qq + (long long)a * L;
-        double e_nb = 0.0;
-        for (int j = 0; j < L; ++j) {
-            const double eps = Er[j], qq = Qr[j];
-            if (j == a || (eps == 0.0 && qq == 0.0)) continue;
-            const V3 d = pa - ld(p, j);
-            const double r = norm(d);
-            double dE = 0.0;
-            if (eps != 0.0) {                            // buffered 14-7
-                const double Rs = Rr[j];
-                const double R2 = Rs * Rs, R7 = R2 * R2 * R2 * Rs;
-                const double r2 = r * r, r6 = r2 * r2 * r2, r7 = r6 * r;
-                const double den = r + 0.07 * Rs;
-                const double a1 = 1.07 * Rs / den;
-                const double a2 = a1 * a1, a7 = a2 * a2 * a2 * a1;
-                const double bden = r7 + 0.12 * R7;
-                const double bt = 1.12 * R7 / bden - 2.0;
-                e_nb += eps * a7 * bt;
-                dE += eps * ((-7.0 * a7 / den) * bt + a7 * (-1.12 * R7 * 7.0 * r6 / (bden * bden)));
+        double e_nb = 0.0, e_b = 0.0;
+        if (a < L) {
+            for (int q = T.inc_ptr[a] + sub; q < T.inc_ptr[a + 1]; q += tpa) {
+                const int code = T.inc[q];
+                const int kind = (code >> 28) & 7, slot = (code >> 24) & 15, t = code & 0xFFFFFF;
+                double e;
+                ga = ga + bonded_term(T, kind, t, slot, p, e);
+                if (slot == 0) e_b += e;
             }
-            if (qq != 0.0) {                             // buffered Coulomb, constant dielectric
-                const double rb = r + ELE_BUF;
-                e_nb += ELE_K * qq / rb;
-                dE += -ELE_K * qq / (rb * rb);
+            const V3 pa = ld(p, a);
+            const double* Rr = T.vdw_R + (long long)a * L;
+            const double* Er = T.vdw_eps + (long long)a * L;
+            const double* Qr = T.ele_qq + (long long)a * L;
+            for (int j = sub; j < L; j += tpa) {
+                const double eps = Er[j], qq = Qr[j];
+                if (j == a || (eps == 0.0 && qq == 0.0)) continue;
+                const V3 d = pa - ld(p, j);
+                const double r = norm(d);
+                double dE = 0.0;
+                if (eps != 0.0) {                            // buffered 14-7
+                    const double Rs = Rr[j];
+                    const double R2 = Rs * Rs, R7 = R2 * R2 * R2 * Rs;
+                    const double r2 = r * r, r6 = r2 * r2 * r2, r7 = r6 * r;
+                    const double den = r + 0.07 * Rs;
+                    const double a1 = 1.07 * Rs / den;
+                    const double a2 = a1 * a1, a7 = a2 * a2 * a2 * a1;
+                    const double bden = r7 + 0.12 * R7;
+                    const double bt = 1.12 * R7 / bden - 2.0;
+                    e_nb += eps * a7 * bt;
+                    dE += eps * ((-7.0 * a7 / den) * bt + a7 * (-1.12 * R7 * 7.0 * r6 / (bden * bden)));
+                }
+                if (qq != 0.0) {                             // buffered Coulomb, constant dielectric
+                    const double rb = r + ELE_BUF;
+                    e_nb += ELE_K * qq / rb;
+                    dE += -ELE_K * qq / (rb * rb);
+                }
+                ga = ga + (dE / r) * d;
             }
-            ga = ga + (dE / r) * d;
         }
-        e_own += 0.5 * e_nb;                             // every pair is visited from both of its atoms
-        if (g) { g[3 * a] = ga.x; g[3 * a + 1] = ga.y; g[3 * a + 2] = ga.z; }
+        double e_a = e_b + 0.5 * e_nb;                       // every pair is visited from both of its atoms
+        for (int o = 1; o < tpa; o <<= 1) {                  // fixed tree over the atom's lanes
+            ga.x += __shfl_xor(ga.x, o); ga.y += __shfl_xor(ga.y, o); ga.z += __shfl_xor(ga.z, o);
+            e_a += __shfl_xor(e_a, o);
+        }
+        if (sub == 0 && a < L) {
+            e_own += e_a;
+            if (g) { g[3 * a] = ga.x; g[3 * a + 1] = ga.y; g[3 * a + 2] = ga.z; }
+        }
     }
     return block_sum_d(e_own, red);
 }
@@ -239,6 +261,41 @@ __global__ __launch_bounds__(NT) void mmff_energy_grad_kernel(const pd_mmff_term
 constexpr double FUNCTOL = 1e-4, MOVETOL = 1e-7, EPS_ = 3e-8, TOLX = 4.0 * EPS_, MAXSTEP = 100.0, FORCE_TOL = 1e-4;
 
 // x_ref = x with ligand rows relaxed: BFGSOpt.h::minimize on the MMFF94 energy, maxIts = max_iters
+// out[i] = sign * sum_j H[j][i] v[j] for the symmetric dim x dim matrix H (column reads are coalesced).  With dim <= NT / 2 the
+// j range is cut into NT / dim parts summed in a fixed order (partials through `part`, NT doubles of LDS): 96 outputs of a
+// 32-atom ligand use 192 threads instead of 96, each with half the dependent chain.  Must be called by all NT threads.
+__device__ void matvec_sym(const double* __restrict__ H, const double* __restrict__ v, double* __restrict__ out, double sign,
+                           int dim, double* part) {
+    const int tid = threadIdx.x;
+    const int parts = dim <= NT ? NT / dim : 1;
+    if (parts == 1) {
+        for (int i = tid; i < dim; i += NT) {
+            double h = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < dim; ++j) h += H[(long long)j * dim + i] * v[j];
+            out[i] = sign * h;
+        }
+        __syncthreads();
+        return;
+    }
+    const int jc = (dim + parts - 1) / parts;
+    double acc = 0.0;
+    if (tid < parts * dim) {
+        const int i = tid % dim, pt = tid / dim;
+        const int j0 = pt * jc, j1 = (j0 + jc < dim) ? j0 + jc : dim;
+#pragma unroll 4
+        for (int j = j0; j < j1; ++j) acc += H[(long long)j * dim + i] * v[j];
+    }
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < dim) {
+        double h = 0.0;
+        for (int pt = 0; pt < parts; ++pt) h += part[pt * dim + tid];
+        out[tid] = sign * h;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(NT) void mmff_relax_kernel(const pd_mmff_terms T, const float* __restrict__ x,
                                                        const int* __restrict__ lig_idx, float* __restrict__ x_ref,
                                                        double* __restrict__ ws, int A, int max_iters) {
@@ -246,6 +303,7 @@ __global__ __launch_bounds__(NT) void mmff_relax_kernel(const pd_mmff_terms T, c
     const int L = T.n_atoms, dim = 3 * L, b = blockIdx.x, tid = threadIdx.x;
     double* sp = sm;                 // positions under evaluation [dim]
     double* red = sm + dim;          // [4]
+    double* part = red + 4;          // [NT] partial sums of matvec_sym
     double* base = ws + (long long)b * ((long long)dim * dim + 8ll * dim);
     double* H = base;                                  // inverse Hessian [dim][dim], kept exactly symmetric
     double* pos = H + (long long)dim * dim;
@@ -342,11 +400,10 @@ __global__ __launch_bounds__(NT) void mmff_relax_kernel(const pd_mmff_terms T, c
         if (test < FORCE_TOL) break;
         // ---------------- BFGS update of the inverse Hessian (H is symmetric: column reads are coalesced)
         double fac = 0.0, fae = 0.0, sdg = 0.0, sxi = 0.0;
+        __syncthreads();                                // dgrad is complete
+        matvec_sym(H, dgrad, hdg, 1.0, dim, part);
         for (int i = tid; i < dim; i += NT) {
-            double h = 0.0;
-            for (int j = 0; j < dim; ++j) h += H[(long long)j * dim + i] * dgrad[j];
-            hdg[i] = h;
-            fac += dgrad[i] * xi[i]; fae += dgrad[i] * h; sdg += dgrad[i] * dgrad[i]; sxi += xi[i] * xi[i];
+            fac += dgrad[i] * xi[i]; fae += dgrad[i] * hdg[i]; sdg += dgrad[i] * dgrad[i]; sxi += xi[i] * xi[i];
         }
         fac = block_sum_d(fac, red); fae = block_sum_d(fae, red); sdg = block_sum_d(sdg, red); sxi = block_sum_d(sxi, red);
         if (fac > sqrt(EPS_ * sdg * sxi)) {
@@ -354,19 +411,15 @@ __global__ __launch_bounds__(NT) void mmff_relax_kernel(const pd_mmff_terms T, c
             const double fad = 1.0 / fae;
             for (int i = tid; i < dim; i += NT) dgrad[i] = fac * xi[i] - fad * hdg[i];
             __syncthreads();
-            for (long long e = tid; e < (long long)dim * dim; e += NT) {
-                const int r = (int)(e / dim), c = (int)(e % dim);
-                const int i = r < c ? r : c, j = r < c ? c : r;          // the (i <= j) element RDKit computes and mirrors
+            const unsigned udim = (unsigned)dim, n2 = udim * udim;       // dim <= 3072: 32-bit index arithmetic
+            for (unsigned e = tid; e < n2; e += NT) {
+                const unsigned r = e / udim, c = e - r * udim;
+                const unsigned i = r < c ? r : c, j = r < c ? c : r;      // the (i <= j) element RDKit computes and mirrors
                 H[e] += (fac * xi[i]) * xi[j] - (fad * hdg[i]) * hdg[j] + (fae * dgrad[i]) * dgrad[j];
             }
         }
         __syncthreads();
-        for (int i = tid; i < dim; i += NT) {
-            double v = 0.0;
-            for (int j = 0; j < dim; ++j) v -= H[(long long)j * dim + i] * grad[j];
-            xi[i] = v;
-        }
-        __syncthreads();
+        matvec_sym(H, grad, xi, -1.0, dim, part);
     }
     __syncthreads();
     for (int i = tid; i < dim; i += NT) ob[3 * lig_idx[i / 3] + i % 3] = (float)pos[i];
@@ -397,7 +450,7 @@ PD_EXPORT int pd_mmff_relax(const pd_mmff_terms* terms, const float* x, const in
     if (!terms_ok(terms) || !x || !lig_idx || !x_ref || !ws || B <= 0 || A < terms->n_atoms || max_iters < 0) return PD_ERR_ARG;
     const long long dim = 3ll * terms->n_atoms;
     if (ws_doubles < (long long)B * (dim * dim + 8 * dim)) return PD_ERR_ARG;
-    const size_t lds = ((size_t)dim + 4) * sizeof(double);
+    const size_t lds = ((size_t)dim + 4 + NT) * sizeof(double);
     hipLaunchKernelGGL(mmff_relax_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, *terms, x, lig_idx, x_ref, ws, A, max_iters);
     return pd_check_launch();
 }
