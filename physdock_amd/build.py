@@ -67,6 +67,8 @@ def compile_cmd(src, out, mode=("-c",)):
     for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES", "PD_F16_MIN_TILES_SMALL"):
         if os.environ.get(knob) and base == "gemm_f16.hip":
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
+    if os.environ.get("PD_ATTN_MIN_WAVES") and base == "attention.hip":     # lab: query waves from which the split-operand kernels take a launch
+        cmd[1:1] = ["-DPD_ATTN_MIN_WAVES=" + os.environ["PD_ATTN_MIN_WAVES"]]
     if os.environ.get("PD_ATTN_ABL") and base == "attn_f16.hip":      # lab: VALU ablations of the fp16-parts attention (wrong results)
         cmd[1:1] = ["-DPD_ATTN_ABL=" + os.environ["PD_ATTN_ABL"]]
     if os.environ.get("PD_TRANSITION_BM") and base == "transition_f16.hip":     # lab: 128-row tiles, one block per CU

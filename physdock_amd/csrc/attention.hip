@@ -258,6 +258,9 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const pd_attn_args p)
 
 // number of key chunks pd_attention would use (1 = no split): only when the launch leaves most of the chip idle, the
 // key range is long enough and the caller supplied a workspace of nsplit * nbatch * nq * (32 + 2) * nheads floats
+#ifndef PD_ATTN_MIN_WAVES
+#define PD_ATTN_MIN_WAVES 1024
+#endif
 static int attn_nsplit(const pd_attn_args* a) {
 #ifdef PD_LAB
     static const int on = [] { const char* e = getenv("PD_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
@@ -282,7 +285,7 @@ PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
     if (!a) return PD_ERR_ARG;
     // the bf16 split-operand kernel pays off when the launch fills the chip (>= one 32-query wave per SIMD); smaller launches
     // are latency-bound and stay on the fp32-MFMA kernel (with its key-split option)
-    if (!a->fp32_mfma && attn_nsplit(a) <= 1 && (long long)a->nbatch * a->nheads * ((a->nq + 31) / 32) >= 1024)
+    if (!a->fp32_mfma && attn_nsplit(a) <= 1 && (long long)a->nbatch * a->nheads * ((a->nq + 31) / 32) >= PD_ATTN_MIN_WAVES)
         return (a->f16x3 ? 2000 : 1000) + (a->nq > 128 ? 8 : 4);      // 2000 +: two-part fp16 operands (attn_f16.hip)
 #ifdef PD_LAB
     static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
