@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 5
+#define PD_ABI_VERSION 6
 
 enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFRAG = 3 };
 
@@ -94,6 +94,16 @@ typedef struct pd_gemm_args {
     const void* A2;              /* optional: A already normalised, modulated, scaled by the power of two pd_gemm derives from
                                     *a_amax, and split into two fp16 parts [2][M][K] (pd_norm_split2); K % 32 == 0, no prologue  */
     const float* a_amax;         /* device scalar: upper bound of |A'|                                                         */
+    /* ABI 6, head-norm epilogue of the fp16-format kernel only (the q|k|v projection of a DiT block): output columns
+       n >= y2_col0 (k and v) are NOT stored to Y but written ALREADY SCALED AND SPLIT for the attention kernel
+       (pd_attn_args.K2 / V2) into Y2, fp16 elements, row stride ldy2 = 2 * (N - y2_col0): inside a row every group of four
+       columns c = n - y2_col0 = 4 g + e occupies eight consecutive elements - the four high parts at 8 g + e, the four low
+       parts at 8 g + 4 + e - so that one 16-byte load yields both parts of four values.  A value is multiplied by the power
+       of two pd_attention derives from the bound y2_amax[c / hn_split] (device floats: max|k|, max|v|) before it is split.
+       Any launch that cannot honour Y2 fails with PD_ERR_UNSUPPORTED - it is never silently ignored.                      */
+    void* Y2;
+    const float* y2_amax;
+    int y2_col0, ldy2;
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
 /* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling);
@@ -183,6 +193,14 @@ typedef struct pd_attn_args {
                                 follows - two fp16 parts [2][nbatch*nq][nheads*32] of o times the power of two derived from the v
                                 bound (|o| <= max|v|), i.e. pd_gemm_args.A2 with a_amax = &f16_amax[2]; rows are (batch, query)
                                 in order, so it needs o_bs = nq * o_ss and o_ss = nheads * 32.  16-byte aligned.              */
+    /* ABI 6, f16x3 launches only: K and V already scaled (by the powers of two this kernel derives from f16_amax[1] /
+       f16_amax[2]) and split into two fp16 parts by the producing projection (pd_gemm_args.Y2 layout): the high parts of dims
+       4 g .. 4 g + 3 of (b, key, h) at K2[b * kv2_bs + key * kv2_ss + 64 h + 8 g ..], the low parts four elements further
+       (fp16 elements; 16-byte aligned).  The staging of a key tile is then a copy - every query block of a (batch, head) no
+       longer re-splits the same K and V.  K / V (fp32) are ignored when K2 / V2 are given; both or neither.               */
+    const void* K2;
+    const void* V2;
+    long long kv2_bs, kv2_ss;
 } pd_attn_args;
 /* Launches that cannot fill the chip (nbatch * nheads * ceil(nq/128) < 512 blocks) with a long key range are split into
  * up to 8 key chunks when ws holds nsplit * nbatch * nq * nheads * 34 floats; a second kernel merges the chunks. */

@@ -59,6 +59,7 @@ class GemmArgs(C.Structure):
         ("vecA", C.c_int), ("vecW", C.c_int), ("vecY", C.c_int),
         ("ksplit_ws", _fp), ("ksplit_ws_bytes", C.c_longlong), ("ksplit", C.c_int),
         ("W2", _fp), ("w_inv", _fp), ("A2", _fp), ("a_amax", _fp),
+        ("Y2", _fp), ("y2_amax", _fp), ("y2_col0", C.c_int), ("ldy2", C.c_int),      # ABI 6
     ]
 
 
@@ -71,6 +72,7 @@ class AttnArgs(C.Structure):
         ("bias", _fp), ("scale", C.c_float), ("bias_nk", C.c_int), ("fp32_mfma", C.c_int),
         ("ws", _fp), ("ws_bytes", C.c_longlong), ("nsplit", C.c_int),
         ("f16x3", C.c_int), ("f16_q_amax", C.c_float), ("f16_k_amax", C.c_float), ("f16_v_amax", C.c_float), ("f16_amax", _fp), ("O2", _fp),
+        ("K2", _fp), ("V2", _fp), ("kv2_bs", C.c_longlong), ("kv2_ss", C.c_longlong),      # ABI 6
     ]
 
 

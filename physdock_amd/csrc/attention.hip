@@ -299,7 +299,7 @@ PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
 }
 
 PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
-    if (!a || !a->Q || !a->K || !a->V || (!a->O && !a->O2)) return PD_ERR_ARG;
+    if (!a || !a->Q || ((!a->K || !a->V) && !(a->K2 && a->V2)) || (!a->O && !a->O2) || (!a->K2) != (!a->V2)) return PD_ERR_ARG;
     if (a->nq <= 0 || a->nk <= 0 || a->nbatch <= 0 || a->nheads <= 0) return PD_ERR_ARG;
     // 16-byte vector access on every row start
     const long long strides[] = {a->q_bs, a->q_ss, a->k_bs, a->k_ss, a->v_bs, a->v_ss, a->o_bs, a->o_ss};
@@ -307,7 +307,7 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O | (uintptr_t)a->bias) & 15)
         return PD_ERR_UNSUPPORTED;
     const int variant = pd_attention_variant(a);
-    if (a->O2 && variant < 2000) return PD_ERR_UNSUPPORTED;       // only the fp16-parts kernel writes the split output
+    if ((a->O2 || a->K2) && variant < 2000) return PD_ERR_UNSUPPORTED;       // only the fp16-parts kernel writes the split output / reads pre-split K, V
     if (variant >= 1000) return pd_attention_split_try(a, stream, 0);
     if (variant > 100) {
         if (((uintptr_t)a->ws & 15) != 0) return PD_ERR_UNSUPPORTED;

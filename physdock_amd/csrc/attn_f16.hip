@@ -66,7 +66,8 @@ __device__ __forceinline__ int vpos(int k) {
     return 16 * s + 8 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
 }
 
-template <int NW, int NP>
+// PRE: K and V arrive already scaled and split (pd_attn_args.K2 / V2, written by the q|k|v projection's epilogue): staging copies
+template <int NW, int NP, bool PRE = false>
 __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2, 4))) void attn_parts_kernel(const pd_attn_args p) {
     typedef Parts<NP> PT;
     typedef typename PT::frag frag;
@@ -138,6 +139,10 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     constexpr int RPP = 8 * NW, NST = KT / RPP;
     const int srow = tid >> 3, sc = tid & 7;
     f32x4 rk[NST], rv[NST];
+    // PRE: one 16-byte chunk per tensor holds (hi(e0,e1), hi(e2,e3), lo(e0,e1), lo(e2,e3)) of the thread's four dims
+    // (pd_gemm_args.Y2 row layout): the same registers, the same address arithmetic as the fp32 rows, no scale / split VALU
+    const float* K2b = reinterpret_cast<const float*>(p.K2) + (((long long)b * p.kv2_bs + h * 64) >> 1) + 4 * sc;
+    const float* V2b = reinterpret_cast<const float*>(p.V2) + (((long long)b * p.kv2_bs + h * 64) >> 1) + 4 * sc;
     auto gload = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
@@ -145,8 +150,13 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
             rk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (key < p.nk) {
-                rk[i] = *reinterpret_cast<const f32x4*>(Kb + (long long)key * p.k_ss + 4 * sc);
-                rv[i] = *reinterpret_cast<const f32x4*>(Vb + (long long)key * p.v_ss + 4 * sc);
+                if constexpr (PRE) {
+                    rk[i] = *reinterpret_cast<const f32x4*>(K2b + (((long long)key * p.kv2_ss) >> 1));
+                    rv[i] = *reinterpret_cast<const f32x4*>(V2b + (((long long)key * p.kv2_ss) >> 1));
+                } else {
+                    rk[i] = *reinterpret_cast<const f32x4*>(Kb + (long long)key * p.k_ss + 4 * sc);
+                    rv[i] = *reinterpret_cast<const f32x4*>(Vb + (long long)key * p.v_ss + 4 * sc);
+                }
             }
         }
     };
@@ -157,7 +167,12 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         for (int i = 0; i < NST; ++i) {
             const int kr = srow + RPP * i;                         // key row inside the tile
             unsigned k0[NP], k1[NP], v0[NP], v1[NP];               // packed pairs: (e0, e1), (e2, e3)
-            if constexpr (NP == 2) {
+            if constexpr (PRE) {
+                static_assert(!PRE || NP == 2, "pre-split K / V: two fp16 parts");
+                const u32x4 kb = __builtin_bit_cast(u32x4, rk[i]), vb = __builtin_bit_cast(u32x4, rv[i]);
+                k0[0] = kb[0]; k1[0] = kb[1]; k0[NP - 1] = kb[2]; k1[NP - 1] = kb[3];
+                v0[0] = vb[0]; v1[0] = vb[1]; v0[NP - 1] = vb[2]; v1[NP - 1] = vb[3];
+            } else if constexpr (NP == 2) {
 #if defined(PD_ATTN_ABL) && PD_ATTN_ABL == 1      // lab ablation (wrong results): K / V staged without scale + split VALU work
                 k0[0] = __float_as_uint(rk[i][0]); k0[1] = __float_as_uint(rk[i][1]); k1[0] = __float_as_uint(rk[i][2]); k1[1] = __float_as_uint(rk[i][3]);
                 v0[0] = __float_as_uint(rv[i][0]); v0[1] = __float_as_uint(rv[i][1]); v1[0] = __float_as_uint(rv[i][2]); v1[1] = __float_as_uint(rv[i][3]);
@@ -312,20 +327,20 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
 
 template <int NP> constexpr int lds_bytes() { return 2 * NP * (K_PART + V_PART) * 2; }
 
-template <int NW, int NP>
+template <int NW, int NP, bool PRE>
 bool raise_lds() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_parts_kernel<NW, NP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_parts_kernel<NW, NP, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                lds_bytes<NP>()) == hipSuccess;
 }
 
-template <int NP>
+template <int NP, bool PRE>
 void launch(const pd_attn_args* a, hipStream_t stream) {
     if (a->nq > 128) {
         dim3 grid(a->nbatch, (a->nq + 255) / 256, a->nheads);
-        hipLaunchKernelGGL((attn_parts_kernel<8, NP>), grid, dim3(512), lds_bytes<NP>(), stream, *a);
+        hipLaunchKernelGGL((attn_parts_kernel<8, NP, PRE>), grid, dim3(512), lds_bytes<NP>(), stream, *a);
     } else {
         dim3 grid(a->nbatch, 1, a->nheads);
-        hipLaunchKernelGGL((attn_parts_kernel<4, NP>), grid, dim3(256), lds_bytes<NP>(), stream, *a);
+        hipLaunchKernelGGL((attn_parts_kernel<4, NP, PRE>), grid, dim3(256), lds_bytes<NP>(), stream, *a);
     }
 }
 
@@ -333,11 +348,17 @@ void launch(const pd_attn_args* a, hipStream_t stream) {
 
 // init_only: 1 raise the dynamic-LDS limits; 0 launch.  Called by pd_attention_split_try (attn_split.hip) for f16x3 launches.
 extern "C" int pd_attention_f16_try(const pd_attn_args* a, void* stream, int init_only) {
-    if (init_only == 1) return raise_lds<8, 2>() && raise_lds<4, 2>() ? PD_OK : PD_ERR_LAUNCH;
+    if (init_only == 1)
+        return raise_lds<8, 2, false>() && raise_lds<4, 2, false>() && raise_lds<8, 2, true>() && raise_lds<4, 2, true>() ? PD_OK : PD_ERR_LAUNCH;
     // the fp16 format needs finite positive magnitude bounds for q, k, v: by value or in device memory (f16_amax[3])
     if (!a->f16_amax && !(a->f16_q_amax > 0.f && a->f16_k_amax > 0.f && a->f16_v_amax > 0.f)) return PD_ERR_ARG;
     if (a->O2 && (((uintptr_t)a->O2 & 15) || a->o_ss != (long long)a->nheads * 32 || a->o_bs != (long long)a->nq * a->o_ss))
         return PD_ERR_ARG;                       // the split output is a dense [rows][C] operand
-    launch<2>(a, (hipStream_t)stream);
+    if (a->K2) {                                 // pre-split K / V: 16-byte chunks (four dims, both parts)
+        if (!a->V2 || (((uintptr_t)a->K2 | (uintptr_t)a->V2) & 15) || a->kv2_ss % 8 || a->kv2_bs % 8) return PD_ERR_ARG;
+        launch<2, true>(a, (hipStream_t)stream);
+    } else {
+        launch<2, false>(a, (hipStream_t)stream);
+    }
     return pd_check_launch();
 }

@@ -670,9 +670,10 @@ PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     pd_gemm_args p = *args;
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
-    if (v >= 0 && (p.A3 || p.A2)) {  // pre-split A: exactly pd_gemm's rule - a split-operand kernel on the whole problem, or nothing
+    if (v >= 0 && (p.A3 || p.A2 || p.Y2)) {  // pre-split A / Y2: exactly pd_gemm's rule - a split-operand kernel on the whole problem, or nothing
         int split = 0;
         const int q = persistent_try(&p, pro, 128, nullptr, 2, &split);
+        if (p.Y2 && split != 2) return v;            // only the fp16-format kernel writes the pre-split k | v
         return q >= 0 && split ? v + 5000 + 10000 * (q & 0xff) + 100000 * (q >> 8) + 1000000 * split : v;
     }
     if (v >= 0 && use_stream() && stream_tile(cfg, p)) {
@@ -692,10 +693,10 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
-    if (p.A3 || p.A2) {  // pre-split A: only a split-operand kernel can read it; anything else is an error, never the raw A
+    if (p.A3 || p.A2 || p.Y2) {  // pre-split A: only a split-operand kernel can read it; anything else is an error, never the raw A
         int split = 0;
         const int q = persistent_try(&p, pro, 128, nullptr, 2, &split);
-        if (q < 0 || !split) return PD_ERR_UNSUPPORTED;
+        if (q < 0 || !split || (p.Y2 && split != 2)) return PD_ERR_UNSUPPORTED;
         return split == 2 ? pd_gemm_f16_try(&p, pro, 128, stream, 0) : pd_gemm_split_try(&p, pro, 128, stream, 0);
     }
     if (use_stream() && stream_tile(cfg, p)) {

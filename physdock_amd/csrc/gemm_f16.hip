@@ -19,6 +19,7 @@
 // ([2][M][K] fp16, PRO == 3: the staging is a 16-byte copy).
 #include <stdlib.h>
 #include <type_traits>
+#define PD_EPILOGUE_Y2 1      // the head-norm epilogue of THIS family can write k | v pre-split for the attention kernel (pd_gemm_args.Y2)
 #include "gemm_tile_common.h"
 
 namespace {
@@ -468,6 +469,11 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
         if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group % 64 != 0) epi = -1;
     } else epi = p.mul ? -1 : EPI_PLAIN;
     if (epi < 0) return PD_ERR_UNSUPPORTED;
+    if (p.Y2) {          // k | v written pre-split for the attention kernel: head-norm epilogue only, whole 32-column heads
+        if (epi != EPI_HN || !p.y2_amax || p.hn_split <= 0 || p.hn_split % 32 != 0 || p.y2_col0 % 32 != 0 ||
+            p.ldy2 < 2 * (p.N - p.y2_col0) || p.ldy2 % 8 != 0 || ((uintptr_t)p.Y2 & 15))
+            return PD_ERR_UNSUPPORTED;
+    }
     if (init_only == 2) {        // query: the EPI kind, + 0x100 when the launch takes the 64 x 128 tile
         const int r = dispatch_f16(1, pro, epi, nullptr, nullptr, small);
         return r == PD_OK ? epi + (small ? 0x100 : 0) : r;

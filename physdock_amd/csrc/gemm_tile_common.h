@@ -90,17 +90,53 @@ __device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&a
                     for (int r = 0; r < 16; ++r) PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], gv[r] + rv[r]);
                     __builtin_amdgcn_sched_barrier(0);      // keep the 16/32 loads of one fragment from piling up with the next
                 } else if constexpr (EPI == EPI_HN) {
+                    // pd_gemm_args.Y2: this fragment (one head's 32 columns of k or v) goes to the attention kernel already scaled
+                    // and split into two fp16 parts instead of to Y (the launcher admits Y2 only on the fp16-format kernel)
+#ifdef PD_EPILOGUE_Y2                 // defined by gemm_f16.hip only: the other kernel families never get a launch with Y2
+                    const bool to_y2 = p.Y2 != nullptr && ncol0 >= p.y2_col0;
+#else
+                    constexpr bool to_y2 = false;
+#endif
+                    float y2s = 1.f;
+                    unsigned short* __restrict__ Y2o = nullptr;
+                    if (to_y2) {
+                        y2s = pd_pow2_scale(p.y2_amax[(ncol0 - p.y2_col0) / p.hn_split]);
+                        // row layout: groups of four columns as (4 high parts, 4 low parts): column c = 4 g + e -> 8 g + e, low + 4
+                        Y2o = reinterpret_cast<unsigned short*>(p.Y2) + (long long)(mb + hh * 4) * p.ldy2 + 2 * (ncol0 - p.y2_col0) +
+                              8 * (l31 >> 2) + (l31 & 2);          // (the lane pair's even column: 32-bit stores, see below)
+                    }
+                    float ov[16];
                     if (ncol0 < p.hn_cols) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float v = acc[i][j][r] + c0[j];
                             const float ss = pd_half_sum32(v * v);        // a head = the 32 lanes of a wave half
-                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], v * rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps) * c1[j]);
+                            ov[r] = v * rsqrtf(ss * (1.0f / 32.0f) + p.hn_eps) * c1[j];
                         }
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], acc[i][j][r] + c0[j]);
+                        for (int r = 0; r < 16; ++r) ov[r] = acc[i][j][r] + c0[j];
+                    }
+                    if (to_y2) {
+                        // two rows per split: a lane holds (row r, row r + 1) of ITS column as packed pairs; one exchange with the
+                        // neighbouring column's lane (quad_perm 1,0,3,2) turns that into (column e, column e + 1) pairs - the even
+                        // lane keeps row r, the odd lane row r + 1 - so every lane issues two 32-bit stores per row pair (high
+                        // parts, low parts) instead of four 16-bit ones
+                        const bool odd = (l31 & 1) != 0;
+                        const unsigned sel = odd ? 0x07060302u : 0x01000504u;       // v_perm_b32(own, neighbour, sel)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const pd_parts2 q2 = pd_split2h(ov[r] * y2s, ov[r + 1] * y2s);
+                            const unsigned nh = (unsigned)__builtin_amdgcn_mov_dpp((int)q2.h, 0xB1, 0xf, 0xf, true);
+                            const unsigned nl = (unsigned)__builtin_amdgcn_mov_dpp((int)q2.l, 0xB1, 0xf, 0xf, true);
+                            const unsigned dh = __builtin_amdgcn_perm(q2.h, nh, sel), dl = __builtin_amdgcn_perm(q2.l, nl, sel);
+                            unsigned* d = reinterpret_cast<unsigned*>(Y2o + (long long)pd_frag_row(odd ? r + 1 : r, 0) * p.ldy2);
+                            d[0] = dh;
+                            d[2] = dl;                                        // low parts: four fp16 elements further
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], ov[r]);
                     }
                 } else {
                     if (p.act == PD_ACT_SILU) {

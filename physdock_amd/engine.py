@@ -504,17 +504,27 @@ class Engine:
             return dict(A3=a3)
         qkv = self.lws("dit_qkv", rows, 3 * C)
         hn = dict(hn_w=P.headnorm(prefix + ".attention"), hn_cols=2 * C, hn_split=C, hn_eps=eps)
-        if presplit and ops.PRESPLIT_QKV:
-            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, a_amax=b_y, **norm_split(tab_off, b_y), **hn)
-        else:
-            st = self.stats(x, rows, C, LN, eps)
-            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
-                      pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
         st3 = (N * 3 * C, 3 * C)
         # bnd: device address of this (step, block)'s magnitude bounds: chip-filling attention launches then take the two-part
         # fp16 operand format too - and write their output already split for linear_o (no split VALU in that GEMM's staging)
         akw = dict(nq=N, nk=nk, nbatch=B, nheads=H, q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias,
                    bias_nk=N, ws=self.attn_ws(B, N, nk, H), f16_amax=bnd)
+        qkv_presplit = bool(presplit and ops.PRESPLIT_QKV)
+        # k | v leave the projection already scaled and split for that attention kernel (bounds bnd[1], bnd[2]): only when BOTH
+        # launches are the fp16-format kernels - asked of the library, never assumed
+        kv2 = None
+        if f16 and ops.F16_ATTN and ops.SPLIT_ATTN and ops.KV_PRESPLIT \
+                and ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw) >= 2000 \
+                and ops.kv2_supported(rows, C, a2=qkv_presplit and a2 is not None, per_group_rows=N if per_sample else 0):
+            kv2 = self.lws("dit_kv2", rows, 4 * C, dtype=torch.float16)      # per row: k then v, groups of (4 high, 4 low) parts
+            hn.update(Y2=kv2, y2_amax=bnd + 4, y2_col0=C)
+            akw.update(KV2=kv2, kv2_strides=(N * 4 * C, 4 * C))
+        if qkv_presplit:
+            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, a_amax=b_y, **norm_split(tab_off, b_y), **hn)
+        else:
+            st = self.stats(x, rows, C, LN, eps)
+            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
+                      pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         o_split = f16 and ops.F16_ATTN and ops.SPLIT_ATTN and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C \
             and ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw) >= 2000 \

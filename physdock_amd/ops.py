@@ -67,13 +67,40 @@ def presplit_supported(M, N, K, *, glu=0, hn=False, f16=False, gate=False):
     return r
 
 
+_KV2_OK = {}
+
+
+def kv2_supported(M, Cdim, *, a2, per_group_rows=0):
+    """Does the q|k|v projection of a DiT block ([M, C] -> [M, 3 C], head-norm epilogue) take the fp16-format kernel AND write
+    k | v pre-split for the attention kernel (pd_gemm_args.Y2)?  Asked of the library (pd_gemm_variant), as presplit_supported."""
+    key = (M, Cdim, bool(a2), int(per_group_rows))
+    r = _KV2_OK.get(key)
+    if r is None:
+        a = GemmArgs()
+        a.A = a.W = a.Y = 1 << 20
+        a.W2 = a.w_inv = a.a_amax = a.Y2 = a.y2_amax = 1 << 20
+        if a2:
+            a.A2 = 1 << 20
+        else:
+            a.stats = a.pro_w = a.pro_b = 1 << 20
+            a.pro_rows_per_group, a.pro_gstride = int(per_group_rows), (6 * Cdim if per_group_rows else 0)
+        a.M, a.N, a.K = M, 3 * Cdim, Cdim
+        a.lda, a.ldw, a.ldy = Cdim, Cdim, 3 * Cdim
+        a.batch, a.out_scale = 1, 1.0
+        a.hn_w, a.hn_cols, a.hn_split = 1 << 20, 2 * Cdim, Cdim
+        a.y2_col0, a.ldy2 = Cdim, 4 * Cdim
+        r = _lib.init().pd_gemm_variant(C.byref(a)) >= 2000000
+        _KV2_OK[key] = r
+    return r
+
+
 def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0, sY=0,
          a_kmajor=False, w_kmajor=False, stats=None, pro_w=None, pro_b=None, pro_rows_per_group=0,
          pro_gstride=0, pro_act=ACT_NONE, rowscale_acc=None, bias=None, sBias=0, hn_w=None, hn_cols=0,
          hn_split=32, hn_eps=0.0, act=ACT_NONE, glu=0, rowscale=None, maskadd=None, maskval=0.0,
          mul=None, ldmul=0, mul_rows_per_group=0, mul_gstride=0, out_scale=1.0, res=None, ldres=0,
          res_row_mod=0, sRes=0, out_mode=OUT_ROWMAJOR, T1=0, T2=0, frag_transpose=False, W3=None, ksplit_ws=None, A3=None,
-         W2=None, a_amax=None, A2=None):
+         W2=None, a_amax=None, A2=None, Y2=None, y2_amax=None, y2_col0=0):
     """Y = epilogue(prologue(A) @ W^T); see include/physdock_hip.h pd_gemm_args.
     A/W/Y and the optional operands may be tensors or raw device addresses (ints)."""
     def P(x):
@@ -93,8 +120,12 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
         a.W2, a.w_inv = W2[0].data_ptr(), W2[1].data_ptr()
         a.a_amax = a_amax if isinstance(a_amax, int) else ptr(a_amax)
         a.A2 = A2.data_ptr() if A2 is not None else None
-    elif A2 is not None:
-        raise ValueError("A2 (pre-split fp16 A) needs W2 and a_amax")
+        if Y2 is not None:       # head-norm epilogue: columns >= y2_col0 (k | v) written pre-split for pd_attention (K2 / V2)
+            a.Y2, a.y2_col0 = Y2.data_ptr(), int(y2_col0)
+            a.y2_amax = y2_amax if isinstance(y2_amax, int) else ptr(y2_amax)
+            a.ldy2 = int(Y2.shape[-1])
+    elif A2 is not None or Y2 is not None:
+        raise ValueError("A2 / Y2 (pre-split fp16 operands) need W2 and a_amax")
     a.M, a.N, a.K = M, N, K
     a.lda = lda if lda is not None else (M if a_kmajor else K)
     a.ldw = ldw if ldw is not None else (N if w_kmajor else K)
@@ -156,6 +187,9 @@ FUSED_TRANSITION = True
 TRANSITION_HOOK = None
 #: fp16-parts attention launches write their output already split for the projection that follows (pd_attn_args.O2 -> A2)
 ATTN_SPLIT_OUT = True
+#: the q|k|v projection writes k | v already scaled and split for the fp16-parts attention kernel (pd_gemm_args.Y2 -> pd_attn_args.K2 / V2):
+#: the 8 query blocks of a (sample, head) stage K / V tiles with copies instead of re-splitting them
+KV_PRESPLIT = True
 
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None
@@ -239,7 +273,8 @@ def attn_split_ws_numel(nbatch, nq, nk, nheads):
 
 
 def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_strides, o_strides, bias=None,
-              scale=1.0 / math.sqrt(32.0), ws=None, bias_nk=0, f16_amax=None, O2=None, query_only=False):
+              scale=1.0 / math.sqrt(32.0), ws=None, bias_nk=0, f16_amax=None, O2=None, query_only=False,
+              KV2=None, kv2_strides=None):
     """strides = (batch_stride, seq_stride) in floats; Q/K/V/O tensors or raw addresses.  ws: optional float scratch
     tensor (attn_split_ws_numel) enabling key-split launches for small grids.  bias_nk: key count the bias buffer was laid
     out for (the padded count when nk is the real one)."""
@@ -265,6 +300,10 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
             a.f16_amax = f16_amax
         else:
             a.f16_q_amax, a.f16_k_amax, a.f16_v_amax = (float(v) for v in f16_amax)
+    if KV2 is not None:      # [rows][4 C] fp16: k | v as written by gemm(Y2=) (groups of 4 dims: 4 high parts, 4 low parts)
+        Cc = nheads * 32
+        a.K2, a.V2 = KV2.data_ptr(), KV2.data_ptr() + 4 * Cc          # v follows k inside a row: 2 C fp16 elements = 4 C bytes
+        a.kv2_bs, a.kv2_ss = kv2_strides
     if ws is not None:
         a.ws, a.ws_bytes = ptr(ws), ws.numel() * 4
     if query_only:            # the kernel pd_attention would pick (pd_attention_variant): >= 2000 = fp16-parts kernel

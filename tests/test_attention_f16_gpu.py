@@ -113,3 +113,97 @@ def test_f16_attention_split_output_is_the_scaled_two_part_split_of_o():
     rec = (o2.double().sum(0) / scale).reshape(B, n, C).cpu()
     assert float(o2[0].float().abs().max()) < 2 ** 15
     assert float((rec - o.double()).abs().max()) <= 2.0 ** -21 * float(o.abs().max())
+
+
+@pytest.mark.parametrize("per_sample,B,N_,C", [(False, 64, 256, 512), (True, 64, 256, 512), (False, 10, 2048, 128), (True, 8, 2048, 128)])
+def test_kv_written_presplit_by_the_projection_is_bit_identical(per_sample, B, N_, C):
+    """ABI 6: the q|k|v projection's head-norm epilogue writes k | v already scaled and split (pd_gemm_args.Y2) and the
+    attention kernel stages them with copies (pd_attn_args.K2 / V2) - the SAME fp16 parts the kernel would have produced from
+    the fp32 k, v, so the attention output is identical to the bit; q still arrives as fp32.  Token (C = 512, pre-split A2 and
+    in-kernel prologue) and atom (C = 128) shapes, one AdaLN row for all samples and one per sample."""
+    from physdock_amd import ops
+    from physdock_amd.packing import split2_f16
+    import ctypes as C_
+    rows, H = B * N_, C // 32
+    x = (torch.randn(rows, C, generator=g(1)) * 2 + 0.5).cuda()
+    ngrp = B if per_sample else 1
+    tab = torch.randn(ngrp, 3 * C, generator=g(2)).cuda() * 0.5
+    tab[:, C:2 * C] += 1.0
+    Wq = (torch.randn(3 * C, C, generator=g(3)) / math.sqrt(C)).cuda()
+    hnw = (1 + 0.1 * torch.randn(2, 32, generator=g(4))).cuda()
+    st = torch.empty(rows, 2, device="cuda")
+    ops.rowstats(x, st, rows, C, mode=ops.LN, eps=1e-5)
+    grp = dict(pro_rows_per_group=N_, pro_gstride=3 * C) if per_sample else {}
+    ymax = torch.tensor([float(tab[:, C:2 * C].abs().max()) * math.sqrt(C) + float(tab[:, :C].abs().max())], device="cuda")
+    hn = dict(hn_w=hnw, hn_cols=2 * C, hn_split=C, hn_eps=1e-5)
+    pro = dict(stats=st, pro_b=tab, pro_w=tab.data_ptr() + 4 * C, **grp)
+    w2q = split2_f16(Wq)
+    qkv = torch.empty(rows, 3 * C, device="cuda")
+    ops.gemm(x, Wq, qkv, rows, 3 * C, C, W2=w2q, a_amax=ymax, **hn, **pro)
+    # rigorous bounds for q, k (head norm: sqrt(32) max|gain|) and the observed max of v as its bound
+    bq = math.sqrt(32.0) * float(hnw.abs().max())
+    amax = torch.tensor([bq, bq, float(qkv[:, 2 * C:].abs().max()) * 1.01], device="cuda")
+    bias = torch.randn(ops.bias_frag_numel(H, N_, N_), generator=g(5)).cuda()
+    st3 = (N_ * 3 * C, 3 * C)
+    akw = dict(nq=N_, nk=N_ - 3, nbatch=B, nheads=H, q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N_ * C, C), bias=bias,
+               bias_nk=N_, f16_amax=amax)
+    o_ref = torch.empty(rows, C, device="cuda")
+    ops.attention(qkv.data_ptr(), qkv.data_ptr() + 4 * C, qkv.data_ptr() + 8 * C, o_ref, **akw)
+    assert ops.kv2_supported(rows, C, a2=False, per_group_rows=N_ if per_sample else 0)
+    # the same projection with Y2: q to qkv2 (k, v columns of qkv2 stay untouched), k | v to kv2
+    qkv2 = torch.full((rows, 3 * C), float("nan"), device="cuda")
+    kv2 = torch.zeros(rows, 4 * C, dtype=torch.float16, device="cuda")     # per row: k | v, groups of four dims as (4 high, 4 low)
+    seen = []
+    L = ops._lib.init()
+    ops.GEMM_HOOK = lambda a, launch: (seen.append(L.pd_gemm_variant(C_.byref(a))), launch())
+    try:
+        ops.gemm(x, Wq, qkv2, rows, 3 * C, C, W2=w2q, a_amax=ymax, Y2=kv2, y2_amax=amax.data_ptr() + 4, y2_col0=C, **hn, **pro)
+    finally:
+        ops.GEMM_HOOK = None
+    assert seen[-1] >= 2000000
+    assert torch.equal(qkv2[:, :C], qkv[:, :C]) and torch.isnan(qkv2[:, C:]).all()
+    # the parts are the two-part split of k, v times the kernel's power-of-two scales
+    def pow2(b):
+        return 2.0 ** (14 - math.floor(math.log2(b)))
+    rec = kv2.double().reshape(rows, 2 * C // 4, 2, 4).sum(2).reshape(rows, 2 * C)
+    torch.testing.assert_close(rec[:, :C] / pow2(bq), qkv[:, C:2 * C].double(), rtol=0, atol=float(qkv[:, C:2 * C].abs().max()) * 2 ** -21)
+    torch.testing.assert_close(rec[:, C:] / pow2(float(amax[2])), qkv[:, 2 * C:].double(), rtol=0, atol=float(amax[2]) * 2 ** -21)
+    o_pre = torch.empty(rows, C, device="cuda")
+    variants = []
+    ops.ATTN_HOOK = lambda a, launch: (variants.append(L.pd_attention_variant(C_.byref(a))), launch())
+    try:
+        ops.attention(qkv2.data_ptr(), 0, 0, o_pre, KV2=kv2, kv2_strides=(N_ * 4 * C, 4 * C), **akw)
+    finally:
+        ops.ATTN_HOOK = None
+    assert variants[-1] >= 2000
+    assert torch.equal(o_pre, o_ref)
+    # pre-split A operand as well (token rows): same k | v parts
+    if C >= 256:
+        a2 = torch.empty(2, rows, C, dtype=torch.float16, device="cuda")
+        ops.norm_split2(x, a2, rows, C, ymax, mode=ops.LN, eps=1e-5, b=tab, w=tab.data_ptr() + 4 * C,
+                        rows_per_group=N_ if per_sample else 0, gstride=3 * C if per_sample else 0)
+        kv2b = torch.zeros_like(kv2)
+        assert ops.kv2_supported(rows, C, a2=True)
+        ops.gemm(x, Wq, qkv2, rows, 3 * C, C, W2=w2q, a_amax=ymax, A2=a2, Y2=kv2b, y2_amax=amax.data_ptr() + 4, y2_col0=C, **hn)
+        assert torch.equal(kv2b, kv2)
+
+
+def test_presplit_kv_is_never_silently_ignored():
+    """a launch that cannot write Y2 (too small for the fp16-format kernel) or an attention launch that cannot read K2 / V2 fails
+    loudly instead of running without them"""
+    from physdock_amd import ops
+    from physdock_amd.packing import split2_f16
+    M, C = 256, 128
+    x = torch.randn(M, C, device="cuda"); W = torch.randn(3 * C, C, device="cuda")
+    st = torch.empty(M, 2, device="cuda"); ops.rowstats(x, st, M, C, mode=ops.LN, eps=1e-5)
+    hnw = torch.ones(2, 32, device="cuda")
+    amax = torch.tensor([8.0, 8.0, 8.0], device="cuda")
+    kv2 = torch.zeros(M, 4 * C, dtype=torch.float16, device="cuda")
+    assert not ops.kv2_supported(M, C, a2=False)
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, W, torch.empty(M, 3 * C, device="cuda"), M, 3 * C, C, W2=split2_f16(W), a_amax=amax, stats=st, hn_w=hnw,
+                 hn_cols=2 * C, hn_split=C, hn_eps=1e-5, Y2=kv2, y2_amax=amax.data_ptr() + 4, y2_col0=C)
+    qkv = torch.randn(M, 3 * C, device="cuda")
+    with pytest.raises(RuntimeError):       # 1 x 4 heads x 256 queries: far below one wave per SIMD -> fp32 kernel, which has no K2 path
+        ops.attention(qkv.data_ptr(), 0, 0, torch.empty(M, C, device="cuda"), nq=M, nk=M, nbatch=1, nheads=4, q_strides=(M * 3 * C, 3 * C),
+                      k_strides=(0, 0), v_strides=(0, 0), o_strides=(M * C, C), f16_amax=amax, KV2=kv2, kv2_strides=(M * 4 * C, 4 * C))

@@ -237,9 +237,10 @@ def test_bounds_on_the_medium_model():
     model.load_state_dict(seeded_state_dict(param_shapes(cfg), seed=0), strict=True)
     model = model.cuda().eval()
     batch = {k: v.cuda() for k, v in cfg1_batch(0).items()}
-    old, old_t = ops.ATTN_SPLIT_OUT, ops.FUSED_TRANSITION
+    old, old_t, old_kv = ops.ATTN_SPLIT_OUT, ops.FUSED_TRANSITION, ops.KV_PRESPLIT
     ops.ATTN_SPLIT_OUT = False                       # keep o as an fp32 tensor for this inspection
     ops.FUSED_TRANSITION = False                     # ... and the atom blocks' hidden activations as a tensor
+    ops.KV_PRESPLIT = False                          # ... and k, v as fp32 columns of the q|k|v buffer
     seen = []
     variant(ops, seen)
     try:
@@ -247,7 +248,7 @@ def test_bounds_on_the_medium_model():
         model.sample_diffusion(batch, num_sample=16, steps=steps, karras_noise_schedule_power=1000, seed=1, align_ref_pos=False,
                                use_graph=False)
     finally:
-        ops.ATTN_SPLIT_OUT, ops.FUSED_TRANSITION = old, old_t
+        ops.ATTN_SPLIT_OUT, ops.FUSED_TRANSITION, ops.KV_PRESPLIT = old, old_t, old_kv
         ops.GEMM_HOOK = None
     # 18 blocks x 4 projections per step, minus the two narrow token projections (128 tiles at 16 samples), on the fp16 kernels
     # (the trunk's GEMMs carry no bounds and stay on bf16 x 6 / fp32)
