@@ -215,7 +215,8 @@ class LaunchTimer:
             v = L.pd_attention_variant(C.byref(a))          # 4 / 8 waves per block, or 4 + 100 * key chunks
             name = "attn_kernel<%d, %s>" % (v % 100, "true" if v > 100 else "false")
             if v >= 2000:       # fp16 matrix pipe, two-part operands, three products per block (csrc/attn_f16.hip)
-                name = "attn_parts_kernel<%d, 2, %s>" % (v % 100, "true" if a.K2 else "false")      # true: K / V arrive pre-split (K2 / V2)
+                # template arguments as rocprofv3 prints them: waves, parts, K / V pre-split (K2 / V2), key-split launch
+                name = "attn_parts_kernel<%d, 2, %s, %s>" % (v % 100, "true" if a.K2 else "false", "true" if v % 1000 > 100 else "false")
             elif v >= 1000:     # bf16 matrix pipe, three-part operands, six products per block (csrc/attn_split.hip)
                 name = "attn_split_kernel<%d>" % (v % 100)
             self.split[name] = 3 if v >= 2000 else (6 if v >= 1000 else 0)

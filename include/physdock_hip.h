@@ -206,7 +206,8 @@ typedef struct pd_attn_args {
  * up to 8 key chunks when ws holds nsplit * nbatch * nq * nheads * 34 floats; a second kernel merges the chunks. */
 int pd_attention(const pd_attn_args* args, void* stream);
 /* waves per block (4 or 8 = template argument of attn_kernel) pd_attention picks for these arguments; 4 + 100 * nsplit for
- * a key-split launch; 1000 + waves for attn_split_kernel<waves>, 2000 + waves for attn_parts_kernel<waves, 2> (profiling) */
+ * a key-split launch; 1000 + waves for attn_split_kernel<waves>, 2000 + waves for attn_parts_kernel<waves, 2>, 2000 + 4 +
+ * 100 * nsplit for a key-split launch on attn_parts_kernel<4, 2, false, true> (profiling) */
 int pd_attention_variant(const pd_attn_args* args);
 
 /* ---- pair-representation / pooling kernels (pair.hip) ----------------------------------

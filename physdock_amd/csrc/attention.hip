@@ -279,6 +279,8 @@ static int attn_nsplit(const pd_attn_args* a) {
 
 // attn_split.hip: the same kernel on the bf16 matrix pipe (3 x bf16 split operands)
 extern "C" int pd_attention_split_try(const pd_attn_args* a, void* stream, int init_only);
+// attn_f16.hip: key-split launch of the fp16-parts kernel (partials in the combine kernel's format)
+extern "C" int pd_attention_f16_split(const pd_attn_args* a, void* stream, int init_only);
 
 // waves per block pd_attention uses for these arguments (= template argument of attn_kernel; for profiling)
 PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
@@ -294,7 +296,8 @@ PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
 #endif
     // 8-wave blocks pay off (+2 %) when they still fill the chip twice over; short query ranges / few batches keep 4 waves
     const int ns = attn_nsplit(a);
-    if (ns > 1) return 4 + 100 * ns;                                   // split launch: 4-wave blocks, ns key chunks
+    if (ns > 1)                                                        // split launch: 4-wave blocks, ns key chunks;
+        return 4 + 100 * ns + ((a->f16x3 && !a->fp32_mfma && !a->O2 && !a->K2) ? 2000 : 0);      // 2000 +: on the fp16-parts kernel
     return (wide && a->nq >= 512 && (long long)a->nbatch * a->nheads * ((a->nq + 255) / 256) >= 1024) ? 8 : 4;
 }
 
@@ -307,7 +310,17 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O | (uintptr_t)a->bias) & 15)
         return PD_ERR_UNSUPPORTED;
     const int variant = pd_attention_variant(a);
-    if ((a->O2 || a->K2) && variant < 2000) return PD_ERR_UNSUPPORTED;       // only the fp16-parts kernel writes the split output / reads pre-split K, V
+    if ((a->O2 || a->K2) && (variant < 2000 || variant % 1000 > 100)) return PD_ERR_UNSUPPORTED;   // only the unsplit fp16-parts kernel writes the split output / reads pre-split K, V
+    if (variant >= 2000 && variant % 1000 > 100) {       // key-split launch on the fp16-parts kernel + the shared combine kernel
+        if (((uintptr_t)a->ws & 15) != 0) return PD_ERR_UNSUPPORTED;
+        pd_attn_args s = *a;
+        s.nsplit = (variant % 1000) / 100;
+        const int r = pd_attention_f16_split(&s, stream, 0);
+        if (r != PD_OK) return r;
+        const long long total = (long long)a->nbatch * a->nq * a->nheads * 8;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s);
+        return pd_check_launch();
+    }
     if (variant >= 1000) return pd_attention_split_try(a, stream, 0);
     if (variant > 100) {
         if (((uintptr_t)a->ws & 15) != 0) return PD_ERR_UNSUPPORTED;

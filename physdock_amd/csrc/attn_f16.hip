@@ -67,7 +67,9 @@ __device__ __forceinline__ int vpos(int k) {
 }
 
 // PRE: K and V arrive already scaled and split (pd_attn_args.K2 / V2, written by the q|k|v projection's epilogue): staging copies
-template <int NW, int NP, bool PRE = false>
+// SPLIT: the key range is cut into p.nsplit chunks (blockIdx.y = query block * nsplit + chunk), partial results to p.ws in the
+// format of attention.hip's attn_combine_kernel - the fp16-parts form of its key-split launch for a handful of samples
+template <int NW, int NP, bool PRE = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2, 4))) void attn_parts_kernel(const pd_attn_args p) {
     typedef Parts<NP> PT;
     typedef typename PT::frag frag;
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.x, h = blockIdx.z, qb = blockIdx.y;
+    const int b = blockIdx.x, h = blockIdx.z;
+    const int qb = SPLIT ? blockIdx.y / p.nsplit : blockIdx.y, chunk = SPLIT ? blockIdx.y % p.nsplit : 0;
     const int q0 = qb * (32 * NW) + wave * 32;
     const int query = q0 + l31;
     const bool wave_active = q0 < p.nq;
@@ -198,8 +201,10 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         }
     };
 
-    const int nit = (p.nk + KT - 1) / KT;
-    gload(0);
+    const int nit_all = (p.nk + KT - 1) / KT;
+    const int it_lo = SPLIT ? (int)((long long)nit_all * chunk / p.nsplit) : 0;
+    const int nit = SPLIT ? (int)((long long)nit_all * (chunk + 1) / p.nsplit) : nit_all;
+    gload(it_lo * KT);
     sstore(0);
     __syncthreads();
 
@@ -284,8 +289,8 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     };
     const int nfull32 = p.nk >> 5;
 
-    for (int it = 0; it < nit; ++it) {
-        const int cur = it & 1;
+    for (int it = it_lo; it < nit; ++it) {
+        const int cur = (it - it_lo) & 1;
         if (it + 1 < nit) gload((it + 1) * KT);
         if (wave_active) {
 #pragma unroll
@@ -299,6 +304,25 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         __syncthreads();
     }
 
+    if constexpr (SPLIT) {
+        if (query < p.nq) {      // partial result of this key chunk: [chunk][b][query][h*32 + dim], (m, l) per (chunk, b, h, query);
+            // o and l both carry the 2^14 of the p format (it cancels in the combine), o additionally the V scale: undone here
+            const float l = pd_xhalf_sum(l_run);
+            const int C = p.nheads * 32;
+            float* wo = p.ws + (((long long)chunk * p.nbatch + b) * p.nq + query) * C + h * 32 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {o[4 * g] * inv_sv, o[4 * g + 1] * inv_sv, o[4 * g + 2] * inv_sv, o[4 * g + 3] * inv_sv};
+                *reinterpret_cast<f32x4*>(wo + 8 * g) = v;
+            }
+            if (hh == 0) {
+                float* ml = p.ws + (long long)p.nsplit * p.nbatch * p.nq * C
+                            + ((((long long)chunk * p.nbatch + b) * p.nheads + h) * p.nq + query) * 2;
+                ml[0] = m_run; ml[1] = l;
+            }
+        }
+        return;
+    }
     if (query < p.nq) {
         const float l = pd_xhalf_sum(l_run);
         if (NP == 2 && p.O2) {
@@ -346,10 +370,25 @@ void launch(const pd_attn_args* a, hipStream_t stream) {
 
 }  // namespace
 
+// key-split launch of the fp16-parts kernel (pd_attention, a->nsplit chunks, 4-wave blocks as the fp32 form): partial results
+// to a->ws; the caller runs attn_combine_kernel afterwards.  init_only: 1 raise the dynamic-LDS limit.
+extern "C" int pd_attention_f16_split(const pd_attn_args* a, void* stream, int init_only) {
+    auto k = attn_parts_kernel<4, 2, false, true>;
+    if (init_only == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<2>()) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    if (!a->f16_amax && !(a->f16_q_amax > 0.f && a->f16_k_amax > 0.f && a->f16_v_amax > 0.f)) return PD_ERR_ARG;
+    if (a->O2 || a->K2 || a->nsplit < 2 || !a->ws) return PD_ERR_UNSUPPORTED;
+    dim3 grid(a->nbatch, ((a->nq + 127) / 128) * a->nsplit, a->nheads);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes<2>(), (hipStream_t)stream, *a);
+    return pd_check_launch();
+}
+
 // init_only: 1 raise the dynamic-LDS limits; 0 launch.  Called by pd_attention_split_try (attn_split.hip) for f16x3 launches.
 extern "C" int pd_attention_f16_try(const pd_attn_args* a, void* stream, int init_only) {
     if (init_only == 1)
-        return raise_lds<8, 2, false>() && raise_lds<4, 2, false>() && raise_lds<8, 2, true>() && raise_lds<4, 2, true>() ? PD_OK : PD_ERR_LAUNCH;
+        return raise_lds<8, 2, false>() && raise_lds<4, 2, false>() && raise_lds<8, 2, true>() && raise_lds<4, 2, true>() &&
+                       pd_attention_f16_split(nullptr, nullptr, 1) == PD_OK ? PD_OK : PD_ERR_LAUNCH;
     // the fp16 format needs finite positive magnitude bounds for q, k, v: by value or in device memory (f16_amax[3])
     if (!a->f16_amax && !(a->f16_q_amax > 0.f && a->f16_k_amax > 0.f && a->f16_v_amax > 0.f)) return PD_ERR_ARG;
     if (a->O2 && (((uintptr_t)a->O2 & 15) || a->o_ss != (long long)a->nheads * 32 || a->o_bs != (long long)a->nq * a->o_ss))

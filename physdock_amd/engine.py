@@ -514,7 +514,7 @@ class Engine:
         # launches are the fp16-format kernels - asked of the library, never assumed
         kv2 = None
         if f16 and ops.F16_ATTN and ops.SPLIT_ATTN and ops.KV_PRESPLIT \
-                and ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw) >= 2000 \
+                and ops.unsplit_f16_attention(ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw)) \
                 and ops.kv2_supported(rows, C, a2=qkv_presplit and a2 is not None, per_group_rows=N if per_sample else 0):
             kv2 = self.lws("dit_kv2", rows, 4 * C, dtype=torch.float16)      # per row: k then v, groups of (4 high, 4 low) parts
             hn.update(Y2=kv2, y2_amax=bnd + 4, y2_col0=C)
@@ -527,7 +527,7 @@ class Engine:
                       pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         o_split = f16 and ops.F16_ATTN and ops.SPLIT_ATTN and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C \
-            and ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw) >= 2000 \
+            and ops.unsplit_f16_attention(ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw)) \
             and ops.presplit_supported(rows, C, C, f16=True, gate=True)
         if o_split:
             o2 = self.lws("dit_o2", 2, rows, C, dtype=torch.float16)

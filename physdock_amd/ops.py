@@ -272,6 +272,12 @@ def attn_split_ws_numel(nbatch, nq, nk, nheads):
     return s * nbatch * nq * nheads * 34 if s >= 2 else 0
 
 
+def unsplit_f16_attention(variant):
+    """pd_attention_variant id of an UNSPLIT fp16-parts launch (2000 + waves): the form that can write O2 / read K2, V2
+    (2000 + waves + 100 * chunks is the key-split form for a handful of samples)"""
+    return variant >= 2000 and variant % 1000 < 100
+
+
 def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_strides, o_strides, bias=None,
               scale=1.0 / math.sqrt(32.0), ws=None, bias_nk=0, f16_amax=None, O2=None, query_only=False,
               KV2=None, kv2_strides=None):

@@ -207,3 +207,42 @@ def test_presplit_kv_is_never_silently_ignored():
     with pytest.raises(RuntimeError):       # 1 x 4 heads x 256 queries: far below one wave per SIMD -> fp32 kernel, which has no K2 path
         ops.attention(qkv.data_ptr(), 0, 0, torch.empty(M, C, device="cuda"), nq=M, nk=M, nbatch=1, nheads=4, q_strides=(M * 3 * C, 3 * C),
                       k_strides=(0, 0), v_strides=(0, 0), o_strides=(M * C, C), f16_amax=amax, KV2=kv2, kv2_strides=(M * 4 * C, 4 * C))
+
+
+@pytest.mark.parametrize("B,H,n,nk", [(1, 4, 2048, 2048), (2, 4, 2048, 1999), (3, 4, 1024, 1024)])
+def test_f16_key_split_launch_for_a_handful_of_samples(B, H, n, nk):
+    """few samples x long key range: pd_attention cuts the keys into chunks (partials + combine kernel).  With magnitude bounds
+    the chunks run on the fp16-parts kernel too (variant 2000 + 4 + 100 * chunks); error against float64 not above the fp32
+    key-split launch's"""
+    from physdock_amd import ops
+    import ctypes as C_
+    C = H * 32
+    q = torch.randn(B, n, C, generator=g(1))
+    k = torch.randn(B, nk, C, generator=g(2)) * (1 + torch.rand(B, nk, 1, generator=g(12)))
+    v = torch.randn(B, nk, C, generator=g(3)) * torch.exp(1.5 * torch.randn(B, nk, C, generator=g(13)))
+    bias = 2 * torch.randn(H, n, nk, generator=g(4))
+    bias[:, :, ::7] = -1e9
+    ref = ref64(q, k, v, bias)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    frag = ops.bias_to_frag(bias).cuda()
+    ws = torch.empty(ops.attn_split_ws_numel(B, n, nk, H), device="cuda")
+    assert ws.numel() > 0
+    amax = torch.tensor([float(q.abs().max()), float(k.abs().max()), float(v.abs().max())], device="cuda")
+    L = ops._lib.init()
+    outs, variants = {}, {}
+    for mode in ("fp32", "f16"):
+        o = torch.empty(B, n, C, device="cuda")
+        seen = []
+        ops.ATTN_HOOK = lambda a, launch: (seen.append(L.pd_attention_variant(C_.byref(a))), launch())
+        try:
+            ops.attention(qd, kd, vd, o, nq=n, nk=nk, nbatch=B, nheads=H, q_strides=(n * C, C), k_strides=(nk * C, C),
+                          v_strides=(nk * C, C), o_strides=(n * C, C), bias=frag, ws=ws, f16_amax=amax if mode == "f16" else None)
+        finally:
+            ops.ATTN_HOOK = None
+        outs[mode], variants[mode] = o.cpu().double(), seen[-1]
+    assert 100 < variants["fp32"] < 1000 and variants["f16"] >= 2000 and variants["f16"] % 1000 == variants["fp32"], variants
+    scale = float(ref.abs().max())
+    e32 = float((outs["fp32"] - ref).abs().max()) / scale
+    e16 = float((outs["f16"] - ref).abs().max()) / scale
+    print(f"B={B} n={n} nk={nk}: key-split fp32 {e32:.2e}  f16 parts {e16:.2e}  (variants {variants})")
+    assert e16 <= max(1.5 * e32, 2e-6), (e16, e32)
