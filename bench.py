@@ -383,7 +383,11 @@ def main():
         for tag in ("r03", "r02"):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same call (tools/collect_profiles.sh)
             pmc = os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")
             if os.path.exists(pmc) and args.cfg == "cfg1" and B == 64:
-                rows = [r for r in json.load(open(pmc)) if r["kernel"].replace("void ", "") == dom["kernel"]]
+                allrows = json.load(open(pmc))
+                rows = [r for r in allrows if r["kernel"].replace("void ", "") == dom["kernel"]]
+                if not rows:        # same kernel template, later template arguments renamed / added since the PMC passes
+                    stem = dom["kernel"].split(",")[0]
+                    rows = [r for r in allrows if r["kernel"].replace("void ", "").startswith(stem)]
                 if rows:
                     n = sum(r["launches"] for r in rows)
                     traffic = sum((r["fetch_bytes_x2"] + r["write_bytes"]) * r["launches"] for r in rows) / n
