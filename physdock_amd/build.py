@@ -69,6 +69,8 @@ def compile_cmd(src, out, mode=("-c",)):
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_ATTN_MIN_WAVES") and base == "attention.hip":     # lab: query waves from which the split-operand kernels take a launch
         cmd[1:1] = ["-DPD_ATTN_MIN_WAVES=" + os.environ["PD_ATTN_MIN_WAVES"]]
+    if os.environ.get("PD_ATTN_LAZY") and base == "attn_f16.hip":     # lab: lazy rescale of the attention accumulator (threshold in log2 units)
+        cmd[1:1] = ["-DPD_ATTN_LAZY=" + os.environ["PD_ATTN_LAZY"]]
     if os.environ.get("PD_ATTN_ABL") and base == "attn_f16.hip":      # lab: VALU ablations of the fp16-parts attention (wrong results)
         cmd[1:1] = ["-DPD_ATTN_ABL=" + os.environ["PD_ATTN_ABL"]]
     if os.environ.get("PD_TRANSITION_BM") and base == "transition_f16.hip":     # lab: 128-row tiles, one block per CU

@@ -250,6 +250,19 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
 #pragma unroll
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
         mloc = pd_xhalf_max(mloc);
+#if defined(PD_ATTN_LAZY)      // lab experiment: the reference maximum moves only when some row's maximum exceeds it by more than
+        // PD_ATTN_LAZY (log2 units); p is carried times 2^12 so that 2^PD_ATTN_LAZY of head room exists below the fp16 maximum
+        float alpha = 1.0f;
+        if (__builtin_amdgcn_ballot_w64(mloc > m_run + (float)PD_ATTN_LAZY) != 0ull) {
+            const float m_new = fmaxf(m_run, mloc);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        }
+        const float m_new = m_run;
+        const float m_exp = NP == 2 ? m_new - 12.0f : m_new;
+#else
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
@@ -260,6 +273,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         // fp16 parts: p is carried times 2^14 (inside the exponent), so that its low part stays a normal fp16 number down
         // to p = 2^-16; the sum l carries the same factor and it cancels in o / l
         const float m_exp = NP == 2 ? m_new - 14.0f : m_new;
+#endif
         float psum = 0.f;
         const unsigned short* vbase = sV + l31 * VP + sub * 32 + 8 * hh;
         // one k-step (8 of the lane's 16 keys) at a time: exp, split, the MFMAs - the probabilities of the second half are
