@@ -87,6 +87,12 @@ class Engine:
             ksw = self.ws.get("gemm_ksplit", 9 << 20)
         ops.gemm(A, W, Y, M, N, K, W3=w3, ksplit_ws=ksw, **kw)
 
+    def trunk_attn_bounds(self, prefix, norm_weight):
+        """static |q|, |k|, |v| bounds of a trunk attention (None: keep the bf16 x 6 kernel)"""
+        if not (ops.F16_ATTN and ops.F16_TRUNK_ATTN and ops.SPLIT_ATTN):
+            return None
+        return self.P.attn_static_bounds(prefix, norm_weight)
+
     def lws(self, name, *shape, dtype=torch.float32):
         """lane-private scratch: concurrent sample lanes never share a DiT intermediate"""
         return self.ws.get(f"{name}@{self.lane}", *shape, dtype=dtype)
@@ -139,7 +145,7 @@ class Engine:
         st4 = (N * 4 * C, 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=nk or N, nbatch=nbatch, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias, bias_nk=N,
-                      ws=self.attn_ws(nbatch, N, nk or N, H))
+                      ws=self.attn_ws(nbatch, N, nk or N, H), f16_amax=self.trunk_attn_bounds(prefix, P[f"{prefix}.{norm_name}.weight"]))
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         self.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s)
 
@@ -197,7 +203,8 @@ class Engine:
         else:
             st4, sto = (4 * C, T * 4 * C), (C, T * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
-                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T)
+                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T,
+                      f16_amax=self.trunk_attn_bounds(prefix, nw))
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         self.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z)
 
@@ -403,7 +410,8 @@ class Engine:
         o = self.ws.get("attn_o", rows, C)
         st4 = (4 * C, T * 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=S, nk=S, nbatch=T, nheads=H,
-                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(C, T * C), bias=None)
+                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(C, T * C), bias=None,
+                      f16_amax=self.trunk_attn_bounds(prefix, P[prefix + ".norm_m.weight"]))
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         self.gemm(o, Wo, m, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=m)
 

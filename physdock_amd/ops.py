@@ -190,6 +190,9 @@ ATTN_SPLIT_OUT = True
 #: the q|k|v projection writes k | v already scaled and split for the fp16-parts attention kernel (pd_gemm_args.Y2 -> pd_attn_args.K2 / V2):
 #: the 8 query blocks of a (sample, head) stage K / V tiles with copies instead of re-splitting them
 KV_PRESPLIT = True
+#: trunk attention (triangle, MSA row / column, pair-biased single / atom attention) on the fp16-parts kernel with STATIC bounds
+#: of q, k, v from the projection weights and the norm gain (packing.attn_static_bounds); False: bf16 x 6 as in round 2
+F16_TRUNK_ATTN = True
 
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None

@@ -151,6 +151,19 @@ class PackedWeights:
             return (W, b)
         return self._c(("qkvg", prefix), mk)
 
+    def attn_static_bounds(self, prefix, norm_weight):
+        """device floats [3]: rigorous upper bounds of |q|, |k|, |v| of a trunk attention whose projections (no bias) read an
+        RMS- / LayerNorm-ed row times the static gain `norm_weight`: |W_n . (x^ w)| <= ||W_n w||_2 ||x^||_2 and ||x^||_2 <= sqrt(C)
+        (Cauchy-Schwarz; weights only, so it holds for any input) - the precondition of the two-part fp16 attention format"""
+        def mk():
+            w = norm_weight.double()
+            out = []
+            for c in "qkv":
+                W = self.p[f"{prefix}.linear_{c}.weight"].double()
+                out.append(float((W * w[None, :]).norm(dim=1).max()) * math.sqrt(W.shape[1]) * 1.0001)
+            return torch.tensor(out, dtype=torch.float32, device=norm_weight.device)
+        return self._c(("attn_bounds", prefix, norm_weight.data_ptr()), mk)
+
     def qkv(self, prefix):
         return self._c(("qkv", prefix), lambda: torch.cat(
             [self.p[f"{prefix}.linear_{c}.weight"] for c in "qkv"], 0).contiguous())

@@ -246,3 +246,52 @@ def test_f16_key_split_launch_for_a_handful_of_samples(B, H, n, nk):
     e16 = float((outs["f16"] - ref).abs().max()) / scale
     print(f"B={B} n={n} nk={nk}: key-split fp32 {e32:.2e}  f16 parts {e16:.2e}  (variants {variants})")
     assert e16 <= max(1.5 * e32, 2e-6), (e16, e32)
+
+
+def test_trunk_attention_on_static_bounds():
+    """trunk attentions (triangle, MSA row / column, pair-biased) take the fp16-parts kernel on bounds that follow from the
+    projection weights and the norm gain alone (packing.attn_static_bounds: Cauchy-Schwarz with ||x^||_2 <= sqrt(C)).  On the
+    medium model at the benchmark crop: the bounds hold for the q | k | v the trunk really produces, every chip-filling trunk
+    attention launch runs attn_parts_kernel, and the conditioning outputs agree with the bf16 x 6 path to fp32 rounding"""
+    from physdock_amd import PhysDock, PhysDockConfig, ops, param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import cfg1_batch
+    import ctypes as C_
+    cfg = PhysDockConfig(model_name="medium")
+    model = PhysDock(cfg)
+    model.load_state_dict(seeded_state_dict(param_shapes(cfg), seed=0), strict=True)
+    model = model.cuda().eval()
+    batch = model._prepare_batch({k: v.cuda() for k, v in cfg1_batch(0).items()})
+    eng = model.engine(torch.device("cuda", 0))
+    L = ops._lib.init()
+    outs, variants = {}, {}
+    for flag in (True, False):
+        ops.F16_TRUNK_ATTN = flag
+        seen = []
+        ops.ATTN_HOOK = lambda a, launch: (seen.append(L.pd_attention_variant(C_.byref(a))), launch())
+        try:
+            a_, ap_, s_, z_ = eng.conditioning(batch)
+            outs[flag] = (a_.clone(), s_.clone(), z_.clone())
+        finally:
+            ops.ATTN_HOOK = None
+            ops.F16_TRUNK_ATTN = True
+        variants[flag] = list(seen)
+    n16 = sum(v >= 2000 for v in variants[True])
+    nbf = sum(1000 <= v < 2000 for v in variants[False])
+    assert n16 >= nbf > 0 and not any(v >= 2000 for v in variants[False]), (n16, nbf)
+    for x16, xbf, name in zip(outs[True], outs[False], "asz"):
+        rel = float((x16 - xbf).abs().max() / xbf.abs().max())
+        print(f"conditioning output {name}: fp16-parts vs bf16 x 6 trunk attention, max rel diff {rel:.2e}")
+        assert rel < 2e-5, (name, rel)
+    # the bounds hold on what one triangle attention of the trunk really sees (last call's q|k|v|g buffer, its own layer's bounds)
+    P = eng.P
+    # (the pairformer's last block ends with the column-wise triangle attention: its q|k|v|g buffer is what the workspace holds)
+    prefix = "diffusion_conditioning.token_embedder.pairformer.blocks.%d.triangle_col_attention" % (
+        cfg.model.diffusion_conditioning.no_blocks_pairformer - 1)
+    assert prefix + ".linear_q.weight" in P.p
+    bnd = P.attn_static_bounds(prefix, P[prefix + ".norm.weight"]).cpu()
+    Cz = cfg.model.diffusion_conditioning.c_z
+    qkvg = [t for (n, shape, d_), t in eng.ws.bufs.items() if n == "qkvg" and shape[-1] == 4 * Cz][0]
+    for i, nm in enumerate("qkv"):
+        m = float(qkvg[:, i * Cz:(i + 1) * Cz].abs().max())
+        print(f"{prefix} {nm}: max {m:.3g} bound {float(bnd[i]):.3g} (x{float(bnd[i]) / m:.1f})")
+        assert m <= float(bnd[i]) and float(bnd[i]) <= m * 2 ** 9
