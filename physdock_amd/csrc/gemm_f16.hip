@@ -419,13 +419,13 @@ int dispatch_f16(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s,
     if (small) {
         PD_FCASE(0, EPI_PLAIN, F64) PD_FCASE(1, EPI_PLAIN, F64) PD_FCASE(3, EPI_PLAIN, F64)
         PD_FCASE(1, EPI_HN, F64) PD_FCASE(2, EPI_HN, F64) PD_FCASE(3, EPI_HN, F64)
-        PD_FCASE(0, EPI_GATERES, F64) PD_FCASE(3, EPI_GATERES, F64)
+        PD_FCASE(0, EPI_GATERES, F64) PD_FCASE(3, EPI_GATERES, F64) PD_FCASE(0, EPI_TGATERES, F64)
         return PD_ERR_UNSUPPORTED;
     }
     PD_FCASE(0, EPI_PLAIN, F128) PD_FCASE(1, EPI_PLAIN, F128) PD_FCASE(3, EPI_PLAIN, F128)
     PD_FCASE(1, EPI_HN, F128) PD_FCASE(2, EPI_HN, F128) PD_FCASE(3, EPI_HN, F128)
     PD_FCASE(1, EPI_GLU, F128G) PD_FCASE(2, EPI_GLU, F128G) PD_FCASE(3, EPI_GLU, F128GD)
-    PD_FCASE(0, EPI_GATERES, F128) PD_FCASE(3, EPI_GATERES, F128)
+    PD_FCASE(0, EPI_GATERES, F128) PD_FCASE(3, EPI_GATERES, F128) PD_FCASE(0, EPI_TGATERES, F128)
 #undef PD_FCASE
     return PD_ERR_UNSUPPORTED;
 }
@@ -464,7 +464,7 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
     if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
     else if (p.hn_w) epi = (p.mul || p.res || p.act) ? -1 : EPI_HN;
     else if (p.res) {
-        epi = (p.mul && p.mul_rows_per_group <= 0) ? -1 : EPI_GATERES;
+        epi = (p.mul && p.mul_rows_per_group <= 0) ? EPI_TGATERES : EPI_GATERES;      // gate: one row per group, or a tensor (ldmul)
         if (p.act || p.res_row_mod > 0) epi = -1;
         if (p.mul && p.mul_rows_per_group > 0 && p.mul_rows_per_group % 64 != 0) epi = -1;
     } else epi = p.mul ? -1 : EPI_PLAIN;

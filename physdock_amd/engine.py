@@ -93,6 +93,11 @@ class Engine:
             return None
         return self.P.attn_static_bounds(prefix, norm_weight)
 
+    @staticmethod
+    def o_bound(bounds):
+        """device address of the v bound inside a (q, k, v) bound vector = bound of the attention output (a convex combination of v rows)"""
+        return None if (bounds is None or not (ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM)) else bounds.data_ptr() + 8
+
     def lws(self, name, *shape, dtype=torch.float32):
         """lane-private scratch: concurrent sample lanes never share a DiT intermediate"""
         return self.ws.get(f"{name}@{self.lane}", *shape, dtype=dtype)
@@ -145,9 +150,9 @@ class Engine:
         st4 = (N * 4 * C, 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=nk or N, nbatch=nbatch, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias, bias_nk=N,
-                      ws=self.attn_ws(nbatch, N, nk or N, H), f16_amax=self.trunk_attn_bounds(prefix, P[f"{prefix}.{norm_name}.weight"]))
+                      ws=self.attn_ws(nbatch, N, nk or N, H), f16_amax=(bnd := self.trunk_attn_bounds(prefix, P[f"{prefix}.{norm_name}.weight"])))
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
-        self.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s)
+        self.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s, a_amax=self.o_bound(bnd))
 
     def transition(self, prefix, x, rows, C):
         """x += W2(silu(W1 RMSNorm(x)) * W3 RMSNorm(x))                    (transitions.py:15-18)"""
@@ -157,7 +162,9 @@ class Engine:
         h = self.ws.get("ffn_h", rows, hidden)
         self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_w=P[prefix + ".ffn_norm.weight"], glu=1)
         W2, _, _, _, ldw = P.linear(prefix + ".feed_forward.w2")
-        self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, res=x)
+        hb = P.glu_hidden_bound(prefix + ".feed_forward", P[prefix + ".ffn_norm.weight"]) \
+            if (ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM) else None
+        self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, res=x, a_amax=hb)
 
     def triangle_update(self, prefix, z, T, C, mask, transpose):
         """z += TriangleUpdate(z)                                          (attentions.py:157-171)"""
@@ -204,9 +211,9 @@ class Engine:
             st4, sto = (4 * C, T * 4 * C), (C, T * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T,
-                      f16_amax=self.trunk_attn_bounds(prefix, nw))
+                      f16_amax=(bnd := self.trunk_attn_bounds(prefix, nw)))
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
-        self.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z)
+        self.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z, a_amax=self.o_bound(bnd))
 
     def triangle_block(self, prefix, z, T, C, mask, maskT):
         """layers/transformers.py:48-54.  The reference transposes z for the column variants but NOT the mask
@@ -411,9 +418,9 @@ class Engine:
         st4 = (4 * C, T * 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=S, nk=S, nbatch=T, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(C, T * C), bias=None,
-                      f16_amax=self.trunk_attn_bounds(prefix, P[prefix + ".norm_m.weight"]))
+                      f16_amax=(bnd := self.trunk_attn_bounds(prefix, P[prefix + ".norm_m.weight"])))
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
-        self.gemm(o, Wo, m, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=m)
+        self.gemm(o, Wo, m, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=m, a_amax=self.o_bound(bnd))
 
     def outer_product_mean(self, prefix, m, z, S, T, Cm, Cz):
         """z += RMSNorm(W_o . sum_s q_s (x) k_s + b)                       (outer_product_mean.py:23-31)"""

@@ -193,6 +193,9 @@ KV_PRESPLIT = True
 #: trunk attention (triangle, MSA row / column, pair-biased single / atom attention) on the fp16-parts kernel with STATIC bounds
 #: of q, k, v from the projection weights and the norm gain (packing.attn_static_bounds); False: bf16 x 6 as in round 2
 F16_TRUNK_ATTN = True
+#: ... and the projections that consume the attention output (|o| <= max|v|) and the SwiGLU hidden activations of the trunk's
+#: transitions (packing.glu_hidden_bound) on the fp16-format GEMM
+F16_TRUNK_GEMM = True
 
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None

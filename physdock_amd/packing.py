@@ -164,6 +164,16 @@ class PackedWeights:
             return torch.tensor(out, dtype=torch.float32, device=norm_weight.device)
         return self._c(("attn_bounds", prefix, norm_weight.data_ptr()), mk)
 
+    def glu_hidden_bound(self, prefix, norm_weight):
+        """device scalar: rigorous upper bound of |silu(W1 y) (W3 y)| for y = x^ w, ||x^||_2 <= sqrt(C) (RMS- / LayerNorm-ed row
+        times the static gain): |silu(a)| <= |a|, so |h_n| <= ||W1_n w||_2 ||W3_n w||_2 C - weights only, any input"""
+        def mk():
+            w = norm_weight.double()
+            W1, W3 = self.p[prefix + ".w1.weight"].double(), self.p[prefix + ".w3.weight"].double()
+            b = float(((W1 * w[None, :]).norm(dim=1) * (W3 * w[None, :]).norm(dim=1)).max()) * W1.shape[1] * 1.0001
+            return torch.tensor([b], dtype=torch.float32, device=norm_weight.device)
+        return self._c(("glu_h_bound", prefix, norm_weight.data_ptr()), mk)
+
     def qkv(self, prefix):
         return self._c(("qkv", prefix), lambda: torch.cat(
             [self.p[f"{prefix}.linear_{c}.weight"] for c in "qkv"], 0).contiguous())

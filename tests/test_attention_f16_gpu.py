@@ -265,7 +265,7 @@ def test_trunk_attention_on_static_bounds():
     L = ops._lib.init()
     outs, variants = {}, {}
     for flag in (True, False):
-        ops.F16_TRUNK_ATTN = flag
+        ops.F16_TRUNK_ATTN = ops.F16_TRUNK_GEMM = flag        # (the projections that consume o and the transitions' hidden rows too)
         seen = []
         ops.ATTN_HOOK = lambda a, launch: (seen.append(L.pd_attention_variant(C_.byref(a))), launch())
         try:
@@ -273,7 +273,7 @@ def test_trunk_attention_on_static_bounds():
             outs[flag] = (a_.clone(), s_.clone(), z_.clone())
         finally:
             ops.ATTN_HOOK = None
-            ops.F16_TRUNK_ATTN = True
+            ops.F16_TRUNK_ATTN = ops.F16_TRUNK_GEMM = True
         variants[flag] = list(seen)
     n16 = sum(v >= 2000 for v in variants[True])
     nbf = sum(1000 <= v < 2000 for v in variants[False])

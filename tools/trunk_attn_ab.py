@@ -1,3 +1,4 @@
+"""lab: conditioning trunk with / without the static-bound fp16 paths (attention; linear_o and transition w2 GEMMs), same process"""
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -10,7 +11,7 @@ cfg, P, batch, dbatch, confs, model = bench.build_inputs(args, dev)
 eng = model.engine(dev)
 b = model._prepare_batch(dbatch)
 for flag in (True, False, True, False):
-    ops.F16_TRUNK_ATTN = flag
+    ops.F16_TRUNK_ATTN = ops.F16_TRUNK_GEMM = flag
     for _ in range(2):
         eng.conditioning(b)
     torch.cuda.synchronize()
@@ -18,4 +19,4 @@ for flag in (True, False, True, False):
     for _ in range(5):
         eng.conditioning(b)
     torch.cuda.synchronize()
-    print(f"F16_TRUNK_ATTN={flag}: conditioning {1e3 * (time.perf_counter() - t0) / 5:.2f} ms")
+    print(f"F16_TRUNK_ATTN = F16_TRUNK_GEMM = {flag}: conditioning {1e3 * (time.perf_counter() - t0) / 5:.2f} ms")
