@@ -424,7 +424,7 @@ int dispatch_f16(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s,
     }
     PD_FCASE(0, EPI_PLAIN, F128) PD_FCASE(1, EPI_PLAIN, F128) PD_FCASE(3, EPI_PLAIN, F128)
     PD_FCASE(1, EPI_HN, F128) PD_FCASE(2, EPI_HN, F128) PD_FCASE(3, EPI_HN, F128)
-    PD_FCASE(1, EPI_GLU, F128G) PD_FCASE(2, EPI_GLU, F128G) PD_FCASE(3, EPI_GLU, F128GD)
+    PD_FCASE(1, EPI_GLU, F128G) PD_FCASE(2, EPI_GLU, F128G) PD_FCASE(3, EPI_GLU, F128GD) PD_FCASE(1, EPI_GLUT, F128G)
     PD_FCASE(0, EPI_GATERES, F128) PD_FCASE(3, EPI_GATERES, F128) PD_FCASE(0, EPI_TGATERES, F128)
 #undef PD_FCASE
     return PD_ERR_UNSUPPORTED;
@@ -452,16 +452,20 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
         if (pro != 0 || p.pro_act != PD_ACT_NONE || p.K % 32 != 0 || ((uintptr_t)p.A2 & 15)) return PD_ERR_UNSUPPORTED;
         pro = 3;
     }
-    if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || p.out_mode != PD_OUT_ROWMAJOR) return PD_ERR_UNSUPPORTED;
+    // transposed GLU output (the triangle update's gated q | k projections): the rule of gemm_split.hip
+    const bool glut = p.out_mode == PD_OUT_TRANSPOSED && p.glu && !p.hn_w && !p.mul && !p.res && !p.act && !p.rowscale_acc &&
+                      !p.maskadd && p.out_scale == 1.f && p.vecY && (!p.rowscale || ((uintptr_t)p.rowscale & 15) == 0) && !p.A2 && !p.Y2;
+    if (p.a_kmajor || p.w_kmajor || !p.vecA || p.batch != 1 || (p.out_mode != PD_OUT_ROWMAJOR && !glut)) return PD_ERR_UNSUPPORTED;
     if (((uintptr_t)p.W2 & 15) != 0 || p.N % 128 != 0 || p.M % 64 != 0) return PD_ERR_UNSUPPORTED;
     // 128 x 128 tiles when they fill the chip, else 64 x 128 tiles if there are enough of THOSE; smaller launches are latency-bound
     // (k-split fp32 kernel).  The caller's tile (its 64 x 64 choice below 192 row/column blocks) only says the rows come in 64s.
     const long long t128 = p.M % 128 == 0 ? (long long)(p.M / 128) * (p.N / 128) : 0, t64 = (long long)(p.M / 64) * (p.N / 128);
     if (t128 < PD_F16_MIN_TILES && t64 < PD_F16_MIN_TILES_SMALL) return PD_ERR_UNSUPPORTED;
     const bool small = t128 < PD_F16_MIN_TILES;
-    if (p.rowscale_acc || p.rowscale || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
+    if (p.rowscale_acc || (p.rowscale && !glut) || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
-    if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
+    if (glut) epi = small ? -1 : EPI_GLUT;
+    else if (p.glu) epi = (p.hn_w || p.mul || p.res || p.act) ? -1 : EPI_GLU;
     else if (p.hn_w) epi = (p.mul || p.res || p.act) ? -1 : EPI_HN;
     else if (p.res) {
         epi = (p.mul && p.mul_rows_per_group <= 0) ? EPI_TGATERES : EPI_GATERES;      // gate: one row per group, or a tensor (ldmul)

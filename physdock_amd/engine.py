@@ -67,14 +67,15 @@ class Engine:
                 and not kw.get("a_kmajor") and not kw.get("w_kmajor") and N % 64 == 0 \
                 and (kw.get("out_mode", 0) == 0 or (kw.get("out_mode") == OUT_TRANSPOSED and kw.get("glu"))):
             w3 = self.P.w3(W, K)
-        if kw.get("a_amax") is None and w3 is not None and ops.F16_GEMM and ops.F16_NORM_BOUND and kw.get("out_mode", 0) == 0 \
+        rowmajor_or_glut = kw.get("out_mode", 0) == 0 or (kw.get("out_mode") == OUT_TRANSPOSED and kw.get("glu"))
+        if kw.get("a_amax") is None and w3 is not None and ops.F16_GEMM and ops.F16_NORM_BOUND and rowmajor_or_glut \
                 and kw.get("stats") is not None and not kw.get("pro_rows_per_group") \
                 and all(v is None or isinstance(v, torch.Tensor) for v in (kw.get("pro_w"), kw.get("pro_b"))):
             # a norm prologue with STATIC gain / shift bounds its own output for any input: |x^_k| <= sqrt(K) after RMSNorm or
             # LayerNorm, so |x^ w + b| <= sqrt(K) max|w| + max|b| (an activation in the prologue only shrinks it) - the trunk's
             # normalised projections take the two-part fp16 format on this bound
             kw["a_amax"] = self.P.norm_bound(kw.get("pro_w"), kw.get("pro_b"), K)
-        if kw.get("a_amax") is not None and w3 is not None and ops.F16_GEMM and kw.get("out_mode", 0) == 0:
+        if kw.get("a_amax") is not None and w3 is not None and ops.F16_GEMM and rowmajor_or_glut:
             # the caller knows an upper bound of |A'|: two-part fp16 operands (three MFMA products instead of six)
             kw["W2"] = self.P.w2(W, K)
         else:
