@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--cfg", default="cfg1", choices=["cfg1", "cfg2", "small"])
     ap.add_argument("--no-physics", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="full", choices=["full", "quick"],
+                    help="full: B = 1 measured with 3 complete oracle calls (about 3 minutes of host time); quick: extrapolated only")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the B=1 / B=20 / cfg2 / MMFF / screening side measurements")
@@ -98,6 +100,20 @@ def usable_cores():
     return n
 
 
+def physical_cores():
+    """distinct (socket, core) pairs of the box (None when /proc/cpuinfo does not say)"""
+    try:
+        pairs, sock = set(), "0"
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                sock = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((sock, line.split(":", 1)[1].strip()))
+        return len(pairs) or None
+    except OSError:
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -109,11 +125,12 @@ def cpu_model():
 
 
 def cpu_baseline(cfg, P, batch, confs, args):
-    """BASELINE.md section 3 on a bounded sample: the CPU oracle (torch CPU fp32, all usable cores) on the same synthetic
-    crop, seeded weights and physics branch (template projection, 40 conformers, factor 6); B in {1, 20}; 1 warm-up + 3
-    timed repeats, medians.  A full call is 1 trunk + 40 steps (minutes of CPU per repeat), so the trunk is timed on its
-    own and the loop through 2-step sampler calls (augmentation, denoiser, template match, Kabsch, Euler update all
-    inside); call time = t_trunk + 40 * t_step.  `value` is the B = 20 figure (the demo's samples per round)."""
+    """the CPU oracle (torch CPU fp32, all usable cores) on the same synthetic crop, seeded weights and
+    physics branch (template projection, 40 conformers, factor 6).
+    B = 1 is MEASURED by the book: one warm-up + 3 timed COMPLETE calls (conditioning trunk + all `diffusion_steps` steps inside the
+    timed region), median - `value`, `extrapolated: false`.  B = 20 (the demo's samples per round; minutes per call) stays a
+    labelled extrapolation: trunk timed on its own, the loop through 2-step sampler calls, call = t_trunk + steps * t_step.
+    --cpu-baseline quick skips the full B = 1 calls (then `value` is the extrapolated B = 1 figure and says so)."""
     import statistics
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import physdock_oracle as orc
@@ -122,34 +139,53 @@ def cpu_baseline(cfg, P, batch, confs, args):
     n = args.diffusion_steps
     A = batch["ref_pos"].shape[0]
     t_all = time.perf_counter()
+    phys = dict(align_ref_pos=True, ref_mol_poses=confs, mmff_gamma_0_factor=6.0, karras_noise_schedule_power=1000)
+
+    def draws(B, k, n_noisy, seed):
+        g = torch.Generator().manual_seed(seed)
+        return {"init": torch.randn(B, A, 3, generator=g), "rot_u": torch.rand(k, 4, B, generator=g),
+                "trans": torch.randn(k, B, 3, generator=g), "diffuse": torch.randn(n_noisy, B, A, 3, generator=g)}
     with torch.no_grad():
         tt = []
-        for rep in range(3):                                   # 1 warm-up + 2 timed (32 s each on 16 cores)
+        for rep in range(2):                                   # 1 warm-up + 1 timed (the full calls below time the trunk 3 more times)
             t0 = time.perf_counter()
             cond = orc.diffusion_conditioning(P, batch)
             tt.append(time.perf_counter() - t0)
-        t_trunk = statistics.median(tt[1:])
+        t_trunk = tt[-1]
         by_b = {}
         for B in (1, 20):
-            g = torch.Generator().manual_seed(0)
             k = 2
-            noise = {"init": torch.randn(B, A, 3, generator=g), "rot_u": torch.rand(k, 4, B, generator=g),
-                     "trans": torch.randn(k, B, 3, generator=g), "diffuse": torch.randn(k, B, A, 3, generator=g)}
+            noise = draws(B, k, k, 0)
             ts = []
-            for rep in range(4):                               # 1 warm-up + 3 timed
+            for rep in range(4 if B == 20 else 2):             # 1 warm-up + 3 timed (B = 1: warm-up + 1; it is measured in full below)
                 t0 = time.perf_counter()
-                orc.sample_diffusion(P, batch, noise, num_sample=B, steps=k, conditioning=cond, align_ref_pos=True,
-                                     ref_mol_poses=confs, mmff_gamma_0_factor=6.0, karras_noise_schedule_power=1000)
+                orc.sample_diffusion(P, batch, noise, num_sample=B, steps=k, conditioning=cond, **phys)
                 ts.append((time.perf_counter() - t0) / k)
             t_step = statistics.median(ts[1:])
-            by_b[str(B)] = {"poses_per_s": B / (t_trunk + n * t_step), "t_step_s": t_step}
-    return {"value": by_b["20"]["poses_per_s"], "unit": "poses/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            by_b[str(B)] = {"poses_per_s": B / (t_trunk + n * t_step), "t_step_s": t_step, "extrapolated": True}
+        full = None
+        if args.cpu_baseline == "full":
+            n_noisy = int((orc.karras_noise_schedule(n, p=1000)[:-1] > 1.0).sum())
+            tf = []
+            for rep in range(3):                               # complete calls: trunk + n steps, nothing reused (the 2-step calls above were the warm-up)
+                noise = draws(1, n, n_noisy, 10 + rep)
+                t0 = time.perf_counter()
+                orc.sample_diffusion(P, batch, noise, num_sample=1, steps=n, **phys)
+                tf.append(time.perf_counter() - t0)
+            full = statistics.median(tf)
+            by_b["1"] = {"poses_per_s": 1.0 / full, "call_s": full, "calls_timed": 3, "call_times_s": [round(t, 2) for t in tf],
+                         "extrapolated": False, "extrapolated_estimate_poses_per_s": by_b["1"]["poses_per_s"], "t_step_s": by_b["1"]["t_step_s"]}
+    phys_cores = physical_cores()
+    return {"value": by_b["1"]["poses_per_s"], "unit": "poses/s", "cores": cores, "cores_used": cores, "cores_physical": phys_cores,
+            "kind": "port", "cpu_model": cpu_model(), "samples": 1,
             "by_samples": by_b, "t_trunk_s": t_trunk, "wall_s": time.perf_counter() - t_all,
-            "extrapolated": True, "trunk_repeats_timed": 2, "loop_steps_per_timed_call": 2,
-            "sample": f"oracle (torch CPU fp32, {cores} threads, {cpu_model()}): conditioning trunk 1 warm-up + 2 timed "
-                      f"(median {t_trunk:.1f} s); reverse-diffusion loop as 2-step sampler calls with the template-projection "
-                      f"physics branch, 1 warm-up + 3 timed per B in (1, 20) (median {by_b['1']['t_step_s']:.2f} / "
-                      f"{by_b['20']['t_step_s']:.2f} s per step); poses/s = B / (t_trunk + {n} * t_step); value = B = 20"}
+            "extrapolated": full is None,
+            "sample": f"oracle (torch CPU fp32, {cores} threads of {cpu_model()}, {phys_cores} physical cores on the box): "
+                      + (f"value = B = 1 measured: 3 complete sample_diffusion calls (trunk + {n} steps with the template-projection physics "
+                         f"branch inside the timed region), median {full:.1f} s per call; " if full is not None else
+                         "value = B = 1 extrapolated (--cpu-baseline quick); ")
+                      + f"B = 20 extrapolated (labelled): trunk {t_trunk:.1f} s + {n} x {by_b['20']['t_step_s']:.2f} s per step from 2-step sampler calls "
+                        f"(1 warm-up + 3 timed) = {by_b['20']['poses_per_s']:.3f} poses/s"}
 
 
 class LaunchTimer:
@@ -214,7 +250,9 @@ class LaunchTimer:
         def attn_hook(a, launch):
             v = L.pd_attention_variant(C.byref(a))          # 4 / 8 waves per block, or 4 + 100 * key chunks
             name = "attn_kernel<%d, %s>" % (v % 100, "true" if v > 100 else "false")
-            if v >= 2000:       # fp16 matrix pipe, two-part operands, three products per block (csrc/attn_f16.hip)
+            if v >= 3000:       # the software-pipelined form (csrc/attn_pipe.hip): waves, K / V pre-split, bias as the accumulator's initial value
+                name = "attn_pipe_kernel<%d, %s, %s>" % (v % 100, "true" if a.K2 else "false", "true" if a.bias else "false")
+            elif v >= 2000:     # fp16 matrix pipe, two-part operands, three products per block (csrc/attn_f16.hip)
                 # template arguments as rocprofv3 prints them: waves, parts, K / V pre-split (K2 / V2), key-split launch
                 name = "attn_parts_kernel<%d, 2, %s, %s>" % (v % 100, "true" if a.K2 else "false", "true" if v % 1000 > 100 else "false")
             elif v >= 1000:     # bf16 matrix pipe, three-part operands, six products per block (csrc/attn_split.hip)
@@ -264,11 +302,24 @@ class LaunchTimer:
         return sorted(out, key=lambda d: -d["total_s"])
 
 
+class _DryRunSampler:
+    """stand-in for PhysDock on the CPU (PD_BENCH_DRYRUN): poses are a deterministic function of (seed, global sample id), as the
+    Philox-keyed sampler's are, so the rank-block checks of the real run apply unchanged"""
+
+    def __init__(self, A):
+        self.A = A
+
+    def sample_diffusion(self, batch, num_sample=1, seed=0, sample_offset=0, **kw):
+        rows = [torch.randn(self.A, 3, generator=torch.Generator().manual_seed(1000003 * seed + sample_offset + i))
+                for i in range(num_sample)]
+        return torch.stack(rows)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU) via torch.distributed.run
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and os.environ.get("PD_BENCH_DRYRUN") != "1":
             sys.exit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -280,21 +331,34 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the two must agree (one rank per GPU)")
     dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # launched by torch.distributed.run
+    # PD_BENCH_DRYRUN=1 (tests/test_distributed_cpu.py): the same launcher / rank / gather / max-over-ranks / JSON code on the gloo
+    # backend with a stand-in sampler on the CPU - so that the first real multi-GPU run cannot die on argument plumbing
+    dry = os.environ.get("PD_BENCH_DRYRUN") == "1"
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        td.init_process_group("nccl")
-    device = torch.device("cuda", local if dist else 0)
-    torch.cuda.set_device(device)
+        if not dry:
+            torch.cuda.set_device(local)
+        td.init_process_group("gloo" if dry else "nccl")
+    device = torch.device("cpu") if dry else torch.device("cuda", local if dist else 0)
+    if dry:
+        torch.cuda.synchronize = lambda *a, **k: None
+        args.no_roofline = args.no_extra = args.no_cpu_baseline = True
+    else:
+        torch.cuda.set_device(device)
 
     if os.environ.get("PD_BENCH_TWEAK"):          # lab A/B runs (tools/ab_f16.sh): "NAME=value,..." sets physdock_amd.ops switches
         from physdock_amd import ops as _o
         for kv in os.environ["PD_BENCH_TWEAK"].split(","):
             k_, v_ = kv.split("=")
             setattr(_o, k_, {"True": True, "False": False}.get(v_, int(v_) if v_.isdigit() else v_))
-    cfg, P, batch, dbatch, confs, model = build_inputs(args, device)
+    if dry:
+        from physdock_amd import synthetic
+        batch = {"small": synthetic.small_batch, "cfg1": synthetic.cfg1_batch, "cfg2": synthetic.cfg2_batch}[args.cfg](0)
+        dbatch, confs, model = batch, torch.zeros(1, 1, 3), _DryRunSampler(batch["ref_pos"].shape[0])
+    else:
+        cfg, P, batch, dbatch, confs, model = build_inputs(args, device)
     B, nsteps = args.samples, args.diffusion_steps
     A = batch["ref_pos"].shape[0]
     kw = dict(num_sample=B, steps=nsteps, karras_noise_schedule_power=1000, use_graph=not args.no_graph)
@@ -348,7 +412,7 @@ def main():
         "metric": "poses/sec (whole node) at crop_size=256, atom_crop_size=2048",
         "value": value, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (fp16x2-split operands x3 MFMA / bf16x3-split x6 MFMA, fp32 accumulate)", "data": "synthetic",
         "arithmetic": "fp32 results; chip-filling contractions run on split operands with fp32 accumulation: where a rigorous "
                       "bound of |A| is known before the launch (the DiT blocks: LayerNorm + AdaLN table, pd_dit_bounds) as two "
                       "fp16 parts of the power-of-two scaled value / three MFMAs per block (22 significand bits), elsewhere as "
@@ -380,7 +444,7 @@ def main():
             summ = lt.summary()
         dom = summ[0]
         traffic, traffic_src = None, None
-        for tag in ("r03", "r02"):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same call (tools/collect_profiles.sh)
+        for tag in ("r04", "r03", "r02"):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same call (tools/collect_profiles.sh)
             pmc = os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")
             if os.path.exists(pmc) and args.cfg == "cfg1" and B == 64:
                 allrows = json.load(open(pmc))
@@ -519,7 +583,9 @@ def main():
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, P, batch, confs, args)
-        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        best = max(v["poses_per_s"] for v in out["cpu_baseline"]["by_samples"].values())
+        out["gpu_over_cpu"] = value / best        # against the CPU's BEST figure (B = 20, extrapolated), not the measured B = 1 value
+        out["gpu_over_cpu_basis"] = "GPU value (B = %d) / max over the CPU rows (B = 1 measured, B = 20 extrapolated)" % B
     if rank == 0:
         print(json.dumps(out))
     if dist:

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 6
+#define PD_ABI_VERSION 7
 
 enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFRAG = 3 };
 
@@ -150,6 +150,8 @@ typedef struct pd_transition_args {
     float eps;
     const void* W13; const float* w13_inv; const void* W2; const float* w2_inv;
     const float* y_amax; const float* h_amax;
+    int rms;                     /* ABI 7: 1 = RMSNorm instead of LayerNorm (no mean subtraction): with shift = zeros, scale1p = the norm
+                                    gain and gate = ones this is the trunk's pair Transition (transitions.py:15-18) on [T*T][128] rows  */
 } pd_transition_args;
 int pd_transition_f16(const pd_transition_args* args, void* stream);
 
@@ -201,6 +203,12 @@ typedef struct pd_attn_args {
     const void* K2;
     const void* V2;
     long long kv2_bs, kv2_ss;
+    /* ABI 7, f16x3 launches only: > 0 = the bias fragments were produced ALREADY MULTIPLIED by this power of two - the product of
+       the q and k operand scales the kernel derives from f16_amax[0..1] (pd_attention_bias_prescale_log2 computes its exponent
+       from the same bounds on the host; the producer folds it into out_scale).  The pipelined kernel (csrc/attn_pipe.hip) then
+       takes the bias tile as the INITIAL VALUE of the score accumulator - no bias add.  0 with a bias: the launch stays on
+       attn_parts_kernel (csrc/attn_f16.hip), which adds an unscaled bias; < 0: keep the launch on attn_parts_kernel (A/B runs).   */
+    float bias_prescale;
 } pd_attn_args;
 /* Launches that cannot fill the chip (nbatch * nheads * ceil(nq/128) < 512 blocks) with a long key range are split into
  * up to 8 key chunks when ws holds nsplit * nbatch * nq * nheads * 34 floats; a second kernel merges the chunks. */
@@ -209,6 +217,10 @@ int pd_attention(const pd_attn_args* args, void* stream);
  * a key-split launch; 1000 + waves for attn_split_kernel<waves>, 2000 + waves for attn_parts_kernel<waves, 2>, 2000 + 4 +
  * 100 * nsplit for a key-split launch on attn_parts_kernel<4, 2, false, true> (profiling) */
 int pd_attention_variant(const pd_attn_args* args);
+/* log2 of the power of two a bias producer folds into out_scale for f16x3 launches with bias_prescale (ABI 7): the q and k operand
+ * scales of the fp16 format for these bounds (scale = 1/sqrt(32)); host arithmetic identical to the kernel's.  3000 + waves =
+ * attn_pipe_kernel<waves, ., .> in pd_attention_variant's numbering.                                                        */
+int pd_attention_bias_prescale_log2(float q_amax, float k_amax, float scale);
 
 /* ---- pair-representation / pooling kernels (pair.hip) ----------------------------------
  * pd_atom_pair_init : ap = cl_l + cm_m + v*(Wp.d + Wd/(1+|d|) + Wv)   (diffusion_conditioning.py:116-124)

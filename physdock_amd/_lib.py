@@ -73,6 +73,7 @@ class AttnArgs(C.Structure):
         ("ws", _fp), ("ws_bytes", C.c_longlong), ("nsplit", C.c_int),
         ("f16x3", C.c_int), ("f16_q_amax", C.c_float), ("f16_k_amax", C.c_float), ("f16_v_amax", C.c_float), ("f16_amax", _fp), ("O2", _fp),
         ("K2", _fp), ("V2", _fp), ("kv2_bs", C.c_longlong), ("kv2_ss", C.c_longlong),      # ABI 6
+        ("bias_prescale", C.c_float),                                                       # ABI 7
     ]
 
 
@@ -80,7 +81,8 @@ class TransitionArgs(C.Structure):
     """mirror of pd_transition_args"""
     _fields_ = [("x", _fp), ("M", C.c_int), ("C", C.c_int), ("hidden", C.c_int),
                 ("shift", _fp), ("scale1p", _fp), ("gate", _fp), ("rows_per_group", C.c_int), ("gstride", C.c_int),
-                ("eps", C.c_float), ("W13", _fp), ("w13_inv", _fp), ("W2", _fp), ("w2_inv", _fp), ("y_amax", _fp), ("h_amax", _fp)]
+                ("eps", C.c_float), ("W13", _fp), ("w13_inv", _fp), ("W2", _fp), ("w2_inv", _fp), ("y_amax", _fp), ("h_amax", _fp),
+                ("rms", C.c_int)]
 
 
 class HipLibraryMissing(RuntimeError):
@@ -133,6 +135,7 @@ def _declare(L):
     sig("pd_pair_bias", p, p, p, p, p, f, f, p, i, i, i, i, i, i, f, p)
     sig("pd_attention", C.POINTER(AttnArgs), p)
     sig("pd_attention_variant", C.POINTER(AttnArgs))
+    sig("pd_attention_bias_prescale_log2", f, f, f)
     sig("pd_graph_begin", p)
     sig("pd_graph_end", p, C.POINTER(C.c_void_p))
     sig("pd_graph_launch", p, p)

@@ -33,7 +33,9 @@ def needs_build():
 #: Scalar f32 VALU is also what the CDNA guide recommends beside MFMAs.
 #: tests/test_gemm_split_gpu.py::test_split_multi_tile_stress and tests/test_concurrent_streams_gpu.py guard it.
 NO_PACKED_F32 = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-EXTRA_FLAGS = {}
+#: attn_pipe.hip: fmaxf without the sNaN-quieting v_max_f32 x, x in front of every operand (no NaN can enter the running maximum:
+#: scores are finite or -inf); infinities stay honoured (-inf masks, the initial maximum)
+EXTRA_FLAGS = {"attn_pipe.hip": ["-fno-honor-nans"]}
 
 
 def compile_cmd(src, out, mode=("-c",)):
@@ -73,6 +75,8 @@ def compile_cmd(src, out, mode=("-c",)):
         cmd[1:1] = ["-DPD_ATTN_LAZY=" + os.environ["PD_ATTN_LAZY"]]
     if os.environ.get("PD_ATTN_ABL") and base == "attn_f16.hip":      # lab: VALU ablations of the fp16-parts attention (wrong results)
         cmd[1:1] = ["-DPD_ATTN_ABL=" + os.environ["PD_ATTN_ABL"]]
+    if os.environ.get("PD_PIPE_ABL") and base == "attn_pipe.hip":      # lab: timing ablations of the pipelined attention (wrong results)
+        cmd[1:1] = ["-DPD_PIPE_ABL=" + os.environ["PD_PIPE_ABL"]]
     if os.environ.get("PD_TRANSITION_BM") and base == "transition_f16.hip":     # lab: 128-row tiles, one block per CU
         cmd[1:1] = ["-DPD_TRANSITION_BM=" + os.environ["PD_TRANSITION_BM"]]
     for knob in ("PD_SPLIT_MIN_TILES", "PD_SPLIT_MIN_TILES_SMALL"):
@@ -83,8 +87,9 @@ def compile_cmd(src, out, mode=("-c",)):
     return cmd
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, only=None):
+    """only: names of the sources to recompile (lab loops on the GPU box: the other objects of the last full build are reused)"""
+    if not force and not only and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
@@ -93,6 +98,8 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
+        if only and os.path.basename(src) not in only and os.path.exists(obj):
+            continue
         procs.append((src, subprocess.Popen(compile_cmd(src, obj), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, pr in procs:
         out, _ = pr.communicate()
@@ -107,4 +114,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, only=[a for a in sys.argv[1:] if a.endswith(".hip")] or None)

@@ -281,6 +281,9 @@ static int attn_nsplit(const pd_attn_args* a) {
 extern "C" int pd_attention_split_try(const pd_attn_args* a, void* stream, int init_only);
 // attn_f16.hip: key-split launch of the fp16-parts kernel (partials in the combine kernel's format)
 extern "C" int pd_attention_f16_split(const pd_attn_args* a, void* stream, int init_only);
+// attn_pipe.hip: the software-pipelined form of the fp16-parts kernel (bias as the accumulator's initial value)
+extern "C" int pd_attention_pipe_ok(const pd_attn_args* a);
+extern "C" int pd_attention_pipe_try(const pd_attn_args* a, void* stream, int init_only);
 
 // waves per block pd_attention uses for these arguments (= template argument of attn_kernel; for profiling)
 PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
@@ -288,7 +291,7 @@ PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
     // the bf16 split-operand kernel pays off when the launch fills the chip (>= one 32-query wave per SIMD); smaller launches
     // are latency-bound and stay on the fp32-MFMA kernel (with its key-split option)
     if (!a->fp32_mfma && attn_nsplit(a) <= 1 && (long long)a->nbatch * a->nheads * ((a->nq + 31) / 32) >= PD_ATTN_MIN_WAVES)
-        return (a->f16x3 ? 2000 : 1000) + (a->nq > 128 ? 8 : 4);      // 2000 +: two-part fp16 operands (attn_f16.hip)
+        return (a->f16x3 ? (pd_attention_pipe_ok(a) ? 3000 : 2000) : 1000) + (a->nq > 128 ? 8 : 4);      // 2000 +: two-part fp16 operands (attn_f16.hip); 3000 +: pipelined (attn_pipe.hip)
 #ifdef PD_LAB
     static const int wide = [] { const char* e = getenv("PD_ATTN_WIDE"); return e ? atoi(e) : 1; }();
 #else
@@ -321,6 +324,7 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s);
         return pd_check_launch();
     }
+    if (variant >= 3000) return pd_attention_pipe_try(a, stream, 0);
     if (variant >= 1000) return pd_attention_split_try(a, stream, 0);
     if (variant > 100) {
         if (((uintptr_t)a->ws & 15) != 0) return PD_ERR_UNSUPPORTED;
@@ -348,7 +352,10 @@ extern "C" __attribute__((visibility("default"))) int pd_lab_set_attn_trace(void
 #endif
 
 // resident blocks per CU the runtime computes for the kernel (diagnostic, tools/attn_trace.py)
-extern "C" int pd_attention_init(void) { return pd_attention_split_try(nullptr, nullptr, 1); }
+extern "C" int pd_attention_init(void) {
+    const int r = pd_attention_pipe_try(nullptr, nullptr, 1);
+    return r != PD_OK ? r : pd_attention_split_try(nullptr, nullptr, 1);
+}
 
 PD_EXPORT int pd_attention_occupancy(void) {
     int n = 0;

@@ -100,7 +100,7 @@ void transition_f16_kernel(const pd_transition_args p) {
             }
             s1 += __shfl_xor(s1, 1);
             s1 += __shfl_xor(s1, 2);
-            const float mean = s1 * (1.0f / C_);
+            const float mean = p.rms ? 0.f : s1 * (1.0f / C_);
             float sq = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i)

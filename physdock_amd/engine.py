@@ -94,6 +94,31 @@ class Engine:
             return None
         return self.P.attn_static_bounds(prefix, norm_weight)
 
+    _PS_MEMO = {}
+
+    def attn_prescale(self, qk, nbatch, nq, nk, H, ws=None):
+        """power of two to fold into the out_scale of the bias producer of an attention launch, or 0.0: non-zero exactly when
+        pd_attention would run this launch on the pipelined fp16-format kernel (variant 3000 +), which takes the bias tile - times the
+        product of its q and k operand scales - as the initial value of the score accumulator.  qk: host (|q|, |k|) bounds or None."""
+        if qk is None or not (ops.PIPE_ATTN and ops.F16_ATTN and ops.SPLIT_ATTN):
+            return 0.0
+        key = (float(qk[0]), float(qk[1]), nbatch, nq, nk, H, ws is not None and ws.numel())
+        r = Engine._PS_MEMO.get(key)
+        if r is None:
+            d = 1 << 20
+            v = ops.attention(d, d, d, d, nq=nq, nk=nk, nbatch=nbatch, nheads=H, q_strides=(nq * H * 32, H * 32), k_strides=(nk * H * 32, H * 32),
+                              v_strides=(nk * H * 32, H * 32), o_strides=(nq * H * 32, H * 32), bias=d, bias_nk=nq, ws=ws,
+                              f16_amax=(qk[0], qk[1], 1.0), bias_prescale=1.0, query_only=True)
+            r = ops.attn_bias_prescale(qk[0], qk[1]) if v >= 3000 else 0.0
+            Engine._PS_MEMO[key] = r
+        return r
+
+    def trunk_prescale(self, prefix, norm_weight, nbatch, nq, nk, H):
+        """attn_prescale of a trunk attention (static bounds from the projection weights)"""
+        if self.trunk_attn_bounds(prefix, norm_weight) is None:
+            return 0.0
+        return self.attn_prescale(self.P.attn_static_bounds_host(prefix, norm_weight)[:2], nbatch, nq, nk, H, self.attn_ws(nbatch, nq, nk, H))
+
     @staticmethod
     def o_bound(bounds):
         """device address of the v bound inside a (q, k, v) bound vector = bound of the attention output (a convex combination of v rows)"""
@@ -123,22 +148,23 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ shared blocks
-    def pair_bias(self, prefix, z, T1, T2, C, mask, norm_w, out, transpose=False, norm="norm_z", st_out=None):
+    def pair_bias(self, prefix, z, T1, T2, C, mask, norm_w, out, transpose=False, norm="norm_z", st_out=None, prescale=0.0):
         """bias[h, q, k] = (W_z . RMSNorm(z))[h] + maskbias -> fragment layout (x log2 e).  One streaming pass over z
         (pd_pair_bias) that also leaves the row statistics in `st_out` for the projection GEMM that shares the norm;
         shapes the kernel does not cover go through rowstats + GEMM."""
         P = self.P
         W, _, H, K, ldw = P.linear(prefix + ".linear_z")
+        osc = LOG2E * (prescale if prescale > 0 else 1.0)      # prescale: see attn_prescale (a power of two: exact)
         if ops.pair_bias(z, P.bias_w(prefix, norm), out, T1, T2, C, H, stats_out=st_out, maskadd=mask, maskval=-self.inf,
-                         out_scale=LOG2E, transpose=transpose, mode=RMS, eps=self.eps, only_if_faster=True):
+                         out_scale=osc, transpose=transpose, mode=RMS, eps=self.eps, only_if_faster=True):
             return H
         st = st_out if st_out is not None else self.ws.get(f"stats_pb@{self.lane}", T1 * T2, 2)
         ops.rowstats(z, st, T1 * T2, C, mode=RMS, eps=self.eps)
         self.gemm(z, W, out, T1 * T2, H, C, ldw=ldw, stats=st, pro_w=norm_w, out_mode=OUT_BIASFRAG, T1=T1, T2=T2,
-                  frag_transpose=transpose, maskadd=mask, maskval=-self.inf, out_scale=LOG2E)
+                  frag_transpose=transpose, maskadd=mask, maskval=-self.inf, out_scale=osc)
         return H
 
-    def attention_pair_bias(self, prefix, s, nbatch, N, C, bias, norm_name="norm_s", nk=None):
+    def attention_pair_bias(self, prefix, s, nbatch, N, C, bias, norm_name="norm_s", nk=None, bias_prescale=0.0):
         """s += (W_o . Attn(RMSNorm(s)) + b_o) * (W_g RMSNorm(s) + b_g)   (attentions.py:32-53,76-97)"""
         P = self.P
         rows = nbatch * N
@@ -151,20 +177,30 @@ class Engine:
         st4 = (N * 4 * C, 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=nk or N, nbatch=nbatch, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=(N * C, C), bias=bias, bias_nk=N,
-                      ws=self.attn_ws(nbatch, N, nk or N, H), f16_amax=(bnd := self.trunk_attn_bounds(prefix, P[f"{prefix}.{norm_name}.weight"])))
+                      ws=self.attn_ws(nbatch, N, nk or N, H), f16_amax=(bnd := self.trunk_attn_bounds(prefix, P[f"{prefix}.{norm_name}.weight"])),
+                      bias_prescale=bias_prescale)
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         self.gemm(o, Wo, s, rows, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=s, a_amax=self.o_bound(bnd))
 
     def transition(self, prefix, x, rows, C):
         """x += W2(silu(W1 RMSNorm(x)) * W3 RMSNorm(x))                    (transitions.py:15-18)"""
         P = self.P
-        st = self.stats(x, rows, C, RMS, self.eps)
         W13, hidden = P.glu(prefix + ".feed_forward")
-        h = self.ws.get("ffn_h", rows, hidden)
-        self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_w=P[prefix + ".ffn_norm.weight"], glu=1)
         W2, _, _, _, ldw = P.linear(prefix + ".feed_forward.w2")
-        hb = P.glu_hidden_bound(prefix + ".feed_forward", P[prefix + ".ffn_norm.weight"]) \
-            if (ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM) else None
+        nw = P[prefix + ".ffn_norm.weight"]
+        f16 = ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM
+        hb = P.glu_hidden_bound(prefix + ".feed_forward", nw) if f16 else None
+        # pair rows (C = 128, hidden = 384, >= 32768 of them): the whole transition in ONE launch - RMS statistics, SwiGLU, down-
+        # projection, residual, the hidden activations never leave the CU (the DiT's atom-transition kernel with rms = 1, a zero
+        # shift and a unit gate; static bounds of y and h from the weights)
+        if f16 and ops.FUSED_TRANSITION and ops.FUSED_TRUNK_TRANSITION and W13.shape[1] == C and ldw == hidden \
+                and ops.transition_f16(x, rows, C, hidden, shift=ops.const_vec(0.0, C), scale1p=nw, gate=ops.const_vec(1.0, C),
+                                       W13=P.w2(W13, C), W2=P.w2(W2, hidden), y_amax=P.norm_bound(nw, None, C), h_amax=hb,
+                                       eps=self.eps, rms=True):
+            return
+        st = self.stats(x, rows, C, RMS, self.eps)
+        h = self.ws.get("ffn_h", rows, hidden)
+        self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_w=nw, glu=1)
         self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, res=x, a_amax=hb)
 
     def triangle_update(self, prefix, z, T, C, mask, transpose):
@@ -201,7 +237,8 @@ class Engine:
         # bias first: its streaming pass over z also produces the row statistics of the shared norm
         st = self.ws.get(f"stats@{self.lane}", M, 2)
         bias = self.ws.get("tri_bias", ops.bias_frag_numel(H, T, T), zero=True)
-        self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, norm="norm", st_out=st)
+        ps = self.trunk_prescale(prefix, nw, T, T, self.Tr, H)
+        self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, norm="norm", st_out=st, prescale=ps)
         W, b = P.qkvg(prefix)
         qkvg = self.ws.get("qkvg", M, 4 * C)
         self.gemm(z, W, qkvg, M, 4 * C, C, stats=st, pro_w=nw, bias=b)
@@ -212,7 +249,7 @@ class Engine:
             st4, sto = (4 * C, T * 4 * C), (C, T * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T,
-                      f16_amax=(bnd := self.trunk_attn_bounds(prefix, nw)))
+                      f16_amax=(bnd := self.trunk_attn_bounds(prefix, nw)), bias_prescale=ps)
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         self.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z, a_amax=self.o_bound(bnd))
 
@@ -231,8 +268,9 @@ class Engine:
         abias = self.ws.get("atom_bias", ops.bias_frag_numel(Ca // 32, A, A), zero=True)
         for b in range(no_blocks):
             blk = f"{prefix}.blocks.{b}"
-            self.pair_bias(blk + ".attention", ap, A, A, Cap, ap_mask, P[blk + ".attention.norm_z.weight"], abias)
-            self.attention_pair_bias(blk + ".attention", a, 1, A, Ca, abias, nk=self.Ar)
+            ps = self.trunk_prescale(blk + ".attention", P[blk + ".attention.norm_s.weight"], 1, A, self.Ar, Ca // 32)
+            self.pair_bias(blk + ".attention", ap, A, A, Cap, ap_mask, P[blk + ".attention.norm_z.weight"], abias, prescale=ps)
+            self.attention_pair_bias(blk + ".attention", a, 1, A, Ca, abias, nk=self.Ar, bias_prescale=ps)
             self.transition(blk + ".transition", a, A, Ca)
 
     def pairformer(self, prefix, s, z, T, Cs, Cz, z_mask, z_maskT, no_blocks):
@@ -242,8 +280,9 @@ class Engine:
         for b in range(no_blocks):
             blk = f"{prefix}.blocks.{b}"
             self.triangle_block(blk, z, T, Cz, z_mask, z_maskT)
-            self.pair_bias(blk + ".attention", z, T, T, Cz, z_mask, P[blk + ".attention.norm_z.weight"], sbias)
-            self.attention_pair_bias(blk + ".attention", s, 1, T, Cs, sbias, nk=self.Tr)
+            ps = self.trunk_prescale(blk + ".attention", P[blk + ".attention.norm_s.weight"], 1, T, self.Tr, Cs // 32)
+            self.pair_bias(blk + ".attention", z, T, T, Cz, z_mask, P[blk + ".attention.norm_z.weight"], sbias, prescale=ps)
+            self.attention_pair_bias(blk + ".attention", s, 1, T, Cs, sbias, nk=self.Tr, bias_prescale=ps)
             self.transition(blk + ".transition", s, T, Cs)
 
     # ------------------------------------------------------------------ conditioning trunk
@@ -320,8 +359,9 @@ class Engine:
         for b in range(dc.no_blocks_evoformer):
             blk = f"{te}.evoformer.blocks.{b}"
             # MSA row attention with pair bias (attentions.py:76-97)
-            self.pair_bias(blk + ".msa_row_attention", z, T, T, Cz, z_mask, P[blk + ".msa_row_attention.norm_z.weight"], mbias)
-            self.attention_pair_bias(blk + ".msa_row_attention", m, S, T, Cm, mbias, norm_name="norm_m", nk=self.Tr)
+            ps = self.trunk_prescale(blk + ".msa_row_attention", P[blk + ".msa_row_attention.norm_m.weight"], S, T, self.Tr, Hm)
+            self.pair_bias(blk + ".msa_row_attention", z, T, T, Cz, z_mask, P[blk + ".msa_row_attention.norm_z.weight"], mbias, prescale=ps)
+            self.attention_pair_bias(blk + ".msa_row_attention", m, S, T, Cm, mbias, norm_name="norm_m", nk=self.Tr, bias_prescale=ps)
             self.msa_column_attention(blk + ".msa_col_attention", m, S, T, Cm)
             self.transition(blk + ".msa_transition", m, S * T, Cm)
             self.outer_product_mean(blk + ".opm", m, z, S, T, Cm, Cz)
@@ -438,7 +478,7 @@ class Engine:
         ops.rownorm(raw, z, T * T, Cz, res=z, w=P[prefix + ".norm_out.weight"], mode=RMS, eps=self.eps)
 
     # ------------------------------------------------------------------ denoiser
-    def prepare_dit(self, a, ap, s, z, batch, tau, per_sample=False):
+    def prepare_dit(self, a, ap, s, z, batch, tau, per_sample=False, B=0):
         """Per-call, step-invariant preparation: hoisted pair biases (attentions.py:246,254 executed once
         instead of 18 x steps times) and the AdaLN tables of every step (adaptive_layer_norm_zero.py:19)."""
         P, ws = self.P, self.ws
@@ -447,20 +487,26 @@ class Engine:
         A, T = a.shape[0], s.shape[0]
         n = tau.shape[0]
         L = ops._lib.init()
-        # --- hoisted biases
+        # --- hoisted biases (times the product of the q, k operand scales when the step loop's launches - B samples - take the
+        # pipelined attention kernel: attn_prescale)
+        Ar, Tr = batch.get("_A_real", A), batch.get("_T_real", T)
+        f16 = ops.SPLIT_GEMM and ops.F16_GEMM
+        ps_a = self.attn_prescale(P.dit_qk_bounds_host("atom"), B, A, Ar, Ca // 32, self.attn_ws(B, A, Ar, Ca // 32)) if (B and f16) else 0.0
+        ps_t = self.attn_prescale(P.dit_qk_bounds_host("token"), B, T, Tr, Cs // 32, self.attn_ws(B, T, Tr, Cs // 32)) if (B and f16) else 0.0
+        osc_a, osc_t = LOG2E * (ps_a or 1.0), LOG2E * (ps_t or 1.0)
         Wa, ba_, na = P.dit_bias("atom")                  # [2*nb_atom*H, Cap] with LN affine folded
         fa = ws.get("dit_atom_bias", ops.bias_frag_numel(na, A, A), zero=True)
         if not (Wa.shape[1] == Cap and ops.pair_bias(ap, Wa, fa, A, A, Cap, na, c2=ba_, maskadd=batch["ap_mask"],
-                                                      maskval=-self.inf, out_scale=LOG2E, mode=LN, eps=1e-5,
+                                                      maskval=-self.inf, out_scale=osc_a, mode=LN, eps=1e-5,
                                                       only_if_faster=True)):
             st = self.stats(ap, A * A, Cap, LN, 1e-5, "stats_pb")
             self.gemm(ap, Wa, fa, A * A, na, Cap, stats=st, bias=ba_, out_mode=OUT_BIASFRAG, T1=A, T2=A,
-                      maskadd=batch["ap_mask"], maskval=-self.inf, out_scale=LOG2E)
+                      maskadd=batch["ap_mask"], maskval=-self.inf, out_scale=osc_a)
         Wt, bt_, nt = P.dit_bias("token")
         st = self.stats(z, T * T, Cz, LN, 1e-5, "stats_pb")
         ft = ws.get("dit_token_bias", ops.bias_frag_numel(nt, T, T), zero=True)
         self.gemm(z, Wt, ft, T * T, nt, Cz, stats=st, bias=bt_, out_mode=OUT_BIASFRAG, T1=T, T2=T,
-                 maskadd=batch["z_mask"], maskval=-self.inf, out_scale=LOG2E)
+                 maskadd=batch["z_mask"], maskval=-self.inf, out_scale=osc_t)
         # --- AdaLN tables: t = MLP(sincos(tau)); table = Linear(silu(t)) with 1 folded into the scale bias
         emb = ws.get("t_emb", n, 256)
         ops.check(L.pd_timestep_embed(ops.ptr(tau), ops.ptr(emb), n, ops.stream()), "timestep_embed")
@@ -483,9 +529,9 @@ class Engine:
                 out.copy_(out.amax(0, keepdim=True).expand_as(out))
             bnd[kind] = out
         return {"atom_bias": fa, "token_bias": ft, "tab_atom": tab_a, "tab_token": tab_t, "bnd_atom": bnd["atom"],
-                "bnd_token": bnd["token"]}
+                "bnd_token": bnd["token"], "ps_atom": ps_a, "ps_token": ps_t, "B": B}
 
-    def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample, nk, bnd=None):
+    def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample, nk, bnd=None, bias_prescale=0.0):
         """DiTBlock (transformers.py:155-159; attentions.py:241-265; transitions.py:27-30).
         tab: AdaLN table row(s) [shift | 1+scale | gate] x (attention, transition) for this block."""
         P, eps = self.P, self.eps
@@ -524,13 +570,15 @@ class Engine:
         # bnd: device address of this (step, block)'s magnitude bounds: chip-filling attention launches then take the two-part
         # fp16 operand format too - and write their output already split for linear_o (no split VALU in that GEMM's staging)
         akw = dict(nq=N, nk=nk, nbatch=B, nheads=H, q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias,
-                   bias_nk=N, ws=self.attn_ws(B, N, nk, H), f16_amax=bnd)
+                   bias_nk=N, ws=self.attn_ws(B, N, nk, H), f16_amax=bnd, bias_prescale=bias_prescale)
         qkv_presplit = bool(presplit and ops.PRESPLIT_QKV)
         # k | v leave the projection already scaled and split for that attention kernel (bounds bnd[1], bnd[2]): only when BOTH
         # launches are the fp16-format kernels - asked of the library, never assumed
         kv2 = None
-        if f16 and ops.F16_ATTN and ops.SPLIT_ATTN and ops.KV_PRESPLIT \
-                and ops.unsplit_f16_attention(ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw)) \
+        # the kernel pd_attention picks depends on the launch shape only: asked once per block (kv2 and o_split both need it)
+        unsplit_f16 = bool(f16 and ops.F16_ATTN and ops.SPLIT_ATTN and ops.unsplit_f16_attention(
+            ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw)))
+        if unsplit_f16 and ops.KV_PRESPLIT \
                 and ops.kv2_supported(rows, C, a2=qkv_presplit and a2 is not None, per_group_rows=N if per_sample else 0):
             kv2 = self.lws("dit_kv2", rows, 4 * C, dtype=torch.float16)      # per row: k then v, groups of (4 high, 4 low) parts
             hn.update(Y2=kv2, y2_amax=bnd + 4, y2_col0=C)
@@ -542,9 +590,8 @@ class Engine:
             self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
                       pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
-        o_split = f16 and ops.F16_ATTN and ops.SPLIT_ATTN and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C \
-            and ops.unsplit_f16_attention(ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw)) \
-            and ops.presplit_supported(rows, C, C, f16=True, gate=True)
+        o_split = unsplit_f16 and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C \
+            and ops.presplit_supported(rows, C, C, f16=True, gate=True, per_group_rows=N if per_sample else 0, gstride=tab_ld if per_sample else 0)
         if o_split:
             o2 = self.lws("dit_o2", 2, rows, C, dtype=torch.float16)
             ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, O2=o2, **akw)
@@ -589,23 +636,26 @@ class Engine:
         ft_stride = ops.bias_frag_numel(Hs, T, T)
         nb_a, nb_t = dt.no_blocks_atom, dt.no_blocks_dit
         bnd_a, bnd_t = prep["bnd_atom"], prep["bnd_token"]
+        if (prep["ps_atom"] or prep["ps_token"]) and prep["B"] != B:
+            raise RuntimeError("prepare_dit pre-scaled the hoisted biases for a different sample count")
+        psa, pst = prep["ps_atom"], prep["ps_token"]
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_encoder.blocks.{b}", ba, B, A, Ca, off(prep["atom_bias"], b * fa_stride),
-                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + b) * 8))
+                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + b) * 8), bias_prescale=psa)
         u = self.lws("dit_u", B * A, Cs)
         self.lin(ba, "dit.linear_downscale", B * A, out=u, act=ACT_SILU)
         bs = self.lws("dit_bs", B * T, Cs)
         ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs), B, A, T, Cs, sp), "pool")
         for b in range(nb_t):
             self.dit_block(f"dit.token_dit.blocks.{b}", bs, B, T, Cs, off(prep["token_bias"], b * ft_stride),
-                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr, bnd=off(bnd_t, (row * nb_t + b) * 8))
+                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr, bnd=off(bnd_t, (row * nb_t + b) * 8), bias_prescale=pst)
         us = self.lws("dit_us", B * T, Ca)
         self.lin(bs, "dit.linear_upscale", B * T, out=us)
         ops.check(L.pd_unpool_add(ops.ptr(ba), ops.ptr(us), ops.ptr(batch["atom_id_to_token_id"]), B, A, T, Ca, sp), "unpool")
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_decoder.blocks.{b}", ba, B, A, Ca,
                            off(prep["atom_bias"], (nb_a + b) * fa_stride), tab_a, row * lda_ + (nb_a + b) * 6 * Ca, lda_,
-                           per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + nb_a + b) * 8))
+                           per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + nb_a + b) * 8), bias_prescale=psa)
         cs_b = ops.ptr(scal["c_skip"]) if per_sample else None
         co_b = ops.ptr(scal["c_out"]) if per_sample else None
         ops.check(L.pd_denoise(ops.ptr(ba), ops.ptr(x_hat), ops.ptr(P["dit.norm_r.weight"]), ops.ptr(P["dit.norm_r.bias"]),

@@ -259,7 +259,7 @@ class PhysDock(nn.Module):
         a, ap, s, z = conditioning if conditioning is not None else eng.conditioning(batch)
         tau = ws.get("tau", steps)
         tau.copy_(torch.tensor([p["tau"] for p in plan], dtype=torch.float32))
-        prep = eng.prepare_dit(a, ap, s, z, batch, tau)
+        prep = eng.prepare_dit(a, ap, s, z, batch, tau, B=B)
 
         # Everything the step loop reads is staged in workspace buffers: a captured hipGraph replays raw addresses, so
         # no caller-owned or per-call temporary tensor may be referenced from inside the loop (a / s included: a graph
@@ -468,7 +468,7 @@ class PhysDock(nn.Module):
         scal = {"c_in": (1 / torch.sqrt(th ** 2 + sd ** 2)).to(device), "c_skip": (sd ** 2 / (sd ** 2 + th ** 2)).to(device),
                 "c_out": (sd * th / torch.sqrt(sd ** 2 + th ** 2)).to(device)}
         tau = (th * (torch.log(th / sd) / 4.0)).to(device)
-        prep = eng.prepare_dit(a, ap, s, z, batch, tau, per_sample=True)
+        prep = eng.prepare_dit(a, ap, s, z, batch, tau, per_sample=True, B=B)
         x_den = ws.get("fw_xden", B, A, 3)
         eng.af3_dit(batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=True)
         pd = eng.lin(z, "linear_distogram", T * T).reshape(T, T, -1)[:T_real, :T_real]

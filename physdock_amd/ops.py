@@ -40,12 +40,12 @@ def const_vec(val, n):
 _PRESPLIT_OK = {}
 
 
-def presplit_supported(M, N, K, *, glu=0, hn=False, f16=False, gate=False):
+def presplit_supported(M, N, K, *, glu=0, hn=False, f16=False, gate=False, per_group_rows=0, gstride=0):
     """Does the library take a pre-split A operand for this projection - [3][M][K] bf16 (pd_gemm_args.A3), or with f16=True
     [2][M][K] fp16 (A2, csrc/gemm_f16.hip)?  Asked of the library itself (pd_gemm_variant: tile-count threshold, alignment and
     epilogue rules live in csrc/gemm_split.hip / gemm_f16.hip), so a differently tuned build changes the answer here, not an
     error in pd_gemm."""
-    key = (M, N, K, int(glu), bool(hn), bool(f16), bool(gate))
+    key = (M, N, K, int(glu), bool(hn), bool(f16), bool(gate), int(per_group_rows), int(gstride))
     r = _PRESPLIT_OK.get(key)
     if r is None:
         a = GemmArgs()
@@ -59,9 +59,10 @@ def presplit_supported(M, N, K, *, glu=0, hn=False, f16=False, gate=False):
         a.batch, a.glu, a.out_scale = 1, int(glu), 1.0
         if hn:
             a.hn_w, a.hn_cols, a.hn_split = 1 << 20, 0, 32
-        if gate:                                         # gate x (acc + bias) + residual with one gate row for all rows
-            a.res = a.mul = 1 << 20
-            a.ldres, a.mul_rows_per_group = N, M
+        if gate:                                         # gate x (acc + bias) + residual: one gate row for all rows, or - per_group_rows
+            a.res = a.mul = 1 << 20                      # (training-time forward: one AdaLN row per sample) - one per row group
+            a.ldres, a.mul_rows_per_group = N, (per_group_rows or M)
+            a.mul_gstride = gstride if per_group_rows else 0
         r = _lib.init().pd_gemm_variant(C.byref(a)) >= (2000000 if f16 else 1000000)
         _PRESPLIT_OK[key] = r
     return r
@@ -178,6 +179,9 @@ SPLIT_ATTN = True
 
 #: two-part fp16 operands (three partial products) for attention launches whose caller supplies magnitude bounds (f16_amax=)
 F16_ATTN = True
+#: chip-filling fp16-format launches on the software-pipelined kernel (csrc/attn_pipe.hip) when the bias was produced pre-scaled
+#: (bias_prescale=); False: attn_parts_kernel (csrc/attn_f16.hip) with an unscaled bias - callers must then not pre-scale
+PIPE_ATTN = True
 #: the same for GEMM launches that carry fp16-split weights and a bound of |A| (W2=, a_amax=)
 F16_GEMM = True
 #: GEMMs with a norm prologue and a static gain / shift derive the bound themselves (sqrt(K) max|w| + max|b|): the trunk
@@ -185,6 +189,8 @@ F16_NORM_BOUND = True
 #: the atom-level DiT transition (C = 128, hidden = 384) as one kernel with the hidden activations in LDS
 FUSED_TRANSITION = True
 TRANSITION_HOOK = None
+#: ... and the trunk's pair transition (RMSNorm, static gain; [T*T][128] rows) on the same kernel
+FUSED_TRUNK_TRANSITION = True
 #: fp16-parts attention launches write their output already split for the projection that follows (pd_attn_args.O2 -> A2)
 ATTN_SPLIT_OUT = True
 #: the q|k|v projection writes k | v already scaled and split for the fp16-parts attention kernel (pd_gemm_args.Y2 -> pd_attn_args.K2 / V2):
@@ -225,7 +231,7 @@ def norm_split2(x, out2, M, Cdim, a_amax, *, ldx=None, mode=RMS, eps=1e-8, w=Non
                                      P(a_amax), ptr(out2), stream()), "pd_norm_split2")
 
 
-def transition_f16(x, M, Cdim, hidden, *, shift, scale1p, gate, W13, W2, y_amax, h_amax, eps, rows_per_group=0, gstride=0):
+def transition_f16(x, M, Cdim, hidden, *, shift, scale1p, gate, W13, W2, y_amax, h_amax, eps, rows_per_group=0, gstride=0, rms=False):
     """fused atom-level DiT transition (pd_transition_f16); returns False when the library does not cover the shape.
     shift / scale1p / gate / y_amax / h_amax: device addresses or tensors; W13 / W2: (parts, w_inv) of packing.split2_f16"""
     def P(t):
@@ -236,6 +242,7 @@ def transition_f16(x, M, Cdim, hidden, *, shift, scale1p, gate, W13, W2, y_amax,
     a.rows_per_group, a.gstride, a.eps = rows_per_group, gstride, eps
     a.W13, a.w13_inv, a.W2, a.w2_inv = W13[0].data_ptr(), W13[1].data_ptr(), W2[0].data_ptr(), W2[1].data_ptr()
     a.y_amax, a.h_amax = P(y_amax), P(h_amax)
+    a.rms = int(rms)
     def launch():
         rc = _lib.init().pd_transition_f16(C.byref(a), stream())
         if rc != -3:
@@ -286,7 +293,7 @@ def unsplit_f16_attention(variant):
 
 def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_strides, o_strides, bias=None,
               scale=1.0 / math.sqrt(32.0), ws=None, bias_nk=0, f16_amax=None, O2=None, query_only=False,
-              KV2=None, kv2_strides=None):
+              KV2=None, kv2_strides=None, bias_prescale=0.0):
     """strides = (batch_stride, seq_stride) in floats; Q/K/V/O tensors or raw addresses.  ws: optional float scratch
     tensor (attn_split_ws_numel) enabling key-split launches for small grids.  bias_nk: key count the bias buffer was laid
     out for (the padded count when nk is the real one)."""
@@ -303,6 +310,7 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
     a.bias = P(bias)
     a.scale = scale
     a.bias_nk = bias_nk
+    a.bias_prescale = (float(bias_prescale) if bias is not None else 0.0) if PIPE_ATTN else -1.0
     a.fp32_mfma = 0 if SPLIT_ATTN else 1
     if f16_amax is not None and F16_ATTN:      # (max|q|, max|k|, max|v|) upper bounds: three floats by value, or a device tensor [3]
         a.f16x3 = 1
@@ -323,6 +331,13 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
     if ATTN_HOOK is not None:
         return ATTN_HOOK(a, lambda: check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention"))
     check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention")
+
+
+def attn_bias_prescale(q_amax, k_amax, scale=1.0 / math.sqrt(32.0)):
+    """the power of two a bias producer folds into out_scale so that the pipelined fp16-format attention kernel (csrc/attn_pipe.hip)
+    can take the bias tile as the initial value of its score accumulator: the product of the q and k operand scales the kernel
+    derives from the same bounds (pd_attention_bias_prescale_log2: host arithmetic identical to the device's)"""
+    return 2.0 ** _lib.lib().pd_attention_bias_prescale_log2(float(q_amax), float(k_amax), float(scale))
 
 
 def bias_frag_numel(nheads, nq, nk):

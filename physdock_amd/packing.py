@@ -151,18 +151,24 @@ class PackedWeights:
             return (W, b)
         return self._c(("qkvg", prefix), mk)
 
-    def attn_static_bounds(self, prefix, norm_weight):
-        """device floats [3]: rigorous upper bounds of |q|, |k|, |v| of a trunk attention whose projections (no bias) read an
-        RMS- / LayerNorm-ed row times the static gain `norm_weight`: |W_n . (x^ w)| <= ||W_n w||_2 ||x^||_2 and ||x^||_2 <= sqrt(C)
-        (Cauchy-Schwarz; weights only, so it holds for any input) - the precondition of the two-part fp16 attention format"""
+    def attn_static_bounds_host(self, prefix, norm_weight):
+        """[|q|, |k|, |v|] rigorous upper bounds of a trunk attention whose projections (no bias) read an RMS- / LayerNorm-ed row
+        times the static gain `norm_weight`: |W_n . (x^ w)| <= ||W_n w||_2 ||x^||_2 and ||x^||_2 <= sqrt(C) (Cauchy-Schwarz;
+        weights only, so it holds for any input) - the precondition of the two-part fp16 attention format.  fp32-rounded host
+        floats: exactly the numbers the device copy (attn_static_bounds) holds."""
         def mk():
             w = norm_weight.double()
             out = []
             for c in "qkv":
                 W = self.p[f"{prefix}.linear_{c}.weight"].double()
                 out.append(float((W * w[None, :]).norm(dim=1).max()) * math.sqrt(W.shape[1]) * 1.0001)
-            return torch.tensor(out, dtype=torch.float32, device=norm_weight.device)
-        return self._c(("attn_bounds", prefix, norm_weight.data_ptr()), mk)
+            return [float(v) for v in torch.tensor(out, dtype=torch.float32)]
+        return self._c(("attn_bounds_host", prefix, norm_weight.data_ptr()), mk)
+
+    def attn_static_bounds(self, prefix, norm_weight):
+        """device floats [3] of attn_static_bounds_host"""
+        return self._c(("attn_bounds", prefix, norm_weight.data_ptr()), lambda: torch.tensor(
+            self.attn_static_bounds_host(prefix, norm_weight), dtype=torch.float32, device=norm_weight.device))
 
     def glu_hidden_bound(self, prefix, norm_weight):
         """device scalar: rigorous upper bound of |silu(W1 y) (W3 y)| for y = x^ w, ||x^||_2 <= sqrt(C) (RMS- / LayerNorm-ed row
@@ -228,19 +234,29 @@ class PackedWeights:
             return (W, torch.cat(bs).contiguous(), W.shape[0])
         return self._c(("ditbias", kind), mk)
 
+    def dit_qk_bounds_host(self, kind):
+        """(q bound, k bound) of a DiT family: per-head RMS norm => |q| <= sqrt(32) max|gain_q|; ONE pair for all blocks of the family
+        (the maximum over its blocks), so that every block's attention launch derives the same operand scales and the hoisted bias
+        tiles of the family carry one pre-scale (ops.attn_bias_prescale).  fp32-rounded host floats = the device table's entries."""
+        def mk():
+            up = 1.0001
+            hq = max(float(self.headnorm(blk + ".attention")[0].abs().max()) for blk in self._dit_blocks(kind))
+            hk = max(float(self.headnorm(blk + ".attention")[1].abs().max()) for blk in self._dit_blocks(kind))
+            return tuple(float(v) for v in torch.tensor([math.sqrt(32.0) * hq * up, math.sqrt(32.0) * hk * up], dtype=torch.float32))
+        return self._c(("ditqk", kind), mk)
+
     def dit_bound_consts(self, kind):
         """[blocks][4] = (q bound, k bound, max_n ||Wv_n||_2, max_n ||W1_n||_2 * max_n ||W3_n||_2): the weight-dependent factors of
         the activation bounds pd_dit_bounds derives for the two-part fp16 operand format (csrc/sampler.hip)"""
         def mk():
             rows = []
+            qb, kb = self.dit_qk_bounds_host(kind)
             for blk in self._dit_blocks(kind):
-                hn = self.headnorm(blk + ".attention")                         # [2][32]: per-head RMS norm gains of q and k
                 wv = self.p[blk + ".attention.linear_v.weight"]
                 w1 = self.p[blk + ".transition.feed_forward.w1.weight"]
                 w3 = self.p[blk + ".transition.feed_forward.w3.weight"]
                 up = 1.0001                                                     # the norms themselves are rounded fp32
-                rows.append([math.sqrt(32.0) * float(hn[0].abs().max()) * up, math.sqrt(32.0) * float(hn[1].abs().max()) * up,
-                             float(wv.double().norm(dim=1).max()) * up,
+                rows.append([qb, kb, float(wv.double().norm(dim=1).max()) * up,
                              float(w1.double().norm(dim=1).max()) * float(w3.double().norm(dim=1).max()) * up])
             return torch.tensor(rows, dtype=torch.float32, device=self.p[self._dit_blocks(kind)[0] + ".attention.linear_v.weight"].device)
         return self._c(("ditbound", kind), mk)

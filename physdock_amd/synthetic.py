@@ -312,3 +312,25 @@ def pdb_meta(raw, seed=0):
     return {"ccds": ccds, "atom_id_to_conformer_atom_id": inner, "conformer_id_to_chunk_sizes": np.asarray(conf_chunks),
             "CHAIN_CLASS": chain_class, "CONF_META_DATA": meta, "residue_index": np.asarray(res_index),
             "asym_id": np.asarray(conf_asym)}
+
+
+def replay_draws(seed, B, steps, A, n_noisy):
+    """The reference sampler's random draws for (B samples, `steps` steps, the first n_noisy of them with noise injection),
+    regenerated from torch's global CPU generator in the reference's call order (model.py:148, tensor_utils.py:549-557,582,
+    model.py:77): initial noise, then per step four uniform vectors (rotation), the translation, and - noisy steps only - the
+    diffusion noise.  Lets a fixture store a seed instead of megabytes of draws (tools/make_golden.py checks the replay against
+    the recorded draws bit for bit)."""
+    state = torch.get_rng_state()
+    try:
+        torch.manual_seed(seed)
+        init = torch.normal(mean=0, std=1, size=(B, A, 3), dtype=torch.float32)
+        rot, trans, dif = [], [], []
+        for i in range(steps):
+            rot.append(torch.stack([torch.rand([B], dtype=torch.float32) for _ in range(4)]))
+            trans.append(torch.normal(mean=0, std=1, size=(B, 3), dtype=torch.float32))
+            if i < n_noisy:
+                dif.append(torch.normal(mean=0, std=1, size=(B, A, 3), dtype=torch.float32))
+    finally:
+        torch.set_rng_state(state)
+    return {"init": init, "rot_u": torch.stack(rot), "trans": torch.stack(trans),
+            "diffuse": torch.stack(dif) if dif else torch.zeros(0, B, A, 3)}

@@ -14,18 +14,27 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-def run(ops, q, k, v, bias, mode, amax=None):
+def run(ops, q, k, v, bias, mode, amax=None, want_variant=None):
+    """mode: fp32 (attention.hip), bf16 (attn_split.hip), f16 (attn_f16.hip: attn_parts_kernel), pipe (attn_pipe.hip: the
+    software-pipelined fp16-format kernel; its bias arrives multiplied by ops.attn_bias_prescale of the q / k bounds)"""
     B, nq, C = q.shape
     nk, H = k.shape[1], C // 32
     o = torch.empty(B, nq, C, device="cuda")
-    old = ops.SPLIT_ATTN
-    ops.SPLIT_ATTN = mode != "fp32"
+    old, oldp = ops.SPLIT_ATTN, ops.PIPE_ATTN
+    ops.SPLIT_ATTN, ops.PIPE_ATTN = mode != "fp32", mode == "pipe"
     try:
-        ops.attention(q.cuda(), k.cuda(), v.cuda(), o, nq=nq, nk=nk, nbatch=B, nheads=H, q_strides=(nq * C, C),
-                      k_strides=(nk * C, C), v_strides=(nk * C, C), o_strides=(nq * C, C),
-                      bias=ops.bias_to_frag(bias).cuda() if bias is not None else None, f16_amax=amax if mode == "f16" else None)
+        bf, ps = (ops.bias_to_frag(bias).cuda() if bias is not None else None), 0.0
+        if mode == "pipe" and bias is not None:
+            qk = [float(a) for a in (amax.cpu() if isinstance(amax, torch.Tensor) else amax)][:2]
+            ps = ops.attn_bias_prescale(*qk)
+            bf = bf * ps                       # a power of two: exact
+        kw = dict(nq=nq, nk=nk, nbatch=B, nheads=H, q_strides=(nq * C, C), k_strides=(nk * C, C), v_strides=(nk * C, C),
+                  o_strides=(nq * C, C), bias=bf, f16_amax=amax if mode in ("f16", "pipe") else None, bias_prescale=ps)
+        if want_variant is not None:
+            assert ops.attention(q.cuda(), k.cuda(), v.cuda(), o, query_only=True, **kw) in want_variant
+        ops.attention(q.cuda(), k.cuda(), v.cuda(), o, **kw)
     finally:
-        ops.SPLIT_ATTN = old
+        ops.SPLIT_ATTN, ops.PIPE_ATTN = old, oldp
     return o.cpu()
 
 
@@ -42,7 +51,8 @@ def ref64(q, k, v, bias):
 
 
 CASES = [(64, 4, 1024, 1024, True, 1.0), (16, 16, 256, 256, True, 1.0), (40, 4, 300, 333, True, 1.0), (32, 8, 1024, 520, False, 1.0),
-         (48, 4, 512, 512, True, 30.0), (48, 4, 512, 512, True, 1e-3)]
+         (48, 4, 512, 512, True, 30.0), (48, 4, 512, 512, True, 1e-3), (300, 4, 100, 100, True, 1.0), (64, 4, 257, 31, True, 1.0),
+         (64, 4, 256, 65, False, 1.0)]
 
 
 @pytest.mark.parametrize("B,H,nq,nk,use_bias,mag", CASES)
@@ -61,16 +71,23 @@ def test_f16_attention_error_vs_float64_not_above_fp32_mfma(B, H, nq, nk, use_bi
     ref = ref64(q, k, v, bias)
     amax = (float(q.abs().max()), float(k.abs().max()), float(v.abs().max()))
     errs = {}
-    for mode in ("fp32", "bf16", "f16"):
-        o = run(ops, q, k, v, bias, mode, amax)
+    for mode in ("fp32", "bf16", "f16", "pipe"):
+        o = run(ops, q, k, v, bias, mode, amax, want_variant=({3004, 3008} if mode == "pipe" else {2004, 2008} if (mode == "f16" and use_bias) else None))
         assert torch.isfinite(o).all(), mode
         e = (o.double() - ref).abs()
         scale = ref.abs().mean()
         errs[mode] = (float(e.max() / scale), float(e.pow(2).mean().sqrt() / scale))
     print(f"attention {B}x{H}x{nq}x{nk} |v|~{mag:g}: err/mean|o| (max, rms)  fp32-MFMA {errs['fp32'][0]:.2e} {errs['fp32'][1]:.2e} | "
-          f"bf16x6 {errs['bf16'][0]:.2e} {errs['bf16'][1]:.2e} | f16x3 {errs['f16'][0]:.2e} {errs['f16'][1]:.2e}")
+          f"bf16x6 {errs['bf16'][0]:.2e} {errs['bf16'][1]:.2e} | f16x3 {errs['f16'][0]:.2e} {errs['f16'][1]:.2e} | "
+          f"f16x3 pipelined {errs['pipe'][0]:.2e} {errs['pipe'][1]:.2e}")
     assert errs["f16"][1] <= 1.05 * errs["fp32"][1] + 1e-9          # rms: not above the fp32 MFMA kernel
     assert errs["f16"][0] <= 1.5 * errs["fp32"][0] + 1e-8           # max: same class (single-element maxima fluctuate)
+    # the pipelined kernel accumulates the products ON TOP of the bias tile (the bias is the accumulator's initial value): every
+    # partial sum of a score is rounded at the magnitude of the finished score instead of only the last one - same fp32 class,
+    # measured 0.9 - 1.4 x the fp32-MFMA kernel's rms error with a bias (and exactly attn_parts_kernel's without one); the
+    # trajectory-level bar (1e-3 A against the reference, tests/test_round2_gpu.py G9) is what the format has to hold
+    assert errs["pipe"][1] <= (1.5 if use_bias else 1.05) * errs["fp32"][1] + 1e-9
+    assert errs["pipe"][0] <= 2.0 * errs["fp32"][0] + 1e-8
     # bounds read from device memory (graph-capturable form) and loose bounds (x64) give the same class of result
     o_dev = run(ops, q, k, v, bias, "f16", torch.tensor(amax, device="cuda"))
     assert torch.equal(o_dev, run(ops, q, k, v, bias, "f16", amax))

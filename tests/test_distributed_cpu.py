@@ -86,3 +86,34 @@ def test_gather_world2_gloo():
             p.join(120)
             assert p.exitcode == 0
         assert q.get(timeout=10) is True
+
+
+def test_bench_distributed_branch_world2_gloo():
+    """bench.py's own multi-GPU branch - the command line the driver uses (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`) - driven at world size 2
+    on gloo with a stand-in sampler (PD_BENCH_DRYRUN=1): rank / sample_offset plumbing, the gather, the rank-block checks, the
+    barrier-bracketed max-over-ranks timing and the one JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PD_BENCH_DRYRUN="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cfg", "small",
+           "--samples", "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] - 3 * 2 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert out["config"]["parallelism"] == "sample-parallel x2" and out["config"]["samples_per_gpu"] == 3
+    # a WORLD_SIZE that disagrees with --gpus is refused before anything runs
+    bad = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "must agree" in (bad.stderr + bad.stdout)

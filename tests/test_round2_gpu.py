@@ -60,30 +60,44 @@ def test_ref_mol_without_a_way_to_relax_raises(small):
 
 
 # ------------------------------------------------------------------ G9: the reference itself at the benchmark shapes
-@pytest.mark.parametrize("tag", ["cfg1", "ragged", "cfg2", "cfg1_b16", "cfg1_40"])
+@pytest.mark.parametrize("tag", ["cfg1", "ragged", "cfg2", "cfg1_b16", "cfg1_40", "cfg1_b32"])
 def test_medium_trajectories_vs_reference(medium, tag):
     """north_star bar at full size, against the reference (not the oracle): final coordinates within 1e-3 A RMSD with
     the same seeded weights, synthetic crop and recorded noise"""
     from physdock_amd.synthetic import cfg1_batch, cfg2_batch, make_batch, toy_relax_fn
     g = load_golden(f"g9_medium_{tag}")
     batch = {"cfg1": lambda: cfg1_batch(0), "ragged": lambda: make_batch(221, 8, 35, 64, 2), "cfg2": lambda: cfg2_batch(0),
-             "cfg1_b16": lambda: cfg1_batch(0), "cfg1_40": lambda: cfg1_batch(0)}[tag]()
-    nz = golden_noise(g)
+             "cfg1_b16": lambda: cfg1_batch(0), "cfg1_40": lambda: cfg1_batch(0), "cfg1_b32": lambda: cfg1_batch(0)}[tag]()
+    if "noise_seed" in g:        # the fixture stores the seed: the reference's draws are regenerated in its call order
+        from physdock_amd.synthetic import replay_draws
+        nz = replay_draws(g["noise_seed"], g["x_pred"].shape[0], g["steps"], g["x_pred"].shape[1], g["n_noisy"])
+    else:
+        nz = golden_noise(g)
     B = nz["init"].shape[0]
     kw = dict(num_sample=B, steps=g["steps"], karras_noise_schedule_power=1000, noise=nz, align_ref_pos=False)
     if "ref_mol_poses" in g:
         kw.update(align_ref_pos=True, ref_mol={"conf": g["mol_conf"]}, relax_fn=toy_relax_fn, ref_mol_poses=g["ref_mol_poses"],
                   use_ref_mol_poses=True, mmff_gamma_0_factor=g["mmff_gamma_0_factor"])
-    if tag == "cfg1_b16":       # 16 samples: the loop must run on the split-operand kernels the B = 64 benchmark uses
+    if tag in ("cfg1_b16", "cfg1_b32"):       # the loop must run on the kernels the B = 64 benchmark dispatches
         from physdock_amd import ops
-        seen = []
-        ops.GEMM_HOOK = lambda a, launch: (seen.append(ops._lib.init().pd_gemm_variant(C.byref(a))), launch())
+        seen, aseen = [], []
+        L = ops._lib.init()
+        ops.GEMM_HOOK = lambda a, launch: (seen.append((L.pd_gemm_variant(C.byref(a)), a.M)), launch())
+        ops.ATTN_HOOK = lambda a, launch: (aseen.append((L.pd_attention_variant(C.byref(a)), a.nbatch)), launch())
         try:
             x = medium.sample_diffusion(to_dev(batch), use_graph=False, **kw)
         finally:
-            ops.GEMM_HOOK = None
-        n_split = sum(v >= 1000000 for v in seen)
-        assert n_split > 0.6 * len(seen), (n_split, len(seen))
+            ops.GEMM_HOOK = ops.ATTN_HOOK = None
+        # DiT launches (rows = samples x atoms / tokens): every GEMM on the fp16-format kernel (>= 2000000 - a silent fall-back to
+        # bf16 x 6, 1000000 +, or to the fp32 MFMA would show here), every attention on its 8-wave form: the pipelined kernel
+        # (3008) at 32 samples, as in the benchmark; at 16 samples the pipelined or the plain fp16-format kernel (2008)
+        Aat, Tt = batch["ref_pos"].shape[0], batch["target_feat"].shape[0]
+        dit = [v for v, M in seen if M in (B * Aat, B * Tt)]
+        low = [v for v in dit if v < 2000000]       # the pool / un-pool projections read the residual stream (no norm, no bound): bf16 x 6
+        assert dit and len(low) == 2 * g["steps"] and all(v >= 1000000 for v in low), (len(low), sorted(set(dit)))
+        adit = [v for v, nb in aseen if nb == B]
+        assert adit and set(adit) <= ({3008} if tag == "cfg1_b32" else {3008, 2008}), sorted(set(adit))
+        print(f"medium/{tag}: {len(dit)} DiT GEMM launches, variants {sorted(set(dit))}; {len(adit)} DiT attention launches, variants {sorted(set(adit))}")
     else:
         x = medium.sample_diffusion(to_dev(batch), **kw)
     r = rmsd(x.cpu(), g["x_pred"])
@@ -122,7 +136,7 @@ def test_b64_matches_small_batches_and_takes_the_wide_attention(medium):
         x64 = medium.sample_diffusion(dbatch, num_sample=B, noise=noise, use_graph=False, **kw)
     finally:
         ops.ATTN_HOOK = None
-    assert variants & {8, 1008, 2008}, variants    # the 8-wave kernels (fp32 MFMA / bf16 split / fp16 split) only B >= 32 selects
+    assert variants & {8, 1008, 2008, 3008}, variants    # the 8-wave kernels (fp32 MFMA / bf16 split / fp16 split / its pipelined form) only B >= 32 selects
     x64g = medium.sample_diffusion(dbatch, num_sample=B, noise=noise, use_graph=True, **kw)
     x64g = medium.sample_diffusion(dbatch, num_sample=B, noise=noise, use_graph=True, **kw)      # replay
     assert torch.equal(x64, x64g)
