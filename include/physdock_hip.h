@@ -155,6 +155,25 @@ typedef struct pd_transition_args {
 } pd_transition_args;
 int pd_transition_f16(const pd_transition_args* args, void* stream);
 
+/* ---- pd_tri_tail (ABI 7): the tail of the trunk's TriangleUpdate in one launch ------------------------------------------------
+ * z[m,:] += sigmoid(W_g RMSNorm(z[m,:]) w_in + b_g) * (W_z RMSNorm(o[:,m]) w_out + b_z)     (attentions.py:163,170-171)
+ * for the channel-major einsum output o [Co][M] (attentions.py:164): replaces the gate projection, the column statistics of o and
+ * the K = Co projection with gate + residual (three launches, a 33 MB gate tensor) - HBM sees z in, o in, z out.  C = 128 and
+ * Co = 32 only (PD_ERR_UNSUPPORTED otherwise).  W_g [C][C] / W_z [C][Co] in the two-part fp16 fragment-major form with inverse
+ * row scales (packing.split2_f16); zn_amax / on_amax: device scalars bounding the normalised rows times their gains
+ * (sqrt(C) max|w_in|, sqrt(Co) max|w_out|).  args == NULL: one-time set-up, called by pd_init.                               */
+typedef struct pd_tri_tail_args {
+    float* z;                    /* [M][C], updated in place */
+    const float* o;              /* [Co][M] */
+    int M, C, Co;
+    const float* w_in; const float* w_out;       /* norm gains [C], [Co] */
+    float eps;
+    const void* Wg; const float* wg_inv; const float* bg;
+    const void* Wz; const float* wz_inv; const float* bz;
+    const float* zn_amax; const float* on_amax;
+} pd_tri_tail_args;
+int pd_tri_tail(const pd_tri_tail_args* args, void* stream);
+
 /* ---- pd_pair_bias: attention pair bias in one streaming pass (pairbias.hip) -------------------
  * frag = fragment layout of [ (norm(x) . Wf^T + c2 + maskadd ? 0 : maskval) * out_scale ] for x [T1*T2, C] (C = 16 or 128),
  * Wf [H][C] = projection weights with the norm gain folded in (Wf[h][k] = w[k] W[h][k]), c2 [H] = projection of the norm

@@ -85,6 +85,13 @@ class TransitionArgs(C.Structure):
                 ("rms", C.c_int)]
 
 
+class TriTailArgs(C.Structure):
+    """mirror of pd_tri_tail_args"""
+    _fields_ = [("z", _fp), ("o", _fp), ("M", C.c_int), ("C", C.c_int), ("Co", C.c_int), ("w_in", _fp), ("w_out", _fp),
+                ("eps", C.c_float), ("Wg", _fp), ("wg_inv", _fp), ("bg", _fp), ("Wz", _fp), ("wz_inv", _fp), ("bz", _fp),
+                ("zn_amax", _fp), ("on_amax", _fp)]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -172,6 +179,7 @@ def _declare(L):
     sig("pd_dit_bounds", p, i, i, i, i, p, p, p)
     sig("pd_norm_split2", p, i, i, i, i, f, p, p, i, i, p, p, p)
     sig("pd_transition_f16", C.POINTER(TransitionArgs), p)
+    sig("pd_tri_tail", C.POINTER(TriTailArgs), p)
     sig("pd_mmff_energy_grad", p, p, p, p, i, p)
     sig("pd_mmff_relax", p, p, p, p, p, ll, i, i, i, p)
     sig("pd_chirality", p, p, p, p, p, i, i, i, p)

@@ -75,6 +75,8 @@ def compile_cmd(src, out, mode=("-c",)):
         cmd[1:1] = ["-DPD_ATTN_LAZY=" + os.environ["PD_ATTN_LAZY"]]
     if os.environ.get("PD_ATTN_ABL") and base == "attn_f16.hip":      # lab: VALU ablations of the fp16-parts attention (wrong results)
         cmd[1:1] = ["-DPD_ATTN_ABL=" + os.environ["PD_ATTN_ABL"]]
+    if os.environ.get("PD_PIPE_LAZY") and base == "attn_pipe.hip":     # lab: threshold of the lazy running maximum (0: plain update)
+        cmd[1:1] = ["-DPD_PIPE_LAZY=" + os.environ["PD_PIPE_LAZY"]]
     if os.environ.get("PD_PIPE_ABL") and base == "attn_pipe.hip":      # lab: timing ablations of the pipelined attention (wrong results)
         cmd[1:1] = ["-DPD_PIPE_ABL=" + os.environ["PD_PIPE_ABL"]]
     if os.environ.get("PD_TRANSITION_BM") and base == "transition_f16.hip":     # lab: 128-row tiles, one block per CU

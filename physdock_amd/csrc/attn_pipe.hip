@@ -46,6 +46,16 @@ constexpr int ABL = PD_PIPE_ABL;
 constexpr int ABL = 0;
 #endif
 
+// Lazy running maximum: the reference maximum of a row moves only when some row of the wave exceeds it by more than PD_PIPE_LAZY
+// (log2 units) - a wave-uniform, rarely taken branch holds the exp2 of the correction and the 17 multiplications of the
+// accumulator / row-sum rescale; probabilities may then reach 2^PD_PIPE_LAZY, so they are carried times 2^(14 - PD_PIPE_LAZY).
+// 0: the plain update (maximum, correction factor and rescale in every sub-tile).
+#ifndef PD_PIPE_LAZY
+#define PD_PIPE_LAZY 3
+#endif
+constexpr int LAZY = PD_PIPE_LAZY;
+constexpr float PSH = 14.0f - (float)LAZY;
+
 __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 // MFMA of a pipelined phase (ablation 4 removes it)
 __device__ __forceinline__ f32x16 pmma(frag a, frag b, f32x16 c) {
@@ -92,28 +102,8 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     const float c_s = 1.0f / (sq * sk);                    // exact: powers of two
     const float inv_sv = 1.0f / sv;
 
-    // Q fragments: k-step s covers dims 16 s + 8 hh .. + 8 of the lane's query; [s][0] high parts, [s][1] low parts
+    // Q fragments (filled in the prologue): k-step s covers dims 16 s + 8 hh .. + 8 of the lane's query; [s][0] high, [s][1] low parts
     frag qf[2][2];
-    {
-        const float* qp = p.Q + (long long)b * p.q_bs + (long long)query * p.q_ss + h * 32 + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-            if (query < p.nq) {
-                v0 = *reinterpret_cast<const f32x4*>(qp + 16 * s);
-                v1 = *reinterpret_cast<const f32x4*>(qp + 16 * s + 4);
-            }
-            u32x4 fh, fl;
-            pd_parts2 t;
-            t = pd_split2h(v0[0] * qs, v0[1] * qs); fh[0] = t.h; fl[0] = t.l;
-            t = pd_split2h(v0[2] * qs, v0[3] * qs); fh[1] = t.h; fl[1] = t.l;
-            t = pd_split2h(v1[0] * qs, v1[1] * qs); fh[2] = t.h; fl[2] = t.l;
-            t = pd_split2h(v1[2] * qs, v1[3] * qs); fh[3] = t.h; fl[3] = t.l;
-            qf[s][0] = __builtin_bit_cast(frag, fh);
-            qf[s][1] = __builtin_bit_cast(frag, fl);
-        }
-    }
-
     const int nsub = (p.nk + 31) >> 5;                     // 32-key sub-tiles with at least one real key
     const int nit = (p.nk + KT - 1) / KT;
     const int nkt32 = ((p.bias_nk > 0 ? p.bias_nk : p.nk) + 31) >> 5;
@@ -211,6 +201,8 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;                  // m_run in units of S' (= s / c_s)
+    float mneg_run = 0.f;                                  // 14 - LAZY - m_run c_s: the additive constant in front of the exp2
+    const float tau_s = (float)LAZY / c_s;                 // the lazy-maximum threshold in units of S'
 
     auto rowmax = [&](const f32x16& s) {
         float m = max3(s[0], s[1], s[2]);
@@ -251,10 +243,24 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         nxt = pmma(kf0[0], qf[0][1], first(nxt));                       // k_hi . q_lo (C = the bias tile, or zero)
         PD_SB();
         kf1[0] = kfrag(kn, 1, 0); kf1[1] = kfrag(kn, 1, 1);
-        const float m_new = __builtin_fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_s);
-        m_run = m_new;
-        const float mneg = __builtin_fmaf(-m_new, c_s, 14.0f);
+        float alpha = 1.0f;
+        if constexpr (LAZY > 0) {
+            if (__builtin_amdgcn_ballot_w64(mloc > m_run + tau_s) != 0ull) {      // rare after the first sub-tiles
+                const float m_new = __builtin_fmaxf(m_run, mloc);
+                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_s);
+                m_run = m_new;
+                mneg_run = __builtin_fmaf(-m_new, c_s, PSH);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] *= alpha;
+                l_run *= alpha;
+            }
+        } else {
+            const float m_new = __builtin_fmaxf(m_run, mloc);
+            alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_s);
+            m_run = m_new;
+            mneg_run = __builtin_fmaf(-m_new, c_s, PSH);
+        }
+        const float mneg = mneg_run;
         if constexpr (!(ABL & 8)) fe4(cur, 0, mneg);
         PD_SB();
         // slot 2
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         nxt = pmma(kf1[1], qf[1][0], nxt);
         PD_SB();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) if constexpr (!(ABL & 8)) o[r] *= alpha;
+        for (int r = 0; r < 8; ++r) if constexpr (!(ABL & 8) && LAZY == 0) o[r] *= alpha;
         float ps1 = (cur[4] + cur[5]) + (cur[6] + cur[7]);
         ps0 += (cur[8] + cur[9]) + (cur[10] + cur[11]);
         PD_SB();
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         nxt = pmma(kf1[0], qf[1][0], nxt);
         PD_SB();
 #pragma unroll
-        for (int r = 8; r < 16; ++r) if constexpr (!(ABL & 8)) o[r] *= alpha;
+        for (int r = 8; r < 16; ++r) if constexpr (!(ABL & 8) && LAZY == 0) o[r] *= alpha;
         ps1 += (cur[12] + cur[13]) + (cur[14] + cur[15]);
         PD_SB();
         // slot 7: the last use of `cur` - the bias tile of sub-tile j+2 is fetched into it right behind
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         // slot 8
         o = pmma(vf0[1], pf0[0], o);                                    // v_lo . p_hi
         PD_SB();
-        l_run = __builtin_fmaf(l_run, alpha, ps0 + ps1);
+        if constexpr (LAZY > 0) l_run += ps0 + ps1; else l_run = __builtin_fmaf(l_run, alpha, ps0 + ps1);
         PD_SB();
         // slot 9: K fragments of sub-tile j+2's first k-step
         o = pmma(vf0[0], pf0[0], o);                                    // v_hi . p_hi
@@ -345,7 +351,8 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         const float m_new = __builtin_fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_s);
         m_run = m_new;
-        const float mneg = __builtin_fmaf(-m_new, c_s, 14.0f);
+        const float mneg = __builtin_fmaf(-m_new, c_s, PSH);
+        mneg_run = mneg;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= alpha;
         float ps = 0.f;
@@ -365,8 +372,36 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         l_run = l_run * alpha + ps;
     };
 
-    // ---- prologue: tile 0 staged, tile 1 requested, bias tiles 0 / 1 in the two score accumulators, scores of sub-tile 0
+    // ---- prologue: every independent request first (K / V tile 0, bias tiles 0 / 1 into the two score accumulators, the lane's
+    // query row) - their latencies overlap instead of adding up, which is most of a short launch (256 keys: 4 tiles per block)
     gload(0);
+    load_bias(sA, 0);
+    load_bias(sB, 1);
+    f32x4 qraw[2][2];
+    {
+        // rows beyond nq read as zero through the descriptor's range check
+        const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Q + (long long)b * p.q_bs + h * 32), 0,
+                                                            (int)(((long long)p.nq - 1) * p.q_ss * 4 + 128), 0x00020000);
+        const int qoff = (int)((long long)query * p.q_ss * 4) + 32 * hh;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qraw[s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, qoff, 64 * s, 0));
+            qraw[s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, qoff, 64 * s + 16, 0));
+        }
+    }
+    PD_SB();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f32x4 v0 = qraw[s][0], v1 = qraw[s][1];
+        u32x4 fh, fl;
+        pd_parts2 t;
+        t = pd_split2h(v0[0] * qs, v0[1] * qs); fh[0] = t.h; fl[0] = t.l;
+        t = pd_split2h(v0[2] * qs, v0[3] * qs); fh[1] = t.h; fl[1] = t.l;
+        t = pd_split2h(v1[0] * qs, v1[1] * qs); fh[2] = t.h; fl[2] = t.l;
+        t = pd_split2h(v1[2] * qs, v1[3] * qs); fh[3] = t.h; fl[3] = t.l;
+        qf[s][0] = __builtin_bit_cast(frag, fh);
+        qf[s][1] = __builtin_bit_cast(frag, fl);
+    }
     sstore(0);
     gload(1);
     lds_barrier();
@@ -374,8 +409,6 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     float mloc = 0.f;
     frag kf0[2];
     if (wave_active) {
-        load_bias(sA, 0);
-        load_bias(sB, 1);
         scores(sA, s_cur);
         kf0[0] = kfrag(s_cur + 32 * KP, 0, 0); kf0[1] = kfrag(s_cur + 32 * KP, 0, 1);
         mloc = rowmax(sA);
@@ -485,6 +518,12 @@ PD_EXPORT int pd_attention_bias_prescale_log2(float q_amax, float k_amax, float 
 extern "C" int pd_attention_pipe_ok(const pd_attn_args* a) {
     if (!a->f16x3 || a->fp32_mfma || a->bias_prescale < 0.f) return 0;      // < 0: the caller asks for attn_parts_kernel (A/B runs)
     if (a->bias && !(a->bias_prescale > 0.f)) return 0;
+    // the kernel addresses q, k, v and the bias through buffer descriptors with 32-bit offsets relative to the (batch, head) base
+    const long long lim = 0xffffff00ll;
+    const long long kss = a->K2 ? a->kv2_ss * 2 : a->k_ss * 4, vss = a->K2 ? a->kv2_ss * 2 : a->v_ss * 4;
+    const long long nkt32 = ((a->bias_nk > 0 ? a->bias_nk : a->nk) + 31) >> 5;
+    if ((long long)a->nq * a->q_ss * 4 >= lim || (long long)(a->nk + 64) * kss >= lim || (long long)(a->nk + 64) * vss >= lim || nkt32 * 4096 >= lim)
+        return 0;
     return 1;
 }
 

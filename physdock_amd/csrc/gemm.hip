@@ -561,6 +561,7 @@ PD_EXPORT int pd_init(void) {
     { const int r = pd_gemm_split_try(nullptr, 0, 0, nullptr, 1); if (r != PD_OK) rc = r; }
     { const int r = pd_gemm_f16_try(nullptr, 0, 0, nullptr, 1); if (r != PD_OK) rc = r; }
     { const int r = pd_transition_f16(nullptr, nullptr); if (r != PD_OK) rc = r; }
+    { const int r = pd_tri_tail(nullptr, nullptr); if (r != PD_OK) rc = r; }
     for (int cfg = 0; cfg < 4; ++cfg)
         for (int lay = 0; lay < 3; ++lay)
             for (int vec = 0; vec < 2; ++vec)

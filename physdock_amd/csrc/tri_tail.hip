@@ -1,0 +1,198 @@
+// Tail of the trunk's TriangleUpdate in ONE kernel (reference primitives/attentions.py:163,170-171; C = 128 pair channels, 32
+// einsum channels):
+//        z[m,:] += sigmoid(W_g RMSNorm_in(z[m,:]) + b_g) * (W_z RMSNorm_out(o[:,m]) + b_z)
+// where o [32][M] is the channel-major output of the triangle einsum (attentions.py:164).  As separate launches this was the
+// gate projection (reads z, writes a 33 MB gate tensor), a column-statistics pass over o, and a K = 32 projection with gate +
+// residual on the generic fp32 kernel (reads o, the gate tensor and z, writes z): 77 us per triangle update at T = 256, sixty
+// of them per trunk pass.  Here a block owns 64 pair rows: it normalises the z rows itself (four threads per row), normalises the
+// 32 einsum channels of its rows (one wave per 8 channels, coalesced along m), keeps both as two-part fp16 operands in LDS,
+// runs the two contractions (K = 128 and K = 32) with weight fragments straight from global memory, and finishes with one
+// read-modify-write of z.  HBM sees z in, o in, z out.  Operand format and accuracy: gemm_f16.hip (bounds: a normalised row
+// times a static gain is bounded by sqrt(K) max|w|).
+#include "gemm_tile_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int C_ = 128;                 // pair channels
+constexpr int CO = 32;                  // einsum channels
+constexpr int BM = 64;                  // rows per block tile
+constexpr int LP = 136;                 // LDS row pitch of the z operand in fp16 (272 bytes)
+constexpr int OP = 40;                  // ... of the o operand (80 bytes)
+constexpr int PART_A = BM * LP, PART_O = BM * OP;
+constexpr int LDS_BYTES = (2 * PART_A + 2 * PART_O) * 2 + 4 * BM * 4;
+constexpr int NKS1 = C_ / 16, NKS2 = CO / 16;
+constexpr int WGPART = (C_ / 32) * NKS1 * 1024;          // bytes per part of W_g (1 KB fragment blocks)
+constexpr int WZPART = (C_ / 32) * NKS2 * 1024;
+
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    _Float16* sA = lds;                          // [2][BM][LP]   RMSNorm_in(z) w_in, scaled and split
+    _Float16* sO = lds + 2 * PART_A;             // [2][BM][OP]   RMSNorm_out(o) w_out, scaled and split
+    float* red = reinterpret_cast<float*>(lds + 2 * PART_A + 2 * PART_O);      // [4][BM] partial sums of squares of o
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const auto rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wg), 0, 2 * WGPART, 0x00020000);
+    const auto rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wz), 0, 2 * WZPART, 0x00020000);
+    const int loff = lane * 16;
+    auto wfrag_g = [&](int block, int part) {
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsg, loff, block * 1024 + part * WGPART, 0));
+    };
+    auto wfrag_z = [&](int block, int part) {
+        return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsz, loff, block * 1024 + part * WZPART, 0));
+    };
+    const float z_s = pd_pow2_scale(*p.zn_amax), o_s = pd_pow2_scale(*p.on_amax);
+    const float inv_z_s = 1.0f / z_s, inv_o_s = 1.0f / o_s;
+    const int ntiles = (p.M + BM - 1) / BM;
+    const int n = 32 * wave + l31;               // this lane's output column
+    const float cg = p.wg_inv[n] * inv_z_s, cz = p.wz_inv[n] * inv_o_s, bg = p.bg ? p.bg[n] : 0.f, bz = p.bz ? p.bz[n] : 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = (long long)tile * BM;
+        // ---- phase 0: RMSNorm of the tile's z rows (four threads per row) -> scale -> split -> sA
+        {
+            const int r = tid >> 2, q = tid & 3;
+            const bool live = row0 + r < p.M;
+            const float* zr = p.z + (row0 + (live ? r : 0)) * C_;
+            f32x4 v[8], gw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gw[i] = *reinterpret_cast<const f32x4*>(p.w_in + 4 * (q + 4 * i));
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = *reinterpret_cast<const f32x4*>(zr + 4 * (q + 4 * i));
+                if (!live) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sq += v[i][e] * v[i][e];
+            }
+            sq += __shfl_xor(sq, 1);
+            sq += __shfl_xor(sq, 2);
+            const float rstd = rsqrtf(sq * (1.0f / C_) + p.eps) * z_s;      // the operand scale rides on rstd
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 4 * (q + 4 * i);
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = v[i][e] * rstd * gw[i][e];
+                const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]);
+                *reinterpret_cast<u32x2*>(sA + r * LP + c) = u32x2{p0.h, p1.h};
+                *reinterpret_cast<u32x2*>(sA + PART_A + r * LP + c) = u32x2{p0.l, p1.l};
+            }
+        }
+        // ---- phase 0b: the 32 einsum channels of the tile's rows: wave = 8 channels, lane = row (coalesced along m)
+        float ov[8];
+        {
+            const bool live = row0 + lane < p.M;
+            const float* orow = p.o + row0 + (live ? lane : 0);
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ov[e] = live ? orow[(long long)(8 * wave + e) * p.M] : 0.f;
+                ss += ov[e] * ov[e];
+            }
+            red[wave * BM + lane] = ss;
+        }
+        block_barrier();
+        {
+            const float ss = red[lane] + red[BM + lane] + red[2 * BM + lane] + red[3 * BM + lane];
+            const float rstd = rsqrtf(ss * (1.0f / CO) + p.eps) * o_s;
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = ov[e] * rstd * p.w_out[8 * wave + e];
+            const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]), p2 = pd_split2h(t[4], t[5]), p3 = pd_split2h(t[6], t[7]);
+            *reinterpret_cast<u32x4*>(sO + lane * OP + 8 * wave) = u32x4{p0.h, p1.h, p2.h, p3.h};
+            *reinterpret_cast<u32x4*>(sO + PART_O + lane * OP + 8 * wave) = u32x4{p0.l, p1.l, p2.l, p3.l};
+        }
+        block_barrier();
+
+        // ---- phase 1: gate logits = sA . W_g^T (K = 128), phase 2: update = sO . W_z^T (K = 32); this wave: all 64 rows x columns
+        // [32 wave, +32)
+        f32x16 accg[2], accz[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accg[i][r] = 0.f; accz[i][r] = 0.f; }
+        {
+            constexpr int PF = 3;
+            f16x8 wf[PF + 1][2];
+            auto wload = [&](int buf, int ks) {
+                wf[buf][0] = wfrag_g(wave * NKS1 + ks, 0);
+                wf[buf][1] = wfrag_g(wave * NKS1 + ks, 1);
+            };
+            f16x8 wz[NKS2][2];
+#pragma unroll
+            for (int ks = 0; ks < NKS2; ++ks) { wz[ks][0] = wfrag_z(wave * NKS2 + ks, 0); wz[ks][1] = wfrag_z(wave * NKS2 + ks, 1); }
+#pragma unroll
+            for (int ks = 0; ks < PF; ++ks) wload(ks, ks);
+            const _Float16* abase = sA + l31 * LP + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < NKS1; ++ks) {
+                if (ks + PF < NKS1) wload((ks + PF) % (PF + 1), ks + PF);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 32 * i * LP + 16 * ks);
+                    const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART_A + 32 * i * LP + 16 * ks);
+                    f32x16 t = accg[i];
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][1], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[ks % (PF + 1)][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][0], t, 0, 0, 0);
+                    accg[i] = t;
+                }
+            }
+            const _Float16* obase = sO + l31 * OP + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < NKS2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f16x8 a0 = *reinterpret_cast<const f16x8*>(obase + 32 * i * OP + 16 * ks);
+                    const f16x8 a1 = *reinterpret_cast<const f16x8*>(obase + PART_O + 32 * i * OP + 16 * ks);
+                    f32x16 t = accz[i];
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wz[ks][1], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wz[ks][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wz[ks][0], t, 0, 0, 0);
+                    accz[i] = t;
+                }
+            }
+        }
+        // ---- epilogue: z += sigmoid(gate logits) * update  (lane = column: 128-byte row segments)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long rb = row0 + 32 * i + 4 * hh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = rb + (r & 3) + 8 * (r >> 2);
+                if (row < p.M) {
+                    float* zp = p.z + row * C_ + n;
+                    *zp = *zp + pd_sigmoid(accg[i][r] * cg + bg) * (accz[i][r] * cz + bz);
+                }
+            }
+        }
+        block_barrier();                          // the LDS tiles are free for the next tile
+    }
+}
+
+}  // namespace
+
+// see include/physdock_hip.h pd_tri_tail_args.  args == nullptr: one-time set-up (dynamic LDS limit), called by pd_init.
+PD_EXPORT int pd_tri_tail(const pd_tri_tail_args* a, void* stream) {
+    if (!a)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(tri_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    if (!a->z || !a->o || !a->w_in || !a->w_out || !a->Wg || !a->wg_inv || !a->Wz || !a->wz_inv || !a->zn_amax || !a->on_amax) return PD_ERR_ARG;
+    if (a->C != C_ || a->Co != CO || a->M <= 0) return PD_ERR_UNSUPPORTED;
+    if (((uintptr_t)a->z | (uintptr_t)a->w_in | (uintptr_t)a->Wg | (uintptr_t)a->Wz) & 15) return PD_ERR_UNSUPPORTED;
+    const int ntiles = (a->M + BM - 1) / BM, grid = 256 * 3;
+    hipLaunchKernelGGL(tri_tail_kernel, dim3(ntiles < grid ? ntiles : grid), dim3(4 * BM), LDS_BYTES, (hipStream_t)stream, *a);
+    return pd_check_launch();
+}

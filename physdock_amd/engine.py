@@ -214,8 +214,15 @@ class Engine:
         self.gemm(z, Wqk, qk, M, 128, C, stats=st, pro_w=nw, bias=bqk, glu=2, rowscale=mask,
                  out_mode=OUT_TRANSPOSED, ldy=M)
         Wg, bg, _, _, ldw = P.linear(prefix + ".linear_g")
-        g = self.ws.get("tri_g", M, C)
-        self.gemm(z, Wg, g, M, C, C, ldw=ldw, stats=st, pro_w=nw, bias=bg, act=ACT_SIGMOID)
+        Wz, bz, _, _, ldwz = P.linear(prefix + ".linear_z")
+        wout = P[prefix + ".norm_out.weight"]
+        # one launch for everything behind the einsum (pd_tri_tail) when the shapes are the model's (C = 128, 32 einsum channels)
+        fused = ops.FUSED_TRI_TAIL and ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM and C == 128 and ldw == C and ldwz == 32 \
+            and Wg.shape[0] == C and Wz.shape == (C, 32)
+        g = None
+        if not fused:
+            g = self.ws.get("tri_g", M, C)
+            self.gemm(z, Wg, g, M, C, C, ldw=ldw, stats=st, pro_w=nw, bias=bg, act=ACT_SIGMOID)
         o = self.ws.get("tri_o", 32, M)
         Tr = self.Tr          # the sum over j runs over REAL tokens only (padded j never enter a reduction)
         if not transpose:   # o[c,i,I] = sum_j q[c,i,j] k[c,I,j]
@@ -223,9 +230,14 @@ class Engine:
         else:               # o[c,a,b] = sum_j k[c,j,a] q[c,j,b]
             self.gemm(off(qk, 32 * M), off(qk, 0), o, T, T, Tr, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M,
                      a_kmajor=True, w_kmajor=True)
+        if fused and ops.tri_tail(z, o, M, C, 32, w_in=nw, w_out=wout, eps=self.eps, Wg=P.w2(Wg, C), bg=bg, Wz=P.w2(Wz, 32), bz=bz,
+                                  zn_amax=P.norm_bound(nw, None, C), on_amax=P.norm_bound(wout, None, 32)):
+            return
+        if g is None:
+            g = self.ws.get("tri_g", M, C)
+            self.gemm(z, Wg, g, M, C, C, ldw=ldw, stats=st, pro_w=nw, bias=bg, act=ACT_SIGMOID)
         st2 = self.stats(o, M, 32, RMS, self.eps, "stats_tri", kmajor=True, ldx=M)
-        Wz, bz, _, _, ldw = P.linear(prefix + ".linear_z")
-        self.gemm(o, Wz, z, M, C, 32, a_kmajor=True, lda=M, ldw=ldw, stats=st2, pro_w=P[prefix + ".norm_out.weight"],
+        self.gemm(o, Wz, z, M, C, 32, a_kmajor=True, lda=M, ldw=ldwz, stats=st2, pro_w=wout,
                  bias=bz, mul=g, ldmul=C, res=z)
 
     def triangle_attention(self, prefix, z, T, C, mask, transpose):

@@ -191,6 +191,8 @@ FUSED_TRANSITION = True
 TRANSITION_HOOK = None
 #: ... and the trunk's pair transition (RMSNorm, static gain; [T*T][128] rows) on the same kernel
 FUSED_TRUNK_TRANSITION = True
+#: the tail of the TriangleUpdate (gate projection, norm of the einsum output, K = 32 projection, gate, residual) in one launch
+FUSED_TRI_TAIL = True
 #: fp16-parts attention launches write their output already split for the projection that follows (pd_attn_args.O2 -> A2)
 ATTN_SPLIT_OUT = True
 #: the q|k|v projection writes k | v already scaled and split for the fp16-parts attention kernel (pd_gemm_args.Y2 -> pd_attn_args.K2 / V2):
@@ -251,6 +253,21 @@ def transition_f16(x, M, Cdim, hidden, *, shift, scale1p, gate, W13, W2, y_amax,
     if TRANSITION_HOOK is not None:          # profiling hook (bench.py): brackets the launch
         return TRANSITION_HOOK(a, launch)
     return launch()
+
+
+def tri_tail(z, o, M, Cdim, Co, *, w_in, w_out, eps, Wg, bg, Wz, bz, zn_amax, on_amax):
+    """tail of a TriangleUpdate in one launch (pd_tri_tail): z += sigmoid(Wg RMSNorm(z) + bg) * (Wz RMSNorm(o) + bz); Wg / Wz:
+    (parts, w_inv) of packing.split2_f16.  Returns False when the library does not cover the shape."""
+    a = _lib.TriTailArgs()
+    a.z, a.o, a.M, a.C, a.Co = ptr(z), ptr(o), M, Cdim, Co
+    a.w_in, a.w_out, a.eps = ptr(w_in), ptr(w_out), eps
+    a.Wg, a.wg_inv, a.bg = Wg[0].data_ptr(), Wg[1].data_ptr(), ptr(bg)
+    a.Wz, a.wz_inv, a.bz = Wz[0].data_ptr(), Wz[1].data_ptr(), ptr(bz)
+    a.zn_amax, a.on_amax = ptr(zn_amax), ptr(on_amax)
+    rc = _lib.init().pd_tri_tail(C.byref(a), stream())
+    if rc != -3:
+        check(rc, "pd_tri_tail")
+    return rc != -3
 
 
 def rownorm(x, y, M, Cdim, *, res=None, w=None, b=None, mode=RMS, eps=1e-8, act=ACT_NONE):

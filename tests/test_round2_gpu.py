@@ -82,19 +82,19 @@ def test_medium_trajectories_vs_reference(medium, tag):
         from physdock_amd import ops
         seen, aseen = [], []
         L = ops._lib.init()
-        ops.GEMM_HOOK = lambda a, launch: (seen.append((L.pd_gemm_variant(C.byref(a)), a.M)), launch())
+        ops.GEMM_HOOK = lambda a, launch: (seen.append((L.pd_gemm_variant(C.byref(a)), a.M, bool(a.K >= 128 and not a.a_kmajor and (a.hn_w or a.glu or (a.mul and a.res))))), launch())
         ops.ATTN_HOOK = lambda a, launch: (aseen.append((L.pd_attention_variant(C.byref(a)), a.nbatch)), launch())
         try:
             x = medium.sample_diffusion(to_dev(batch), use_graph=False, **kw)
         finally:
             ops.GEMM_HOOK = ops.ATTN_HOOK = None
-        # DiT launches (rows = samples x atoms / tokens): every GEMM on the fp16-format kernel (>= 2000000 - a silent fall-back to
-        # bf16 x 6, 1000000 +, or to the fp32 MFMA would show here), every attention on its 8-wave form: the pipelined kernel
-        # (3008) at 32 samples, as in the benchmark; at 16 samples the pipelined or the plain fp16-format kernel (2008)
+        # The four projections of every DiT block (q|k|v with the head norm, linear_o and w2 with gate + residual, the SwiGLU up-
+        # projection; rows = samples x atoms / tokens): all on the fp16-format kernel (>= 2000000 - a silent fall-back to bf16 x 6,
+        # 1000000 +, or to the fp32 MFMA would show here); every attention on its 8-wave form: the pipelined kernel (3008) at 32
+        # samples, as in the benchmark; at 16 samples the pipelined or the plain fp16-format kernel (2008)
         Aat, Tt = batch["ref_pos"].shape[0], batch["target_feat"].shape[0]
-        dit = [v for v, M in seen if M in (B * Aat, B * Tt)]
-        low = [v for v in dit if v < 2000000]       # the pool / un-pool projections read the residual stream (no norm, no bound): bf16 x 6
-        assert dit and len(low) == 2 * g["steps"] and all(v >= 1000000 for v in low), (len(low), sorted(set(dit)))
+        dit = [v for v, M, blk in seen if blk and M in (B * Aat, B * Tt)]
+        assert len(dit) >= 3 * 12 * g["steps"] and all(v >= 2000000 for v in dit), (len(dit), sorted(set(dit)))
         adit = [v for v, nb in aseen if nb == B]
         assert adit and set(adit) <= ({3008} if tag == "cfg1_b32" else {3008, 2008}), sorted(set(adit))
         print(f"medium/{tag}: {len(dit)} DiT GEMM launches, variants {sorted(set(dit))}; {len(adit)} DiT attention launches, variants {sorted(set(adit))}")

@@ -17,7 +17,7 @@ tau = torch.linspace(0, 1, 40, device=dev)
 
 def trunk():
     a, ap, s, z = eng.conditioning(b)
-    return eng.prepare_dit(a, ap, s, z, b, tau)
+    return eng.prepare_dit(a, ap, s, z, b, tau, B=args.samples)
 
 
 for _ in range(2):
