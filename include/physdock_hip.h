@@ -174,6 +174,19 @@ typedef struct pd_tri_tail_args {
 } pd_tri_tail_args;
 int pd_tri_tail(const pd_tri_tail_args* args, void* stream);
 
+/* ---- pd_tri_mul (ABI 7): the triangle-multiplication einsum (attentions.py:164) on the two-part fp16 format ----------------------
+ * transpose == 0:  o[c,i,I] = sum_{j < Treal} q[c,i,j] k[c,I,j];   transpose == 1:  o[c,a,b] = sum_{j < Treal} k[c,j,a] q[c,j,b]
+ * for nch channel planes [T][T] (plane stride ch_stride floats) of q, k, o; q_amax / k_amax: device scalars bounding |q|, |k|
+ * (the gated projection's linear part: ||W_n w||_2 sqrt(C) + |b_n|).  T % 4 == 0.                                              */
+typedef struct pd_tri_mul_args {
+    const float* q; const float* k; float* o;
+    int T, Treal, nch;
+    long long ch_stride;
+    int transpose;
+    const float* q_amax; const float* k_amax;
+} pd_tri_mul_args;
+int pd_tri_mul(const pd_tri_mul_args* args, void* stream);
+
 /* ---- pd_pair_bias: attention pair bias in one streaming pass (pairbias.hip) -------------------
  * frag = fragment layout of [ (norm(x) . Wf^T + c2 + maskadd ? 0 : maskval) * out_scale ] for x [T1*T2, C] (C = 16 or 128),
  * Wf [H][C] = projection weights with the norm gain folded in (Wf[h][k] = w[k] W[h][k]), c2 [H] = projection of the norm

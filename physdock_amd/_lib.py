@@ -92,6 +92,12 @@ class TriTailArgs(C.Structure):
                 ("zn_amax", _fp), ("on_amax", _fp)]
 
 
+class TriMulArgs(C.Structure):
+    """mirror of pd_tri_mul_args"""
+    _fields_ = [("q", _fp), ("k", _fp), ("o", _fp), ("T", C.c_int), ("Treal", C.c_int), ("nch", C.c_int), ("ch_stride", C.c_longlong),
+                ("transpose", C.c_int), ("q_amax", _fp), ("k_amax", _fp)]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -180,6 +186,7 @@ def _declare(L):
     sig("pd_norm_split2", p, i, i, i, i, f, p, p, i, i, p, p, p)
     sig("pd_transition_f16", C.POINTER(TransitionArgs), p)
     sig("pd_tri_tail", C.POINTER(TriTailArgs), p)
+    sig("pd_tri_mul", C.POINTER(TriMulArgs), p)
     sig("pd_mmff_energy_grad", p, p, p, p, i, p)
     sig("pd_mmff_relax", p, p, p, p, p, ll, i, i, i, p)
     sig("pd_chirality", p, p, p, p, p, i, i, i, p)

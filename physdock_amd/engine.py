@@ -225,7 +225,13 @@ class Engine:
             self.gemm(z, Wg, g, M, C, C, ldw=ldw, stats=st, pro_w=nw, bias=bg, act=ACT_SIGMOID)
         o = self.ws.get("tri_o", 32, M)
         Tr = self.Tr          # the sum over j runs over REAL tokens only (padded j never enter a reduction)
-        if not transpose:   # o[c,i,I] = sum_j q[c,i,j] k[c,I,j]
+        f16mul = False
+        if ops.F16_TRI_MUL and ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM and Wqk.shape[0] == 128:
+            bq = P.tri_qk_bounds(prefix, nw)         # static bounds of |q|, |k|: the einsum takes the two-part fp16 format
+            f16mul = ops.tri_mul(off(qk, 0), off(qk, 32 * M), o, T, Tr, 32, M, transpose=transpose, q_amax=bq.data_ptr(), k_amax=bq.data_ptr() + 4)
+        if f16mul:
+            pass
+        elif not transpose:   # o[c,i,I] = sum_j q[c,i,j] k[c,I,j]
             self.gemm(off(qk, 0), off(qk, 32 * M), o, T, T, Tr, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M)
         else:               # o[c,a,b] = sum_j k[c,j,a] q[c,j,b]
             self.gemm(off(qk, 32 * M), off(qk, 0), o, T, T, Tr, lda=T, ldw=T, ldy=T, batch=32, sA=M, sW=M, sY=M,

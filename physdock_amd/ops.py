@@ -193,6 +193,8 @@ TRANSITION_HOOK = None
 FUSED_TRUNK_TRANSITION = True
 #: the tail of the TriangleUpdate (gate projection, norm of the einsum output, K = 32 projection, gate, residual) in one launch
 FUSED_TRI_TAIL = True
+#: the triangle einsum on the two-part fp16 format (csrc/tri_mul.hip) instead of 32 batched fp32-MFMA GEMMs
+F16_TRI_MUL = True
 #: fp16-parts attention launches write their output already split for the projection that follows (pd_attn_args.O2 -> A2)
 ATTN_SPLIT_OUT = True
 #: the q|k|v projection writes k | v already scaled and split for the fp16-parts attention kernel (pd_gemm_args.Y2 -> pd_attn_args.K2 / V2):
@@ -267,6 +269,21 @@ def tri_tail(z, o, M, Cdim, Co, *, w_in, w_out, eps, Wg, bg, Wz, bz, zn_amax, on
     rc = _lib.init().pd_tri_tail(C.byref(a), stream())
     if rc != -3:
         check(rc, "pd_tri_tail")
+    return rc != -3
+
+
+def tri_mul(q, k, o, T, Treal, nch, ch_stride, *, transpose, q_amax, k_amax):
+    """triangle-multiplication einsum on the two-part fp16 format (pd_tri_mul); q / k / o: tensors or raw device addresses.
+    Returns False when the library does not cover the shape."""
+    def P(x):
+        return x if isinstance(x, int) else ptr(x)
+    a = _lib.TriMulArgs()
+    a.q, a.k, a.o = P(q), P(k), P(o)
+    a.T, a.Treal, a.nch, a.ch_stride, a.transpose = T, Treal, nch, ch_stride, int(transpose)
+    a.q_amax, a.k_amax = P(q_amax), P(k_amax)
+    rc = _lib.init().pd_tri_mul(C.byref(a), stream())
+    if rc != -3:
+        check(rc, "pd_tri_mul")
     return rc != -3
 
 

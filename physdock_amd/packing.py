@@ -204,6 +204,18 @@ class PackedWeights:
             return (torch.cat([Wa, Wb], 0).contiguous(), torch.cat([ba, bb]).contiguous())
         return self._c(("triqk", prefix), mk)
 
+    def tri_qk_bounds(self, prefix, norm_weight):
+        """device floats [2]: rigorous upper bounds of the triangle update's gated operands q = (W_qx zn + b) sigmoid(.) mask and k
+        (same with kx): |sigmoid| <= 1, mask in [0, 1], zn = x^ w with ||x^||_2 <= sqrt(C) - weights only, any input"""
+        def mk():
+            w = norm_weight.double()
+            out = []
+            for c in ("qx", "kx"):
+                W, b = self.p[f"{prefix}.linear_{c}.weight"].double(), self.p[f"{prefix}.linear_{c}.bias"].double()
+                out.append(float(((W * w[None, :]).norm(dim=1) * math.sqrt(W.shape[1]) + b.abs()).max()) * 1.0001)
+            return torch.tensor(out, dtype=torch.float32, device=norm_weight.device)
+        return self._c(("triqk_bounds", prefix, norm_weight.data_ptr()), mk)
+
     def bias_w(self, prefix, norm_name):
         """linear_z weights of an attention with the gain of the norm in front folded in: Wf[h][k] = w[k] W[h][k]"""
         return self._c(("biasw", prefix, norm_name), lambda: (

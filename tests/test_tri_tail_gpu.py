@@ -75,3 +75,38 @@ def test_trunk_with_and_without_the_fused_tail_agree():
         print(f"conditioning {name}: fused tail vs three launches max |diff| / max|x| = {rel:.2e}")
         assert rel < 2e-4
     model.release_workspace()
+
+
+@pytest.mark.parametrize("T,Tr,transpose", [(256, 256, False), (256, 256, True), (260, 257, False), (260, 257, True), (64, 64, True), (36, 33, False)])
+def test_tri_mul_vs_float64(T, Tr, transpose):
+    """pd_tri_mul (csrc/tri_mul.hip): both forms of the triangle einsum on the two-part fp16 format against float64, next to the
+    fp32-MFMA batched GEMMs it replaces; operands with a wide dynamic range, bounds given as loose upper bounds"""
+    from physdock_amd import ops
+    nch, M = 32, T * T
+    wide = lambda x, s: x * torch.exp(1.5 * torch.randn(x.shape, generator=g(s)))
+    q = wide(torch.randn(nch, T, T, generator=g(1)), 11)
+    k = wide(torch.randn(nch, T, T, generator=g(2)), 12)
+    # padded pairs are zero in both operands (the projection multiplies by the pair mask)
+    q[:, Tr:, :] = 0; q[:, :, Tr:] = 0; k[:, Tr:, :] = 0; k[:, :, Tr:] = 0
+    qd, kd = q.double(), k.double()
+    ref = torch.einsum("cja,cjb->cab", kd, qd) if transpose else torch.einsum("cij,cIj->ciI", qd, kd)
+    qc, kc = q.cuda().contiguous(), k.cuda().contiguous()
+    amax = torch.tensor([2.0 * float(q.abs().max()), 1.5 * float(k.abs().max())], device="cuda")
+    o = torch.full((nch, T, T), float("nan"), device="cuda")
+    assert ops.tri_mul(qc, kc, o, T, Tr, nch, M, transpose=transpose, q_amax=amax.data_ptr(), k_amax=amax.data_ptr() + 4)
+    o32 = torch.empty(nch, T, T, device="cuda")
+    off = lambda t, n: t.data_ptr() + 4 * n
+    if not transpose:
+        ops.gemm(qc, kc, o32, T, T, Tr, lda=T, ldw=T, ldy=T, batch=nch, sA=M, sW=M, sY=M)
+    else:
+        ops.gemm(kc, qc, o32, T, T, Tr, lda=T, ldw=T, ldy=T, batch=nch, sA=M, sW=M, sY=M, a_kmajor=True, w_kmajor=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o).all()
+    den = torch.einsum("cja,cjb->cab", kd.abs(), qd.abs()) if transpose else torch.einsum("cij,cIj->ciI", qd.abs(), kd.abs())
+    den = den.clamp_min(1e-30)
+    e16 = ((o.cpu().double() - ref).abs() / den)[:, :Tr, :Tr]
+    e32 = ((o32.cpu().double() - ref).abs() / den)[:, :Tr, :Tr]
+    print(f"tri_mul T={T} real {Tr} transpose={transpose}: error / sum|q k| max {float(e16.max()):.2e} rms {float(e16.pow(2).mean().sqrt()):.2e} "
+          f"(fp32 MFMA: {float(e32.max()):.2e} {float(e32.pow(2).mean().sqrt()):.2e})")
+    assert float(e16.pow(2).mean().sqrt()) <= 1.05 * float(e32.pow(2).mean().sqrt()) + 1e-9
+    assert float(e16.max()) <= 1.5 * float(e32.max()) + 1e-8
