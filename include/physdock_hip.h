@@ -171,6 +171,9 @@ typedef struct pd_tri_tail_args {
     const void* Wg; const float* wg_inv; const float* bg;
     const void* Wz; const float* wz_inv; const float* bz;
     const float* zn_amax; const float* on_amax;
+    int mode;                    /* 0: TriangleUpdate tail as above.  1: TriangleAttention tail (attentions.py:204,212-213):
+                                    z[m,:] += (W_g RMSNorm(z[m,:]) w_in + b_g) * (W_z o[m,:] + b_z) with the attention output o [M][C]
+                                    (row-major, Co = C, |o| <= *on_amax = the v bound), a RAW gate, w_out unused              */
 } pd_tri_tail_args;
 int pd_tri_tail(const pd_tri_tail_args* args, void* stream);
 

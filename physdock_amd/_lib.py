@@ -89,7 +89,7 @@ class TriTailArgs(C.Structure):
     """mirror of pd_tri_tail_args"""
     _fields_ = [("z", _fp), ("o", _fp), ("M", C.c_int), ("C", C.c_int), ("Co", C.c_int), ("w_in", _fp), ("w_out", _fp),
                 ("eps", C.c_float), ("Wg", _fp), ("wg_inv", _fp), ("bg", _fp), ("Wz", _fp), ("wz_inv", _fp), ("bz", _fp),
-                ("zn_amax", _fp), ("on_amax", _fp)]
+                ("zn_amax", _fp), ("on_amax", _fp), ("mode", C.c_int)]
 
 
 class TriMulArgs(C.Structure):

@@ -9,6 +9,11 @@
 // runs the two contractions (K = 128 and K = 32) with weight fragments straight from global memory, and finishes with one
 // read-modify-write of z.  HBM sees z in, o in, z out.  Operand format and accuracy: gemm_f16.hip (bounds: a normalised row
 // times a static gain is bounded by sqrt(K) max|w|).
+//
+// MODE 1 is the tail of the trunk's TriangleAttention (attentions.py:204,212-213) on the same structure:
+//        z[m,:] += (W_g RMSNorm(z[m,:]) + b_g) * (W_o o[m,:] + b_o)
+// with the attention output o [M][128] (row-major, bounded by max|v|) as the second operand, K = 128 for both contractions and a
+// RAW gate: the q|k|v|g projection shrinks to q|k|v (a quarter of its 134 MB output gone) and the gate tensor never exists.
 #include "gemm_tile_common.h"
 
 namespace {
@@ -21,12 +26,17 @@ constexpr int C_ = 128;                 // pair channels
 constexpr int CO = 32;                  // einsum channels
 constexpr int BM = 64;                  // rows per block tile
 constexpr int LP = 136;                 // LDS row pitch of the z operand in fp16 (272 bytes)
-constexpr int OP = 40;                  // ... of the o operand (80 bytes)
-constexpr int PART_A = BM * LP, PART_O = BM * OP;
-constexpr int LDS_BYTES = (2 * PART_A + 2 * PART_O) * 2 + 4 * BM * 4;
-constexpr int NKS1 = C_ / 16, NKS2 = CO / 16;
+template <int MODE> struct TM {
+    static constexpr int K2 = MODE == 0 ? CO : C_;           // second contraction's K
+    static constexpr int OP = MODE == 0 ? 40 : LP;           // LDS row pitch of the second operand (80 / 272 bytes)
+    static constexpr int PART_O = BM * OP;
+    static constexpr int NKS2 = K2 / 16;
+    static constexpr int WZPART = (C_ / 32) * NKS2 * 1024;   // bytes per part of the second weight matrix
+    static constexpr int LDS_BYTES = (2 * BM * LP + 2 * PART_O) * 2 + 4 * BM * 4;
+};
+constexpr int PART_A = BM * LP;
+constexpr int NKS1 = C_ / 16;
 constexpr int WGPART = (C_ / 32) * NKS1 * 1024;          // bytes per part of W_g (1 KB fragment blocks)
-constexpr int WZPART = (C_ / 32) * NKS2 * 1024;
 
 __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
@@ -35,7 +45,9 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
 }
 
+template <int MODE>
 __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args p) {
+    constexpr int OP = TM<MODE>::OP, PART_O = TM<MODE>::PART_O, NKS2 = TM<MODE>::NKS2, WZPART = TM<MODE>::WZPART;
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     _Float16* sA = lds;                          // [2][BM][LP]   RMSNorm_in(z) w_in, scaled and split
     _Float16* sO = lds + 2 * PART_A;             // [2][BM][OP]   RMSNorm_out(o) w_out, scaled and split
@@ -90,29 +102,45 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                 *reinterpret_cast<u32x2*>(sA + PART_A + r * LP + c) = u32x2{p0.l, p1.l};
             }
         }
-        // ---- phase 0b: the 32 einsum channels of the tile's rows: wave = 8 channels, lane = row (coalesced along m)
-        float ov[8];
-        {
-            const bool live = row0 + lane < p.M;
-            const float* orow = p.o + row0 + (live ? lane : 0);
-            float ss = 0.f;
+        if constexpr (MODE == 0) {
+            // ---- phase 0b: the 32 einsum channels of the tile's rows: wave = 8 channels, lane = row (coalesced along m)
+            float ov[8];
+            {
+                const bool live = row0 + lane < p.M;
+                const float* orow = p.o + row0 + (live ? lane : 0);
+                float ss = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ov[e] = live ? orow[(long long)(8 * wave + e) * p.M] : 0.f;
-                ss += ov[e] * ov[e];
+                for (int e = 0; e < 8; ++e) {
+                    ov[e] = live ? orow[(long long)(8 * wave + e) * p.M] : 0.f;
+                    ss += ov[e] * ov[e];
+                }
+                red[wave * BM + lane] = ss;
             }
-            red[wave * BM + lane] = ss;
-        }
-        block_barrier();
-        {
-            const float ss = red[lane] + red[BM + lane] + red[2 * BM + lane] + red[3 * BM + lane];
-            const float rstd = rsqrtf(ss * (1.0f / CO) + p.eps) * o_s;
-            float t[8];
+            block_barrier();
+            {
+                const float ss = red[lane] + red[BM + lane] + red[2 * BM + lane] + red[3 * BM + lane];
+                const float rstd = rsqrtf(ss * (1.0f / CO) + p.eps) * o_s;
+                float t[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = ov[e] * rstd * p.w_out[8 * wave + e];
-            const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]), p2 = pd_split2h(t[4], t[5]), p3 = pd_split2h(t[6], t[7]);
-            *reinterpret_cast<u32x4*>(sO + lane * OP + 8 * wave) = u32x4{p0.h, p1.h, p2.h, p3.h};
-            *reinterpret_cast<u32x4*>(sO + PART_O + lane * OP + 8 * wave) = u32x4{p0.l, p1.l, p2.l, p3.l};
+                for (int e = 0; e < 8; ++e) t[e] = ov[e] * rstd * p.w_out[8 * wave + e];
+                const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]), p2 = pd_split2h(t[4], t[5]), p3 = pd_split2h(t[6], t[7]);
+                *reinterpret_cast<u32x4*>(sO + lane * OP + 8 * wave) = u32x4{p0.h, p1.h, p2.h, p3.h};
+                *reinterpret_cast<u32x4*>(sO + PART_O + lane * OP + 8 * wave) = u32x4{p0.l, p1.l, p2.l, p3.l};
+            }
+        } else {
+            // ---- phase 0b: the attention output rows (row-major, no norm): scale -> split -> sO
+            const int r = tid >> 2, q = tid & 3;
+            const bool live = row0 + r < p.M;
+            const float* orow = p.o + (row0 + (live ? r : 0)) * C_;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 4 * (q + 4 * i);
+                f32x4 v = *reinterpret_cast<const f32x4*>(orow + c);
+                if (!live) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                const pd_parts2 p0 = pd_split2h(v[0] * o_s, v[1] * o_s), p1 = pd_split2h(v[2] * o_s, v[3] * o_s);
+                *reinterpret_cast<u32x2*>(sO + r * OP + c) = u32x2{p0.h, p1.h};
+                *reinterpret_cast<u32x2*>(sO + PART_O + r * OP + c) = u32x2{p0.l, p1.l};
+            }
         }
         block_barrier();
 
@@ -130,9 +158,6 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                 wf[buf][0] = wfrag_g(wave * NKS1 + ks, 0);
                 wf[buf][1] = wfrag_g(wave * NKS1 + ks, 1);
             };
-            f16x8 wz[NKS2][2];
-#pragma unroll
-            for (int ks = 0; ks < NKS2; ++ks) { wz[ks][0] = wfrag_z(wave * NKS2 + ks, 0); wz[ks][1] = wfrag_z(wave * NKS2 + ks, 1); }
 #pragma unroll
             for (int ks = 0; ks < PF; ++ks) wload(ks, ks);
             const _Float16* abase = sA + l31 * LP + 8 * hh;
@@ -150,17 +175,26 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                     accg[i] = t;
                 }
             }
+            // second contraction: the same ring on the second weight matrix (NKS2 = 2 or 8 steps)
+            constexpr int PF2 = NKS2 < PF ? NKS2 : PF;
+            auto zload = [&](int buf, int ks) {
+                wf[buf][0] = wfrag_z(wave * NKS2 + ks, 0);
+                wf[buf][1] = wfrag_z(wave * NKS2 + ks, 1);
+            };
+#pragma unroll
+            for (int ks = 0; ks < PF2; ++ks) zload(ks, ks);
             const _Float16* obase = sO + l31 * OP + 8 * hh;
 #pragma unroll
             for (int ks = 0; ks < NKS2; ++ks) {
+                if (ks + PF2 < NKS2) zload((ks + PF2) % (PF + 1), ks + PF2);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const f16x8 a0 = *reinterpret_cast<const f16x8*>(obase + 32 * i * OP + 16 * ks);
                     const f16x8 a1 = *reinterpret_cast<const f16x8*>(obase + PART_O + 32 * i * OP + 16 * ks);
                     f32x16 t = accz[i];
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wz[ks][1], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wz[ks][0], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wz[ks][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][1], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[ks % (PF + 1)][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][0], t, 0, 0, 0);
                     accz[i] = t;
                 }
             }
@@ -174,7 +208,8 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                 const long long row = rb + (r & 3) + 8 * (r >> 2);
                 if (row < p.M) {
                     float* zp = p.z + row * C_ + n;
-                    *zp = *zp + pd_sigmoid(accg[i][r] * cg + bg) * (accz[i][r] * cz + bz);
+                    const float gl = accg[i][r] * cg + bg;
+                    *zp = *zp + (MODE == 0 ? pd_sigmoid(gl) : gl) * (accz[i][r] * cz + bz);
                 }
             }
         }
@@ -184,15 +219,24 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
 
 }  // namespace
 
-// see include/physdock_hip.h pd_tri_tail_args.  args == nullptr: one-time set-up (dynamic LDS limit), called by pd_init.
+// see include/physdock_hip.h pd_tri_tail_args.  args == nullptr: one-time set-up (dynamic LDS limits), called by pd_init.
 PD_EXPORT int pd_tri_tail(const pd_tri_tail_args* a, void* stream) {
     if (!a)
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(tri_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(tri_tail_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, TM<0>::LDS_BYTES) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(tri_tail_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, TM<1>::LDS_BYTES) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
-    if (!a->z || !a->o || !a->w_in || !a->w_out || !a->Wg || !a->wg_inv || !a->Wz || !a->wz_inv || !a->zn_amax || !a->on_amax) return PD_ERR_ARG;
-    if (a->C != C_ || a->Co != CO || a->M <= 0) return PD_ERR_UNSUPPORTED;
-    if (((uintptr_t)a->z | (uintptr_t)a->w_in | (uintptr_t)a->Wg | (uintptr_t)a->Wz) & 15) return PD_ERR_UNSUPPORTED;
-    const int ntiles = (a->M + BM - 1) / BM, grid = 256 * 3;
-    hipLaunchKernelGGL(tri_tail_kernel, dim3(ntiles < grid ? ntiles : grid), dim3(4 * BM), LDS_BYTES, (hipStream_t)stream, *a);
+    if (!a->z || !a->o || !a->w_in || !a->Wg || !a->wg_inv || !a->Wz || !a->wz_inv || !a->zn_amax || !a->on_amax) return PD_ERR_ARG;
+    if (a->mode == 0 && !a->w_out) return PD_ERR_ARG;
+    if (a->mode != 0 && a->mode != 1) return PD_ERR_ARG;
+    if (a->C != C_ || a->Co != (a->mode == 0 ? CO : C_) || a->M <= 0) return PD_ERR_UNSUPPORTED;
+    if (((uintptr_t)a->z | (uintptr_t)a->w_in | (uintptr_t)a->Wg | (uintptr_t)a->Wz | (a->mode ? (uintptr_t)a->o : 0)) & 15) return PD_ERR_UNSUPPORTED;
+    const int ntiles = (a->M + BM - 1) / BM;
+    if (a->mode == 0) {
+        const int grid = 256 * 3;
+        hipLaunchKernelGGL(tri_tail_kernel<0>, dim3(ntiles < grid ? ntiles : grid), dim3(4 * BM), TM<0>::LDS_BYTES, (hipStream_t)stream, *a);
+    } else {
+        const int grid = 256 * 2;
+        hipLaunchKernelGGL(tri_tail_kernel<1>, dim3(ntiles < grid ? ntiles : grid), dim3(4 * BM), TM<1>::LDS_BYTES, (hipStream_t)stream, *a);
+    }
     return pd_check_launch();
 }

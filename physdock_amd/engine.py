@@ -257,18 +257,35 @@ class Engine:
         bias = self.ws.get("tri_bias", ops.bias_frag_numel(H, T, T), zero=True)
         ps = self.trunk_prescale(prefix, nw, T, T, self.Tr, H)
         self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, norm="norm", st_out=st, prescale=ps)
-        W, b = P.qkvg(prefix)
-        qkvg = self.ws.get("qkvg", M, 4 * C)
-        self.gemm(z, W, qkvg, M, 4 * C, C, stats=st, pro_w=nw, bias=b)
+        bnd = self.trunk_attn_bounds(prefix, nw)
+        Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
+        # With the fused tail (pd_tri_tail mode 1: gate projection + linear_o + gate + residual in one launch) the projection in
+        # front is q|k|v only and the gate tensor never exists
+        fused = bnd is not None and ops.FUSED_TRI_ATTN_TAIL and ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM and C == 128 and ldw == C
+        nq = 3 if fused else 4
         o = self.ws.get("attn_o", M, C)
-        if not transpose:
-            st4, sto = (T * 4 * C, 4 * C), (T * C, C)
+        if fused:
+            W, b, Wg, bg = P.qkv_g(prefix)
+            qkvg = self.ws.get("qkv3", M, 3 * C)
         else:
-            st4, sto = (4 * C, T * 4 * C), (C, T * C)
+            W, b = P.qkvg(prefix)
+            qkvg = self.ws.get("qkvg", M, 4 * C)
+        self.gemm(z, W, qkvg, M, nq * C, C, stats=st, pro_w=nw, bias=b)
+        if not transpose:
+            st4, sto = (T * nq * C, nq * C), (T * C, C)
+        else:
+            st4, sto = (nq * C, T * nq * C), (C, T * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
                       q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T,
-                      f16_amax=(bnd := self.trunk_attn_bounds(prefix, nw)), bias_prescale=ps)
-        Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
+                      f16_amax=bnd, bias_prescale=ps)
+        if fused and ops.tri_tail(z, o, M, C, C, w_in=nw, w_out=None, eps=self.eps, Wg=P.w2(Wg, C), bg=bg, Wz=P.w2(Wo, C), bz=bo,
+                                  zn_amax=P.norm_bound(nw, None, C), on_amax=self.o_bound(bnd), mode=1):
+            return
+        if fused:         # (shape outside the kernel: the gate as its own projection, then the three-operand epilogue)
+            gt = self.ws.get("tri_g", M, C)
+            self.gemm(z, Wg, gt, M, C, C, stats=st, pro_w=nw, bias=bg)
+            self.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=gt, ldmul=C, res=z, a_amax=self.o_bound(bnd))
+            return
         self.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=off(qkvg, 3 * C), ldmul=4 * C, res=z, a_amax=self.o_bound(bnd))
 
     def triangle_block(self, prefix, z, T, C, mask, maskT):

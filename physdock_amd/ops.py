@@ -193,6 +193,8 @@ TRANSITION_HOOK = None
 FUSED_TRUNK_TRANSITION = True
 #: the tail of the TriangleUpdate (gate projection, norm of the einsum output, K = 32 projection, gate, residual) in one launch
 FUSED_TRI_TAIL = True
+#: ... and the tail of the TriangleAttention (gate projection, linear_o, gate, residual; the projection in front shrinks to q|k|v)
+FUSED_TRI_ATTN_TAIL = True
 #: the triangle einsum on the two-part fp16 format (csrc/tri_mul.hip) instead of 32 batched fp32-MFMA GEMMs
 F16_TRI_MUL = True
 #: fp16-parts attention launches write their output already split for the projection that follows (pd_attn_args.O2 -> A2)
@@ -257,15 +259,16 @@ def transition_f16(x, M, Cdim, hidden, *, shift, scale1p, gate, W13, W2, y_amax,
     return launch()
 
 
-def tri_tail(z, o, M, Cdim, Co, *, w_in, w_out, eps, Wg, bg, Wz, bz, zn_amax, on_amax):
+def tri_tail(z, o, M, Cdim, Co, *, w_in, w_out, eps, Wg, bg, Wz, bz, zn_amax, on_amax, mode=0):
     """tail of a TriangleUpdate in one launch (pd_tri_tail): z += sigmoid(Wg RMSNorm(z) + bg) * (Wz RMSNorm(o) + bz); Wg / Wz:
     (parts, w_inv) of packing.split2_f16.  Returns False when the library does not cover the shape."""
     a = _lib.TriTailArgs()
     a.z, a.o, a.M, a.C, a.Co = ptr(z), ptr(o), M, Cdim, Co
-    a.w_in, a.w_out, a.eps = ptr(w_in), ptr(w_out), eps
+    a.w_in, a.w_out, a.eps = ptr(w_in), (ptr(w_out) if w_out is not None else None), eps
     a.Wg, a.wg_inv, a.bg = Wg[0].data_ptr(), Wg[1].data_ptr(), ptr(bg)
     a.Wz, a.wz_inv, a.bz = Wz[0].data_ptr(), Wz[1].data_ptr(), ptr(bz)
-    a.zn_amax, a.on_amax = ptr(zn_amax), ptr(on_amax)
+    a.zn_amax, a.on_amax = (zn_amax if isinstance(zn_amax, int) else ptr(zn_amax)), (on_amax if isinstance(on_amax, int) else ptr(on_amax))
+    a.mode = int(mode)
     rc = _lib.init().pd_tri_tail(C.byref(a), stream())
     if rc != -3:
         check(rc, "pd_tri_tail")

@@ -151,6 +151,12 @@ class PackedWeights:
             return (W, b)
         return self._c(("qkvg", prefix), mk)
 
+    def qkv_g(self, prefix):
+        """q|k|v rows of the packed q|k|v|g projection (a view: the first 3 C rows) and the separate gate projection (W_g, b_g)"""
+        W, b = self.qkvg(prefix)
+        C3 = 3 * (W.shape[0] // 4)
+        return W[:C3], b[:C3], self.p[prefix + ".linear_g.weight"], self.p[prefix + ".linear_g.bias"]
+
     def attn_static_bounds_host(self, prefix, norm_weight):
         """[|q|, |k|, |v|] rigorous upper bounds of a trunk attention whose projections (no bias) read an RMS- / LayerNorm-ed row
         times the static gain `norm_weight`: |W_n . (x^ w)| <= ||W_n w||_2 ||x^||_2 and ||x^||_2 <= sqrt(C) (Cauchy-Schwarz;

@@ -52,8 +52,41 @@ def test_tri_tail_vs_float64(M):
     assert float(err.max()) <= 3.0 * float(err32.max()) + 1e-6 * scale
 
 
+@pytest.mark.parametrize("M", [65536, 260 * 260, 100])
+def test_tri_attention_tail_vs_float64(M):
+    """pd_tri_tail mode 1: z += (W_g RMSNorm(z) + b_g) * (W_o o + b_o) - the tail of the TriangleAttention (raw gate)"""
+    from physdock_amd import ops
+    from physdock_amd.packing import split2_f16
+    C, eps = 128, 1e-8
+    z = (torch.randn(M, C, generator=g(1)) * torch.exp(torch.randn(M, 1, generator=g(2)))).cuda()
+    o = (2.0 * torch.randn(M, C, generator=g(3)) * torch.exp(torch.randn(M, C, generator=g(4)))).cuda()
+    w_in = (1 + 0.2 * torch.randn(C, generator=g(5))).cuda()
+    Wg = (torch.randn(C, C, generator=g(7)) / math.sqrt(C)).cuda()
+    bg = (0.3 * torch.randn(C, generator=g(8))).cuda()
+    Wo = (torch.randn(C, C, generator=g(9)) / math.sqrt(C)).cuda()
+    bo = (0.3 * torch.randn(C, generator=g(10))).cuda()
+    zd, od = z.double(), o.double()
+    zn = zd * torch.rsqrt(zd.pow(2).mean(-1, keepdim=True) + eps) * w_in.double()
+    ref = zd + (zn @ Wg.double().t() + bg.double()) * (od @ Wo.double().t() + bo.double())
+    out = z.clone()
+    zb = torch.tensor([math.sqrt(C) * float(w_in.abs().max()) * 1.0001], device="cuda")
+    ob = torch.tensor([float(o.abs().max())], device="cuda")
+    assert ops.tri_tail(out, o, M, C, C, w_in=w_in, w_out=None, eps=eps, Wg=split2_f16(Wg), bg=bg, Wz=split2_f16(Wo), bz=bo,
+                        zn_amax=zb, on_amax=ob, mode=1)
+    torch.cuda.synchronize()
+    zn32 = z * torch.rsqrt(z.pow(2).mean(-1, keepdim=True) + eps) * w_in
+    out32 = z + (zn32 @ Wg.t() + bg) * (o @ Wo.t() + bo)
+    err, err32 = (out.double() - ref).abs(), (out32.double() - ref).abs()
+    scale = float((ref - zd).abs().mean())
+    print(f"tri_tail mode 1 M={M}: error / mean|update| max {float(err.max()) / scale:.2e} rms {float(err.pow(2).mean().sqrt()) / scale:.2e} "
+          f"(torch fp32: {float(err32.max()) / scale:.2e} {float(err32.pow(2).mean().sqrt()) / scale:.2e})")
+    assert torch.isfinite(out).all()
+    assert float(err.pow(2).mean().sqrt()) <= 1.5 * float(err32.pow(2).mean().sqrt()) + 1e-7 * scale
+    assert float(err.max()) <= 3.0 * float(err32.max()) + 1e-6 * scale
+
+
 def test_trunk_with_and_without_the_fused_tail_agree():
-    """the conditioning trunk of the medium model at cfg1 with pd_tri_tail against the three-launch form"""
+    """the conditioning trunk of the medium model at cfg1 with pd_tri_tail / pd_tri_mul against the separate launches"""
     from physdock_amd import PhysDock, PhysDockConfig, ops, param_shapes, seeded_state_dict
     from physdock_amd.synthetic import cfg1_batch
     cfg = PhysDockConfig(model_name="medium")
@@ -65,11 +98,11 @@ def test_trunk_with_and_without_the_fused_tail_agree():
     pb = model._prepare_batch(batch)
     outs = {}
     for flag in (True, False):
-        ops.FUSED_TRI_TAIL = flag
+        ops.FUSED_TRI_TAIL = ops.FUSED_TRI_ATTN_TAIL = ops.F16_TRI_MUL = flag
         try:
             outs[flag] = [t.clone() for t in eng.conditioning(pb)]
         finally:
-            ops.FUSED_TRI_TAIL = True
+            ops.FUSED_TRI_TAIL = ops.FUSED_TRI_ATTN_TAIL = ops.F16_TRI_MUL = True
     for name, a, b in zip("a ap s z".split(), outs[True], outs[False]):
         rel = float((a - b).abs().max() / b.abs().max())
         print(f"conditioning {name}: fused tail vs three launches max |diff| / max|x| = {rel:.2e}")
