@@ -524,6 +524,26 @@ def main():
         torch.cuda.synchronize()
         dts = (time.perf_counter() - t0) / 2
         extra["screening_ligand"].update(shared_trunk_ligands_per_s=1.0 / dts, shared_trunk_ms_per_ligand=1e3 * dts)
+        # graph cache behaviour of a screening stream (one receptor, ligands of different sizes): a NEW ligand size is a cache
+        # miss = one eager pass (it is the call's result) + capture / instantiation of the step-loop graph; every later ligand
+        # of that size replays.  Measured on a ragged system of another shape at the demo's 20 samples per round.
+        from physdock_amd import synthetic as _syn
+        rb = _syn.make_batch(221, 8, 35, 64, 2)
+        rconf = _syn.reference_conformers(rb, n_conf=40, seed=1).to(device)
+        rdb = {k_: (v_.to(device) if isinstance(v_, torch.Tensor) else v_) for k_, v_ in rb.items()}
+        kwr = dict(kw, num_sample=20, ref_mol_poses=rconf) if not args.no_physics else dict(kw, num_sample=20)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        model.sample_diffusion(rdb, seed=70, **kwr)
+        torch.cuda.synchronize(); t_miss = time.perf_counter() - t0
+        cap_ms = model.last_capture_ms
+        t0 = time.perf_counter()
+        for i in range(2):
+            model.sample_diffusion(rdb, seed=71 + i, **kwr)
+        torch.cuda.synchronize(); t_hit = (time.perf_counter() - t0) / 2
+        extra["graph_cache"] = {"new_shape_call_ms": 1e3 * t_miss, "cached_shape_call_ms": 1e3 * t_hit, "capture_ms": cap_ms,
+                                "max_cached_graphs": model.max_cached_graphs,
+                                "note": "new shape = ragged T 256 / A 1803 system at 20 samples: workspace allocation + eager pass + capture; "
+                                        "graphs are keyed by padded AND real atom / token counts and the ligand size"}
         # the same ligands two at a time on two HIP streams of this GPU (parallel.StreamPool): their half-empty tail rounds overlap
         from physdock_amd.parallel import StreamPool
         pool = StreamPool(model, n=2)

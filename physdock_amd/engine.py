@@ -226,7 +226,8 @@ class Engine:
         o = self.ws.get("tri_o", 32, M)
         Tr = self.Tr          # the sum over j runs over REAL tokens only (padded j never enter a reduction)
         f16mul = False
-        if ops.F16_TRI_MUL and ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM and Wqk.shape[0] == 128:
+        if (ops.F16_TRI_MUL is True or (ops.F16_TRI_MUL == "row" and not transpose)) and ops.F16_GEMM and ops.F16_TRUNK_GEMM \
+                and ops.SPLIT_GEMM and Wqk.shape[0] == 128:
             bq = P.tri_qk_bounds(prefix, nw)         # static bounds of |q|, |k|: the einsum takes the two-part fp16 format
             f16mul = ops.tri_mul(off(qk, 0), off(qk, 32 * M), o, T, Tr, 32, M, transpose=transpose, q_amax=bq.data_ptr(), k_amax=bq.data_ptr() + 4)
         if f16mul:

@@ -64,7 +64,8 @@ class PhysDock(nn.Module):
         self._packed: Optional[PackedWeights] = None
         self._engine: Optional[Engine] = None
         self._graphs = {}                 # step-loop hipGraphs, LRU-ordered (dict insertion order)
-        self.max_cached_graphs = 16
+        self.max_cached_graphs = 64       # a screening stream over one receptor needs one graph per ligand SIZE (18 - 44 atoms in the demo)
+        self.last_capture_ms = None       # host time of the most recent graph capture + instantiation (bench.py reports it)
         #: workspace buffers are cached per shape (288 GB of HBM make re-allocation pointless for a stream of
         #: same-size crops); when systems of many different sizes pass through, the cache is dropped beyond this size
         self.workspace_limit_bytes = 160 * 2 ** 30
@@ -393,7 +394,10 @@ class PhysDock(nn.Module):
 
         graphs = None
         if use_graph:
-            key = (B, A, batch["target_feat"].shape[0], steps, noise is not None, poses is not None and (n_conf, n_lig),
+            # (the REAL atom / token counts are launch arguments - reduction bounds - of the captured kernels: two systems that pad
+            #  to the same shape must not share a graph)
+            key = (B, A, batch["target_feat"].shape[0], batch["_A_real"], batch["_T_real"], steps, noise is not None,
+                   poses is not None and (n_conf, n_lig),
                    relaxer.kind, relaxer.kind == "device" and relaxer.terms.signature(), any_mmff and int(mmff_iters),
                    tuple((p["t_hat"], p["align"], p["mmff"], p["eta"]) for p in plan), float(noise_scale_lambda), sample_offset)
             graphs = self._graphs.get(key)
@@ -416,6 +420,8 @@ class PhysDock(nn.Module):
                 # concurrently, but two overlapping captures make unrelated launches of the other thread fail
                 with _CAPTURE_LOCK:
                     torch.cuda.synchronize()
+                    import time as _time
+                    t_cap = _time.perf_counter()
                     execs = []
                     cap = torch.cuda.Stream()
                     with torch.cuda.stream(cap):
@@ -426,6 +432,7 @@ class PhysDock(nn.Module):
                             ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
                             execs.append(ex)
                     torch.cuda.synchronize()
+                    self.last_capture_ms = 1e3 * (_time.perf_counter() - t_cap)
                 # the captured launches hold raw device addresses: keep the MMFF table object whose tables were captured alive
                 # with the graph (a later call with an EQUAL table - same signature, e.g. rebuilt from the same RDKit
                 # molecule - replays against these tables, not against its own freshly built and soon freed ones)

@@ -193,10 +193,15 @@ TRANSITION_HOOK = None
 FUSED_TRUNK_TRANSITION = True
 #: the tail of the TriangleUpdate (gate projection, norm of the einsum output, K = 32 projection, gate, residual) in one launch
 FUSED_TRI_TAIL = True
-#: ... and the tail of the TriangleAttention (gate projection, linear_o, gate, residual; the projection in front shrinks to q|k|v)
-FUSED_TRI_ATTN_TAIL = True
-#: the triangle einsum on the two-part fp16 format (csrc/tri_mul.hip) instead of 32 batched fp32-MFMA GEMMs
-F16_TRI_MUL = True
+#: ... and the tail of the TriangleAttention (gate projection, linear_o, gate, residual; the projection in front shrinks to q|k|v).
+#: Correct (tests/test_tri_tail_gpu.py) but OFF: measured 45.4 (q|k|v) + 39.6 us (tail) against 50.5 (q|k|v|g) + 24.8 us (linear_o with
+#: the gate tensor) per triangle attention at T = 256 - the tail kernel's per-tile latency chain at two blocks per CU costs more than
+#: the 67 MB of gate traffic it removes (profiles/r04_trunk_kernels.txt)
+FUSED_TRI_ATTN_TAIL = False
+#: the triangle einsum on the two-part fp16 format (csrc/tri_mul.hip) instead of 32 batched fp32-MFMA GEMMs: "row" = the outgoing
+#: form only (15.8 vs 16.1 us at T = 256, error vs float64 6.8e-8 vs 1.0e-7 rms); the incoming form's transposing LDS scatter
+#: measured 23.4 vs 16.6 us and stays on the k-major fp32 kernel; True = both forms
+F16_TRI_MUL = "row"
 #: fp16-parts attention launches write their output already split for the projection that follows (pd_attn_args.O2 -> A2)
 ATTN_SPLIT_OUT = True
 #: the q|k|v projection writes k | v already scaled and split for the fp16-parts attention kernel (pd_gemm_args.Y2 -> pd_attn_args.K2 / V2):

@@ -154,6 +154,24 @@ def test_ragged_sizes_are_padded_with_masked_entries():
     assert rmsd(x.cpu(), ref) < 1e-3
 
 
+def test_systems_that_pad_to_the_same_shape_do_not_share_a_graph():
+    """T = 23 / A = 91 and T = 24 / A = 92 both run at the padded shape 24 / 92, but the real counts are launch arguments (reduction
+    bounds) of the captured kernels: each system must replay ITS graph (round 4: the graph key carries the real counts)"""
+    from physdock_amd import PhysDock, param_shapes, seeded_state_dict, small_config
+    from physdock_amd.synthetic import make_batch
+    cfg = small_config()
+    model = PhysDock(cfg); model.load_state_dict(seeded_state_dict(param_shapes(cfg), seed=0)); model = model.cuda().eval()
+    b1, b2 = make_batch(17, 5, 6, 8, seed=2), make_batch(17, 5, 7, 8, seed=2)      # 23 / 91 and 24 / 92
+    assert b2["target_feat"].shape[0] == 24 and b2["ref_pos"].shape[0] == 92
+    kw = dict(num_sample=2, steps=6, karras_noise_schedule_power=1000, align_ref_pos=False, seed=11)
+    eager = [model.sample_diffusion(to_dev(b), use_graph=False, **kw) for b in (b1, b2)]
+    for rep in range(2):                      # capture both, then replay both
+        for b, e in zip((b1, b2), eager):
+            x = model.sample_diffusion(to_dev(b), use_graph=True, **kw)
+            assert torch.equal(x, e), rep
+    assert len(model._graphs) == 2
+
+
 def test_forward_api(small):
     """training-time forward (reference model.py:99-115): keys, shapes, distogram logits vs the oracle"""
     import physdock_oracle as orc

