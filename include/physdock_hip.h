@@ -104,6 +104,13 @@ typedef struct pd_gemm_args {
     void* Y2;
     const float* y2_amax;
     int y2_col0, ldy2;
+    /* ABI 7: row statistics computed INSIDE the consuming kernel: stats == NULL and stats_inline = 1 (RMSNorm) or 2 (LayerNorm,
+       two passes: mean, then centred squares - the arithmetic of pd_rowstats) with stats_eps; pro_w / pro_b / groups as with
+       stats.  Only the fp32 streaming kernel (csrc/gemm_stream.hip: launches too small to fill the chip - few samples, the
+       trunk's single / MSA tracks) does this: a block re-reads its rows (K floats each, L2-resident) before its main loop,
+       which saves the separate pd_rowstats launch - latency, not bytes.  Anything else answers PD_ERR_UNSUPPORTED.          */
+    int stats_inline;
+    float stats_eps;
 } pd_gemm_args;
 int pd_gemm(const pd_gemm_args* args, void* stream);
 /* id of the kernel instantiation pd_gemm would launch for these arguments (for profiling);

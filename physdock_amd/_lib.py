@@ -60,6 +60,7 @@ class GemmArgs(C.Structure):
         ("ksplit_ws", _fp), ("ksplit_ws_bytes", C.c_longlong), ("ksplit", C.c_int),
         ("W2", _fp), ("w_inv", _fp), ("A2", _fp), ("a_amax", _fp),
         ("Y2", _fp), ("y2_amax", _fp), ("y2_col0", C.c_int), ("ldy2", C.c_int),      # ABI 6
+        ("stats_inline", C.c_int), ("stats_eps", C.c_float),                          # ABI 7
     ]
 
 

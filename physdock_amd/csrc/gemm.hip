@@ -591,7 +591,7 @@ static int select_variant(pd_gemm_args& p, int& cfg, bool& akm, bool& wkm, bool&
              (!p.mul || (aligned16(p.mul) && (p.mul_rows_per_group > 0 ? p.mul_gstride % 4 == 0 : p.ldmul % 4 == 0)));
     vec = p.vecA && p.vecW;
     pro = 0;
-    if (p.stats) {
+    if (p.stats || p.stats_inline) {
         if (!p.pro_w || !p.pro_b) return PD_ERR_ARG;      // pass ones / zeros explicitly
         pro = p.pro_rows_per_group > 0 ? 2 : 1;
         if (!akm && (!aligned16(p.pro_w) || !aligned16(p.pro_b) || p.pro_gstride % 4 != 0)) return PD_ERR_UNSUPPORTED;
@@ -671,6 +671,11 @@ PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     pd_gemm_args p = *args;
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
+    if (v >= 0 && !p.stats && p.stats_inline) {       // inline row statistics: the fp32 streaming kernel on the whole problem, or nothing
+        const int tile = use_stream() ? stream_tile(cfg, p) : 0;
+        const int q = (tile && !p.A3 && !p.A2 && !p.Y2) ? pd_gemm_stream_try(&p, pro, tile, nullptr, 2) : PD_ERR_UNSUPPORTED;
+        return q >= 0 ? v + 5000 + 10000 * (q & 0xff) + 100000 * (tile == 128 ? 0 : tile == 64 ? 1 : 2) : PD_ERR_UNSUPPORTED;
+    }
     if (v >= 0 && (p.A3 || p.A2 || p.Y2)) {  // pre-split A / Y2: exactly pd_gemm's rule - a split-operand kernel on the whole problem, or nothing
         int split = 0;
         const int q = persistent_try(&p, pro, 128, nullptr, 2, &split);
@@ -694,6 +699,11 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
+    if (!p.stats && p.stats_inline) {                 // inline row statistics: only the fp32 streaming kernel computes them (full tiles)
+        const int tile = use_stream() ? stream_tile(cfg, p) : 0;
+        if (!tile || p.A3 || p.A2 || p.Y2) return PD_ERR_UNSUPPORTED;
+        return pd_gemm_stream_try(&p, pro, tile, stream, 0);
+    }
     if (p.A3 || p.A2 || p.Y2) {  // pre-split A: only a split-operand kernel can read it; anything else is an error, never the raw A
         int split = 0;
         const int q = persistent_try(&p, pro, 128, nullptr, 2, &split);

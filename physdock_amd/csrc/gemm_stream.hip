@@ -166,8 +166,32 @@ __global__ __launch_bounds__(NT, TL::BLOCKS_PER_CU) void gemm_stream_kernel(cons
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
                 const int m = bm0 + (tid >> 3) + 32 * i;
-                st_mean[i] = p.stats[2 * (long long)m];
-                st_rstd[i] = p.stats[2 * (long long)m + 1];
+                if (p.stats) {
+                    st_mean[i] = p.stats[2 * (long long)m];
+                    st_rstd[i] = p.stats[2 * (long long)m + 1];
+                } else if (!reduce_only) {
+                    // pd_gemm_args.stats_inline: the eight threads that stage row m compute its statistics themselves (the row is K
+                    // floats, L2-resident in the launches that come here) - mean first, then centred squares, as pd_rowstats does
+                    const float* rowp = p.A + (long long)m * p.lda + (tid & 7) * 4;
+                    float s1 = 0.f;
+                    if (p.stats_inline == 2) {
+                        for (int kc = (tid & 7) * 4; kc < p.K; kc += 32) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + (kc - (tid & 7) * 4));
+                            s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                        }
+                        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+                    }
+                    const float mean = p.stats_inline == 2 ? s1 / (float)p.K : 0.f;
+                    float q = 0.f;
+                    for (int kc = (tid & 7) * 4; kc < p.K; kc += 32) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + (kc - (tid & 7) * 4));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+                    }
+                    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+                    st_mean[i] = mean;
+                    st_rstd[i] = rsqrtf(q / (float)p.K + p.stats_eps);
+                }
                 if constexpr (PRO == 2) grp_off[i] = (m / p.pro_rows_per_group) * p.pro_gstride;
             }
         }
@@ -358,6 +382,7 @@ extern "C" int pd_gemm_stream_try(const pd_gemm_args* args, int pro, int tile, v
                       !p.maskadd && p.out_scale == 1.f && p.vecY && (!p.rowscale || ((uintptr_t)p.rowscale & 15) == 0) && tile == 128;
     if (p.a_kmajor || p.w_kmajor || !p.vecA || !p.vecW || p.batch != 1 || (p.out_mode != PD_OUT_ROWMAJOR && !glut)) return PD_ERR_UNSUPPORTED;
     if (p.M % tbm != 0 || p.N % tbn != 0) return PD_ERR_UNSUPPORTED;        // full tiles only
+    if (!p.stats && p.stats_inline && (pro == 0 || p.K % 32 != 0 || (p.stats_inline != 1 && p.stats_inline != 2))) return PD_ERR_UNSUPPORTED;
     if (p.rowscale_acc || (p.rowscale && !glut) || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
     if (glut) epi = EPI_GLUT;

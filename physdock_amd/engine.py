@@ -133,6 +133,10 @@ class Engine:
         ops.rowstats(x, st, M, C, mode=mode, eps=eps, kmajor=kmajor, ldx=ldx)
         return st
 
+    def stats_buf(self, M, name="stats"):
+        """[M, 2] scratch for row statistics the consuming GEMM fills or computes itself (ops.gemm(stats_inline=))"""
+        return self.ws.get(f"{name}@{self.lane}", M, 2)
+
     def attn_ws(self, nbatch, nq, nk, nheads):
         """scratch for key-split attention launches (None when the launch fills the chip by itself)"""
         n = ops.attn_split_ws_numel(nbatch, nq, nk, nheads)
@@ -169,10 +173,10 @@ class Engine:
         P = self.P
         rows = nbatch * N
         H = C // 32
-        st = self.stats(s, rows, C, RMS, self.eps)
         W, b = P.qkvg(prefix)
         qkvg = self.ws.get("qkvg", rows, 4 * C)
-        self.gemm(s, W, qkvg, rows, 4 * C, C, stats=st, pro_w=P[f"{prefix}.{norm_name}.weight"], bias=b)
+        self.gemm(s, W, qkvg, rows, 4 * C, C, stats=self.stats_buf(rows), stats_inline=(RMS, self.eps),
+                  pro_w=P[f"{prefix}.{norm_name}.weight"], bias=b)
         o = self.ws.get("attn_o", rows, C)
         st4 = (N * 4 * C, 4 * C)
         ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=N, nk=nk or N, nbatch=nbatch, nheads=H,
@@ -198,9 +202,8 @@ class Engine:
                                        W13=P.w2(W13, C), W2=P.w2(W2, hidden), y_amax=P.norm_bound(nw, None, C), h_amax=hb,
                                        eps=self.eps, rms=True):
             return
-        st = self.stats(x, rows, C, RMS, self.eps)
         h = self.ws.get("ffn_h", rows, hidden)
-        self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_w=nw, glu=1)
+        self.gemm(x, W13, h, rows, 2 * hidden, C, stats=self.stats_buf(rows), stats_inline=(RMS, self.eps), pro_w=nw, glu=1)
         self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, res=x, a_amax=hb)
 
     def triangle_update(self, prefix, z, T, C, mask, transpose):
@@ -622,9 +625,8 @@ class Engine:
         if qkv_presplit:
             self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, a_amax=b_y, **norm_split(tab_off, b_y), **hn)
         else:
-            st = self.stats(x, rows, C, LN, eps)
-            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=st, pro_b=off(tab, tab_off),
-                      pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
+            self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=self.stats_buf(rows), stats_inline=(LN, eps),
+                      pro_b=off(tab, tab_off), pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         o_split = unsplit_f16 and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C \
             and ops.presplit_supported(rows, C, C, f16=True, gate=True, per_group_rows=N if per_sample else 0, gstride=tab_ld if per_sample else 0)
@@ -647,8 +649,8 @@ class Engine:
         if presplit:
             self.gemm(x, W13, h, rows, 2 * hidden, C, glu=1, a_amax=b_y2, **norm_split(t2, b_y2))
         else:
-            st = self.stats(x, rows, C, LN, eps)
-            self.gemm(x, W13, h, rows, 2 * hidden, C, stats=st, pro_b=off(tab, t2), pro_w=off(tab, t2 + C), glu=1, a_amax=b_y2, **grp)
+            self.gemm(x, W13, h, rows, 2 * hidden, C, stats=self.stats_buf(rows), stats_inline=(LN, eps), pro_b=off(tab, t2),
+                      pro_w=off(tab, t2 + C), glu=1, a_amax=b_y2, **grp)
         self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, t2 + 2 * C), res=x, a_amax=b_h, **mgrp)
 
     def af3_dit(self, batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=False):

@@ -69,6 +69,7 @@ def presplit_supported(M, N, K, *, glu=0, hn=False, f16=False, gate=False, per_g
 
 
 _KV2_OK = {}
+_INLINE_STATS_OK = {}
 
 
 def kv2_supported(M, Cdim, *, a2, per_group_rows=0):
@@ -101,9 +102,12 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
          hn_split=32, hn_eps=0.0, act=ACT_NONE, glu=0, rowscale=None, maskadd=None, maskval=0.0,
          mul=None, ldmul=0, mul_rows_per_group=0, mul_gstride=0, out_scale=1.0, res=None, ldres=0,
          res_row_mod=0, sRes=0, out_mode=OUT_ROWMAJOR, T1=0, T2=0, frag_transpose=False, W3=None, ksplit_ws=None, A3=None,
-         W2=None, a_amax=None, A2=None, Y2=None, y2_amax=None, y2_col0=0):
+         W2=None, a_amax=None, A2=None, Y2=None, y2_amax=None, y2_col0=0, stats_inline=None):
     """Y = epilogue(prologue(A) @ W^T); see include/physdock_hip.h pd_gemm_args.
-    A/W/Y and the optional operands may be tensors or raw device addresses (ints)."""
+    A/W/Y and the optional operands may be tensors or raw device addresses (ints).
+    stats_inline=(mode, eps) with stats = an (uninitialised) [M, 2] scratch tensor: the row statistics of A are the launch's own
+    business - computed inside the kernel when pd_gemm would run it on the fp32 streaming kernel anyway (few samples, the trunk's
+    small tracks: one launch less), by a pd_rowstats launch into `stats` first otherwise."""
     def P(x):
         return x if (x is None or isinstance(x, int)) else ptr(x)
     n_out = N // 2 if glu else N
@@ -145,6 +149,24 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
     a.out_mode, a.T1, a.T2, a.frag_transpose = out_mode, T1, T2, int(frag_transpose)
     if ksplit_ws is not None and KSPLIT_GEMM:
         a.ksplit_ws, a.ksplit_ws_bytes = ptr(ksplit_ws), ksplit_ws.numel() * 4
+    if stats_inline is not None:
+        mode_, eps_ = stats_inline
+        key = (M, N, K, a.lda, int(glu), hn_w is not None, mul is not None, res is not None, pro_rows_per_group > 0, out_mode, act, pro_act,
+               a.W2 is not None, a.W3 is not None, a.ksplit_ws is not None, bool(a_kmajor), batch)
+        ok = _INLINE_STATS_OK.get(key)
+        if ok is None:
+            v = _lib.init().pd_gemm_variant(C.byref(a))              # with the statistics as an operand: which kernel takes it?
+            ok = False
+            if INLINE_STATS and 5000 <= v % 10000 and 0 <= v < 1000000:   # the fp32 streaming kernel: it can compute them itself
+                a.stats, a.stats_inline, a.stats_eps = None, (1 if mode_ == RMS else 2), float(eps_)
+                ok = _lib.init().pd_gemm_variant(C.byref(a)) >= 0
+            _INLINE_STATS_OK[key] = ok
+        if ok:
+            a.stats, a.stats_inline, a.stats_eps = None, (1 if mode_ == RMS else 2), float(eps_)
+        else:
+            a.stats_inline = 0
+            a.stats = P(stats)
+            rowstats(A, stats, M, K, ldx=a.lda, mode=mode_, eps=eps_)
     if GEMM_HOOK is not None:
         return GEMM_HOOK(a, lambda: check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm"))
     check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm")
@@ -170,6 +192,10 @@ PRESPLIT_GEMM = True
 PRESPLIT_QKV = True       # also for q|k|v (12 column blocks): +0.4 % on top of the SwiGLU projection's +1.0 %
 PRESPLIT_MIN_C_F16 = 256  # narrowest rows that take the pre-split path when the operand format is two fp16 parts (atom rows,
                           # C = 128: the split pass costs 43 us per launch against 16 us of statistics - measured -0.8 % end to end)
+
+#: launches on the fp32 streaming kernel compute the row statistics of their norm prologue themselves (gemm(stats_inline=)): one
+#: pd_rowstats launch less in front of every small projection (B = 1: ~38 per step)
+INLINE_STATS = True
 
 #: K-split of launches that cannot fill the chip (few samples) when the caller hands pd_gemm a scratch buffer
 KSPLIT_GEMM = True

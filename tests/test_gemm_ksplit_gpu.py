@@ -95,3 +95,48 @@ def test_large_launches_and_small_scratch_are_left_alone():
     ops.gemm(A[:M], W, Y0, M, N, K)
     ops.gemm(A[:M], W, Y1, M, N, K, ksplit_ws=torch.zeros(8192, device="cuda"))
     assert torch.equal(Y0, Y1)
+
+
+@pytest.mark.parametrize("M,C,mode,ksplit", [(256, 512, "ln", True), (256, 512, "rms", False), (2048, 128, "ln", False), (512, 256, "rms", True)])
+def test_row_statistics_inside_the_kernel(M, C, mode, ksplit):
+    """ops.gemm(stats_inline=): launches on the fp32 streaming kernel compute the statistics of their norm prologue themselves
+    (pd_gemm_args.stats_inline, ABI 7) - same result as a pd_rowstats launch in front, to rounding; one launch less"""
+    import ctypes as C_
+    from physdock_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * torch.exp(torch.randn(M, 1, generator=g)) + 0.3).cuda()
+    w, bsh = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    W = (torch.randn(3 * C, C, generator=g) / C ** 0.5).cuda()
+    md, eps = (ops.LN, 1e-5) if mode == "ln" else (ops.RMS, 1e-8)
+    ws = _ws() if ksplit else None
+    st = torch.empty(M, 2, device="cuda")
+    ops.rowstats(x, st, M, C, mode=md, eps=eps)
+    y0 = torch.empty(M, 3 * C, device="cuda")
+    ops.gemm(x, W, y0, M, 3 * C, C, stats=st, pro_w=w, pro_b=bsh, ksplit_ws=ws)
+    seen = []
+    ops.GEMM_HOOK = lambda a, launch: (seen.append((bool(a.stats), a.stats_inline)), launch())
+    try:
+        y1 = torch.empty(M, 3 * C, device="cuda")
+        st2 = torch.full((M, 2), float("nan"), device="cuda")
+        ops.gemm(x, W, y1, M, 3 * C, C, stats=st2, stats_inline=(md, eps), pro_w=w, pro_b=bsh, ksplit_ws=ws)
+    finally:
+        ops.GEMM_HOOK = None
+    assert seen == [(False, 1 if mode == "rms" else 2)], seen          # the kernel computed them: no statistics operand
+    assert torch.isnan(st2).all()                                       # ... and no pd_rowstats launch filled the scratch
+    xd = x.double()
+    xn = (xd - (xd.mean(-1, keepdim=True) if mode == "ln" else 0))
+    xn = xn * torch.rsqrt(xn.pow(2).mean(-1, keepdim=True) + eps) * w.double() + bsh.double()
+    ref = xn @ W.double().t()
+    e0, e1 = (y0.double() - ref).abs().max(), (y1.double() - ref).abs().max()
+    print(f"inline statistics M={M} C={C} {mode}: max error vs float64 {float(e1):.2e} (statistics launch: {float(e0):.2e})")
+    assert float(e1) <= 1.5 * float(e0) + 1e-6
+    torch.testing.assert_close(y1, y0, rtol=2e-5, atol=2e-5)
+    # a launch that carries split weights and fills the chip goes to a split-operand kernel: those read the statistics as an
+    # operand, so the wrapper runs pd_rowstats first (the scratch is filled)
+    from physdock_amd.packing import split3_bf16
+    Mb = 16384
+    xb = torch.randn(Mb, C, generator=g).cuda()
+    stb = torch.full((Mb, 2), float("nan"), device="cuda")
+    yb = torch.empty(Mb, 3 * C, device="cuda")
+    ops.gemm(xb, W, yb, Mb, 3 * C, C, stats=stb, stats_inline=(md, eps), pro_w=w, pro_b=bsh, W3=split3_bf16(W))
+    assert torch.isfinite(stb).all() and torch.isfinite(yb).all()
