@@ -34,6 +34,13 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef PD_F16_MIN_TILES_SMALL
 #define PD_F16_MIN_TILES_SMALL 160
 #endif
+// lab ablations of the direct-W main loop (timing only, wrong results): 1 every block stages the A rows of tile 0 (L2-hot operand),
+// 2 every wave loads the W fragments of column block 0 / k-step 0, 4 no block barrier inside the slice loop, 8 no A requests in the loop
+#ifdef PD_F16_ABL
+constexpr int F16_ABL = PD_F16_ABL;
+#else
+constexpr int F16_ABL = 0;
+#endif
 #ifdef PD_LAB      // lab build only (tools/gemm_f16_trace.py): in-kernel phase trace of the direct-W main loop
 __device__ unsigned long long* g_f16_trace = nullptr;
 #define PD_F16_TRACE_PTR g_f16_trace
@@ -115,6 +122,7 @@ void gemm_f16_kernel(const pd_gemm_args p) {
     f16x8 rw[NPARTS][NW];
 
     auto gload = [&](int bm0, int bn0, int k0) {
+        if constexpr (F16_ABL & 1) bm0 = 0;
         const int r = bm0 + a_row;                // full tiles only: always < M
         if constexpr (AS) {
             const _Float16* ap2 = A2 + (long long)r * (nk * 32) + k0 + 8 * a_q;
@@ -141,6 +149,7 @@ void gemm_f16_kernel(const pd_gemm_args p) {
     // DW: this wave's B fragments of 16-k step `ks` of column block bn0, straight into MFMA operand registers
     f16x8 wf[2][TN][NPARTS];
     auto wfrag = [&](int buf, int bn0, int ks) {
+        if constexpr (F16_ABL & 2) { bn0 = 0; ks = 0; }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const f16x8* base = W2 + ((long long)((bn0 + wn * (32 * TN) + j * 32) >> 5) * nks + ks) * 64 + lane;
@@ -321,7 +330,7 @@ void gemm_f16_kernel(const pd_gemm_args p) {
                 constexpr bool more = decltype(more_c)::value;
                 const int st = kt & 1;
                 PD_STAMP(0);
-                if constexpr (more) { gload(bm0, bn0, (kt + 1) * 32); __builtin_amdgcn_sched_barrier(0); }   // requests stay where they are written
+                if constexpr (more && !(F16_ABL & 8)) { gload(bm0, bn0, (kt + 1) * 32); __builtin_amdgcn_sched_barrier(0); }   // requests stay where they are written
                 mma2(st, 0);
                 PD_STAMP(1);
                 // every B buffer is re-requested right after its last use
@@ -336,7 +345,7 @@ void gemm_f16_kernel(const pd_gemm_args p) {
                     // the other stage was last read in the previous iteration, which every wave left through its barrier
                     stage2(st ^ 1, (kt + 1) * 32);
                     PD_STAMP(4);
-                    lds_barrier();
+                    if constexpr (!(F16_ABL & 4)) lds_barrier();
                     PD_STAMP(5);
                 }
             };

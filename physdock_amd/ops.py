@@ -194,8 +194,10 @@ PRESPLIT_MIN_C_F16 = 256  # narrowest rows that take the pre-split path when the
                           # C = 128: the split pass costs 43 us per launch against 16 us of statistics - measured -0.8 % end to end)
 
 #: launches on the fp32 streaming kernel compute the row statistics of their norm prologue themselves (gemm(stats_inline=)): one
-#: pd_rowstats launch less in front of every small projection (B = 1: ~38 per step)
-INLINE_STATS = True
+#: pd_rowstats launch less in front of every small projection (B = 1: ~38 per step).  Correct (tests/test_gemm_ksplit_gpu.py) and
+#: OFF: the statistics pass at the head of every block (two dependent sweeps over its rows) costs the consuming kernels more
+#: than the 4.6 us launch it saves - token SwiGLU 11.2 -> 22.2 us, q|k|v 8.7 -> 13.5 us, B = 1 call 88.5 -> 104.4 ms
+INLINE_STATS = False
 
 #: K-split of launches that cannot fill the chip (few samples) when the caller hands pd_gemm a scratch buffer
 KSPLIT_GEMM = True
