@@ -35,7 +35,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define PD_F16_MIN_TILES_SMALL 160
 #endif
 // lab ablations of the direct-W main loop (timing only, wrong results): 1 every block stages the A rows of tile 0 (L2-hot operand),
-// 2 every wave loads the W fragments of column block 0 / k-step 0, 4 no block barrier inside the slice loop, 8 no A requests in the loop
+// 2 every wave loads the W fragments of column block 0 / k-step 0, 4 no block barrier inside the slice loop, 8 no A requests in the loop,
+// 16 the A fragments are read from LDS once per tile instead of once per k-step (no LDS reads in the loop), 32 no LDS staging stores
 #ifdef PD_F16_ABL
 constexpr int F16_ABL = PD_F16_ABL;
 #else
@@ -271,6 +272,7 @@ void gemm_f16_kernel(const pd_gemm_args p) {
         };
         // ---- DW tiles: the whole 32-k slice in ra goes to LDS stage s; fragments of k-step ks come from there and from wf[ks]
         auto stage2 = [&](int s, int k0) {
+            if constexpr (F16_ABL & 32) { if (k0 > 0) return; }
             _Float16* base = lds + s * TL::STAGE + a_row * PITCH2;
             if constexpr (AS) {
 #pragma unroll
@@ -288,14 +290,32 @@ void gemm_f16_kernel(const pd_gemm_args p) {
                     *reinterpret_cast<f16x4*>(base + BM * PITCH2 + o) = pl;
                 }
         };
+        f16x8 fa_abl[TM][NPARTS];
+        bool fa_abl_have = false;
         auto mma2 = [&](int s, int ks) {
             f16x8 fa[TM][NPARTS];
             const _Float16* base = lds + s * TL::STAGE + (wm * (32 * TM) + l31) * PITCH2 + 16 * ks + 8 * hh;
+            if (!(F16_ABL & 16) || !fa_abl_have) {
 #pragma unroll
-            for (int part = 0; part < NPARTS; ++part)
+                for (int part = 0; part < NPARTS; ++part)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fa[i][part] = *reinterpret_cast<const f16x8*>(base + part * BM * PITCH2 + i * 32 * PITCH2);
+                    for (int i = 0; i < TM; ++i)
+                        fa[i][part] = *reinterpret_cast<const f16x8*>(base + part * BM * PITCH2 + i * 32 * PITCH2);
+            }
+            if constexpr (F16_ABL & 16) {
+                if (!fa_abl_have) {
+#pragma unroll
+                    for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) fa_abl[i][part] = fa[i][part];
+                    fa_abl_have = true;
+                } else {
+#pragma unroll
+                    for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) fa[i][part] = fa_abl[i][part];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

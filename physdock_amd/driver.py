@@ -147,6 +147,8 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
             x_pred = model.sample_diffusion(batch, **call)
         if isinstance(x_pred, tuple):
             x_pred, cond = x_pred
+        if rnd + 1 >= max_rounds:            # no later round can take it: the shared conditioning (clones of a [A,c], ap [A,A,c], s,
+            cond = None                      # z [T,T,128] - hundreds of MB at large crops, per StreamPool replica) is released here
         # accept / reject (redocking.py:303-317): on the device when a ChiralityReference is given (one kernel, one [B]
         # mask to the host), else through the injected per-pose callable (which needs the poses on the host)
         dev_ok = chirality.accept(x_pred).tolist() if (physics_correction and chirality is not None) else None
@@ -169,6 +171,7 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
         if physics_correction:
             factor = next_gamma_factor(factor, any(flags))
             if len(accept) >= max_samples:
+                cond = None                  # accept count reached: the shared conditioning is released with the loop
                 break
             used = select_reference_templates(x_pred, ligand_idx, ref_mol_poses, max_samples - len(ligand_templates))
             reference_templates = [ref_mol_poses[i] for i in used.tolist()]

@@ -103,17 +103,39 @@ _TERMS_MEMO_MAX = 32
 AUTO_BACKEND_FOR_RDKIT_MOL = "host"
 
 
+def _mol_signature(mol):
+    """what the MMFF tables of a molecule depend on, as far as the object lets us read it (RDKit getters; duck-typed): atom count,
+    elements / formal charges / aromaticity, bonds with their orders.  A molecule edited in place (AddHs, charge or bond edits)
+    changes it, so a memo entry built from the earlier state is not served again."""
+    sig = [int(mol.GetNumAtoms())]
+    try:
+        for i in range(sig[0]):
+            a = mol.GetAtomWithIdx(i)
+            sig.append(tuple(int(getattr(a, g)()) for g in ("GetAtomicNum", "GetFormalCharge", "GetIsAromatic") if hasattr(a, g)))
+        for b in mol.GetBonds():
+            sig.append((int(b.GetBeginAtomIdx()), int(b.GetEndAtomIdx()),
+                        float(b.GetBondTypeAsDouble()) if hasattr(b, "GetBondTypeAsDouble") else 0.0))
+    except Exception:       # an object that does not answer these getters keeps the identity-only behaviour
+        pass
+    return tuple(sig)
+
+
 def _memo_terms(ref_mol, strict):
     from . import mmff
     key = id(ref_mol)
+    sig = _mol_signature(ref_mol)
     hit = _TERMS_MEMO.get(key)
-    if hit is not None and hit[0] is ref_mol:
+    if hit is not None and hit[0] is ref_mol and hit[2] == sig:
         return hit[1]
     terms = mmff.terms_from_rdkit(ref_mol, strict=strict)
     if terms is not None:
+        # the tables were uploaded (and self-checked) on THIS thread's stream; the memo is shared by every StreamPool replica:
+        # publish only what has landed on the device, as ops.const_vec does
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
         if len(_TERMS_MEMO) >= _TERMS_MEMO_MAX:
             _TERMS_MEMO.pop(next(iter(_TERMS_MEMO)))
-        _TERMS_MEMO[key] = (ref_mol, terms)          # holds the molecule: id() stays unique while the entry lives
+        _TERMS_MEMO[key] = (ref_mol, terms, sig)     # holds the molecule: id() stays unique while the entry lives
     return terms
 
 
