@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import threading
 from typing import Dict, Optional
 
@@ -31,6 +32,8 @@ from .params import param_shapes
 
 
 _CAPTURE_LOCK = threading.Lock()
+#: PD_CHECK_FINITE=1: every sample_diffusion call checks its poses for inf / NaN (one tiny reduction + a host sync) and raises
+_CHECK_FINITE = os.environ.get("PD_CHECK_FINITE") == "1"
 
 
 def _register(root: nn.Module, name: str, tensor: torch.Tensor):
@@ -63,6 +66,7 @@ class PhysDock(nn.Module):
             _register(self, name, torch.zeros(shape))
         self._packed: Optional[PackedWeights] = None
         self._engine: Optional[Engine] = None
+        self._packed_versions = None
         self._graphs = {}                 # step-loop hipGraphs, LRU-ordered (dict insertion order)
         self.max_cached_graphs = 64       # a screening stream over one receptor needs one graph per ligand SIZE (18 - 44 atoms in the demo)
         self.last_capture_ms = None       # host time of the most recent graph capture + instantiation (bench.py reports it)
@@ -95,7 +99,16 @@ class PhysDock(nn.Module):
         self._invalidate()
         return r
 
+    def _param_versions(self):
+        """sum of the parameters' in-place modification counters: the packed weights, their fp16 / bf16 splits and every static
+        magnitude bound derive from the values at pack time, so an in-place update (optimizer step, `p.data.mul_`, ...) must
+        rebuild them - a stale bound would let the fp16 operand format overflow silently.  (Writes through `p.data` bypass the
+        counters by PyTorch's design: call `_invalidate()` after those, or run with PD_CHECK_FINITE=1.)"""
+        return sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+
     def engine(self, device) -> Engine:
+        if self._engine is not None and self._packed_versions != self._param_versions():
+            self._invalidate()               # a weight was modified in place since the engine was built
         if self._engine is None or self._engine.device != device:
             if device.type != "cuda":
                 raise RuntimeError("physdock_amd.PhysDock runs its sampler on an MI355X (HIP) device only; "
@@ -105,6 +118,7 @@ class PhysDock(nn.Module):
                 raise RuntimeError("model parameters and batch must be on the same device")
             self._packed = PackedWeights(params, self.config)
             self._engine = Engine(self._packed, self.config, device)
+            self._packed_versions = self._param_versions()
         return self._engine
 
     @staticmethod
@@ -442,6 +456,11 @@ class PhysDock(nn.Module):
                     for ex in old["exec"]:
                         L.pd_graph_destroy(ex)
         out = x_a[:, :A_real].clone()
+        if _CHECK_FINITE and not bool(torch.isfinite(out).all()):
+            # PD_CHECK_FINITE=1: a violated magnitude bound (weights changed behind the engine's back, a caller-supplied bound that
+            # does not hold) overflows the fp16 operand format to inf / NaN - make that loud instead of returning it
+            raise FloatingPointError("sample_diffusion produced non-finite coordinates: an fp16-format operand bound was violated "
+                                     "(rebuild the engine after changing weights; ops.F16_GEMM / F16_ATTN = False to confirm)")
         if return_conditioning:
             return out, tuple(t.clone() for t in cond_out)
         return out

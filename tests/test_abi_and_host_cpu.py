@@ -160,3 +160,20 @@ def test_bench_gpus_flag_is_not_inert():
     env["WORLD_SIZE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "must agree" in r.stderr and "{" not in r.stdout
+
+
+def test_in_place_weight_updates_are_seen_by_the_version_sum():
+    """the engine (packed weights, operand splits, static fp16 bounds) is rebuilt when a parameter was modified in place:
+    PhysDock.engine() compares the sum of the parameters' version counters with the one recorded at pack time"""
+    import torch
+    from physdock_amd import PhysDock, small_config
+    m = PhysDock(small_config())
+    v0 = m._param_versions()
+    p = next(iter(m.parameters()))
+    with torch.no_grad():
+        p.mul_(2.0)
+    assert m._param_versions() == v0 + 1
+    with torch.no_grad():
+        p.add_(1.0)
+    assert m._param_versions() == v0 + 2
+    # (writes through `p.data` bypass autograd's version counters by design: after those, call model._invalidate())
