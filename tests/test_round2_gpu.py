@@ -107,6 +107,33 @@ def test_medium_trajectories_vs_reference(medium, tag):
     medium.release_workspace()
 
 
+# ------------------------------------------------------------------ forward() at a chip-filling shape whose atom count is not a multiple of 64
+def test_forward_at_a_chip_filling_shape_with_ragged_rows_per_sample(medium):
+    """forward() runs one AdaLN row PER SAMPLE (48 of them), so the gate of linear_o is grouped by A atoms per
+    sample; with 48 A % 128 == 0 but A % 64 != 0 (A = 2056) the attention must not hand linear_o a pre-split operand the grouped
+    gate epilogue cannot take.  The denoiser output is checked against a second pass with every fp16 / split fast path off."""
+    from physdock_amd import ops
+    from physdock_amd.synthetic import make_batch
+    batch = make_batch(224, 9, 40, 16, seed=5)                    # T = 264, A = 2056
+    assert batch["ref_pos"].shape[0] == 2056
+    dbatch = to_dev(batch)
+    torch.manual_seed(0)
+    out = medium(dbatch)
+    assert out["x_denoised"].shape[1:] == (2056, 3) and bool(torch.isfinite(out["x_denoised"]).all())
+    saved = (ops.F16_GEMM, ops.F16_ATTN, ops.SPLIT_GEMM, ops.SPLIT_ATTN)
+    ops.F16_GEMM = ops.F16_ATTN = ops.SPLIT_GEMM = ops.SPLIT_ATTN = False
+    try:
+        torch.manual_seed(0)
+        ref = medium(dbatch)
+    finally:
+        ops.F16_GEMM, ops.F16_ATTN, ops.SPLIT_GEMM, ops.SPLIT_ATTN = saved
+    assert torch.equal(out["t_hat"], ref["t_hat"])               # same noise levels drawn
+    rel = float((out["x_denoised"] - ref["x_denoised"]).abs().max() / ref["x_denoised"].abs().max())
+    print(f"forward() at A = 2056 x 48 samples: fast paths vs fp32-MFMA kernels max |diff| / max|x| = {rel:.2e}")
+    assert rel < 2e-4
+    medium.release_workspace()
+
+
 # ------------------------------------------------------------------ the bench configuration (B=64) against small batches
 def test_b64_matches_small_batches_and_takes_the_wide_attention(medium):
     """BASELINE config #2 is timed at B=64; samples never interact, so rows {0, 1, 63} of a B=64 call must equal a B=3
