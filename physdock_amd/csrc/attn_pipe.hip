@@ -92,6 +92,9 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     const int q0 = qb * (32 * NW) + wave * 32;
     const int query = q0 + l31;
     const bool wave_active = q0 < p.nq;
+    // lanes with a real query: the lanes of the padding rows of a ragged last wave hold whatever the bias buffer's padding holds and
+    // must not take part in the wave-wide decision to move the running maximum (the result would depend on that padding)
+    const unsigned long long qlanes = __builtin_amdgcn_ballot_w64(query < p.nq);
 
     // power-of-two operand scales from the magnitude bounds (as attn_f16.hip); S' = S / c_s is what the matrix pipe accumulates
     float qs = p.scale * PD_LOG2E;
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         kf1[0] = kfrag(kn, 1, 0); kf1[1] = kfrag(kn, 1, 1);
         float alpha = 1.0f;
         if constexpr (LAZY > 0) {
-            if (__builtin_amdgcn_ballot_w64(mloc > m_run + tau_s) != 0ull) {      // rare after the first sub-tiles
+            if ((__builtin_amdgcn_ballot_w64(mloc > m_run + tau_s) & qlanes) != 0ull) {      // rare after the first sub-tiles
                 const float m_new = __builtin_fmaxf(m_run, mloc);
                 alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_s);
                 m_run = m_new;

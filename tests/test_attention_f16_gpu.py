@@ -312,3 +312,33 @@ def test_trunk_attention_on_static_bounds():
         m = float(qkvg[:, i * Cz:(i + 1) * Cz].abs().max())
         print(f"{prefix} {nm}: max {m:.3g} bound {float(bnd[i]):.3g} (x{float(bnd[i]) / m:.1f})")
         assert m <= float(bnd[i]) and float(bnd[i]) <= m * 2 ** 9
+
+
+@pytest.mark.parametrize("B,H,nq,nk", [(64, 4, 228, 228), (8, 4, 1828, 1827), (64, 4, 100, 70), (256, 4, 228, 228)])
+def test_pipelined_kernel_ignores_the_padding_of_the_bias_buffer(B, H, nq, nk):
+    """The fragment layout of the bias pads queries and keys to 32; the producer (pd_pair_bias) writes the real entries only, so the
+    padding holds whatever the previous system left in the (shape-keyed, shared) scratch.  The result must not depend on it: the
+    wave-wide decision to move the running maximum once let the padding rows of a ragged last wave vote (a 1e-5 history
+    dependence of the trunk of a system of 227 tokens after one of 224)."""
+    from physdock_amd import ops
+    q, k, v = (torch.randn(B, n, H * 32, generator=g(31 + i)) for i, n in enumerate((nq, nk, nk)))
+    bias = torch.randn(H, nq, nk, generator=g(34)) * 2
+    amax = (float(q.abs().max()), float(k.abs().max()), float(v.abs().max()))
+    ps = ops.attn_bias_prescale(*amax[:2])
+    nqt, nkt = (nq + 31) // 32, (nk + 31) // 32
+    valid = torch.zeros(H, nqt * 32, nkt * 32)
+    valid[:, :nq, :nk] = 1
+    vfrag = ops.bias_to_frag(valid) != 0
+    outs = []
+    for fill in (0.0, 3.0 * ps, -7.0e4 * ps, float("inf"), float("nan")):
+        bf = ops.bias_to_frag(bias) * ps
+        bf = torch.where(vfrag, bf, torch.full_like(bf, fill)).cuda()
+        o = torch.empty(B, nq, H * 32, device="cuda")
+        kw = dict(nq=nq, nk=nk, nbatch=B, nheads=H, q_strides=(nq * H * 32, H * 32), k_strides=(nk * H * 32, H * 32),
+                  v_strides=(nk * H * 32, H * 32), o_strides=(nq * H * 32, H * 32), bias=bf, f16_amax=amax, bias_prescale=ps)
+        assert ops.attention(q.cuda(), k.cuda(), v.cuda(), o, query_only=True, **kw) >= 3000
+        ops.attention(q.cuda(), k.cuda(), v.cuda(), o, **kw)
+        outs.append(o.cpu())
+    assert torch.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
