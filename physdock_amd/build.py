@@ -66,7 +66,7 @@ def compile_cmd(src, out, mode=("-c",)):
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_KSPLIT_MAX_BYTES") and base == "gemm_stream.hip":
         cmd[1:1] = ["-DPD_KSPLIT_MAX_BYTES=" + os.environ["PD_KSPLIT_MAX_BYTES"]]
-    for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES", "PD_F16_MIN_TILES_SMALL", "PD_F16_ABL"):
+    for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES", "PD_F16_MIN_TILES_SMALL", "PD_F16_ABL", "PD_F16_T256", "PD_F16_T256_BPC"):
         if os.environ.get(knob) and base == "gemm_f16.hip":
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_ATTN_MIN_WAVES") and base == "attention.hip":     # lab: query waves from which the split-operand kernels take a launch
@@ -77,6 +77,8 @@ def compile_cmd(src, out, mode=("-c",)):
         cmd[1:1] = ["-DPD_ATTN_ABL=" + os.environ["PD_ATTN_ABL"]]
     if os.environ.get("PD_PIPE_LAZY") and base == "attn_pipe.hip":     # lab: threshold of the lazy running maximum (0: plain update)
         cmd[1:1] = ["-DPD_PIPE_LAZY=" + os.environ["PD_PIPE_LAZY"]]
+    if os.environ.get("PD_PIPE_XCD") and base == "attn_pipe.hip":      # lab: XCD-aware block order
+        cmd[1:1] = ["-DPD_PIPE_XCD=" + os.environ["PD_PIPE_XCD"]]
     if os.environ.get("PD_PIPE_ABL") and base == "attn_pipe.hip":      # lab: timing ablations of the pipelined attention (wrong results)
         cmd[1:1] = ["-DPD_PIPE_ABL=" + os.environ["PD_PIPE_ABL"]]
     if os.environ.get("PD_TRANSITION_BM") and base == "transition_f16.hip":     # lab: 128-row tiles, one block per CU

@@ -54,6 +54,10 @@ constexpr int ABL = 0;
 #define PD_PIPE_LAZY 3
 #endif
 constexpr int LAZY = PD_PIPE_LAZY;
+#ifndef PD_PIPE_XCD
+#define PD_PIPE_XCD 0
+#endif
+constexpr bool XCDMAP = PD_PIPE_XCD != 0;
 constexpr float PSH = 14.0f - (float)LAZY;
 
 __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -88,7 +92,20 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.x, h = blockIdx.z, qb = blockIdx.y;
+    int b = blockIdx.x, h = blockIdx.z, qb = blockIdx.y;
+    if constexpr (XCDMAP) {
+        // Workgroups go to the eight XCDs round-robin in dispatch order (x fastest).  With the plain (sample, query block, head)
+        // grid XCD k gets the samples b = k mod 8 of EVERY (head, query block): each of the eight L2s fetches the whole bias.
+        // Here an XCD owns P / 8 (head, query block) pairs - for the atom shape four query blocks of one head - for all samples:
+        // it fetches 1 / 8 of the bias per round of co-resident samples, and a (sample, head) K / V pair goes to two L2s.
+        const int nqb = gridDim.y, P = nqb * gridDim.z;
+        if ((P & 7) == 0) {
+            const int L = blockIdx.x + gridDim.x * (blockIdx.y + nqb * blockIdx.z);
+            const int ppx = P >> 3, slot = L >> 3;
+            const int pair = (L & 7) * ppx + slot % ppx;
+            b = slot / ppx; h = pair / nqb; qb = pair % nqb;
+        }
+    }
     const int q0 = qb * (32 * NW) + wave * 32;
     const int query = q0 + l31;
     const bool wave_active = q0 < p.nq;

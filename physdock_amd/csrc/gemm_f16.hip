@@ -36,7 +36,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #endif
 // lab ablations of the direct-W main loop (timing only, wrong results): 1 every block stages the A rows of tile 0 (L2-hot operand),
 // 2 every wave loads the W fragments of column block 0 / k-step 0, 4 no block barrier inside the slice loop, 8 no A requests in the loop,
-// 16 the A fragments are read from LDS once per tile instead of once per k-step (no LDS reads in the loop), 32 no LDS staging stores
+// 16 the A fragments are read from LDS once per tile instead of once per k-step (no LDS reads in the loop), 32 no LDS staging stores,
+// 64 no W fragment requests in the loop
 #ifdef PD_F16_ABL
 constexpr int F16_ABL = PD_F16_ABL;
 #else
@@ -52,14 +53,14 @@ constexpr int NPARTS = 2;            // operand parts: (hi, lo) fp16
 constexpr int PITCH = 24;            // LDS-W tiles: 16 k per row, 48 bytes apart
 constexpr int PITCH2 = 40;           // DW tiles: 32 k per row, 80 bytes apart (conflict-free ds_read_b128 fragments)
 
-template <int BM_, int BN_, int WM_, int NWAVES_, bool DW_>
+template <int BM_, int BN_, int WM_, int NWAVES_, bool DW_, int BPC_ = 0>
 struct FTile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = NWAVES_ / WM_, NT = 64 * NWAVES_;
     static constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     static constexpr bool DW = DW_;      // direct W: the B fragments go from global memory straight into MFMA registers
     static constexpr int STAGE = DW ? NPARTS * BM * PITCH2 : NPARTS * (BM + BN) * PITCH;      // fp16 elements per stage
     static constexpr int LDS_BYTES = 2 * STAGE * 2;
-    static constexpr int BLOCKS_PER_CU = NWAVES_ == 8 ? 2 : 4;
+    static constexpr int BLOCKS_PER_CU = BPC_ ? BPC_ : (NWAVES_ == 8 ? 2 : 4);
     static constexpr int WAVES_PER_SIMD = NWAVES_ * BLOCKS_PER_CU / 4;
     static constexpr int GRID = 256 * BLOCKS_PER_CU;
 };
@@ -115,10 +116,10 @@ void gemm_f16_kernel(const pd_gemm_args p) {
     const int w_row = tid / TPR_W, w_q = tid % TPR_W;
     // PRO == 3: A arrives pre-split and pre-scaled (pd_norm_split2, [2][M][Kp] fp16): a thread copies one 16-byte chunk per part
     constexpr bool AS = PRO == 3;
-    static_assert(!AS || TPR_A == 4, "pre-split A: four 8-k chunks per row slice");
+    constexpr int CPA = 4 / TPR_A;               // pre-split A: 8-k chunks per thread, part and slice (four per row)
     const _Float16* __restrict__ A2 = reinterpret_cast<const _Float16*>(p.A2);
     const long long apart = (long long)p.M * (nk * 32);
-    f16x8 ra2[NPARTS];
+    f16x8 ra2[NPARTS][AS ? CPA : 1];
     f32x4 ra[2][CPH_A];                          // [half][i]: chunk 4*half + a_q + TPR_A*i of the thread's row
     f16x8 rw[NPARTS][NW];
 
@@ -128,7 +129,9 @@ void gemm_f16_kernel(const pd_gemm_args p) {
         if constexpr (AS) {
             const _Float16* ap2 = A2 + (long long)r * (nk * 32) + k0 + 8 * a_q;
 #pragma unroll
-            for (int part = 0; part < NPARTS; ++part) ra2[part] = *reinterpret_cast<const f16x8*>(ap2 + part * apart);
+            for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                for (int i = 0; i < CPA; ++i) ra2[part][i] = *reinterpret_cast<const f16x8*>(ap2 + part * apart + 8 * TPR_A * i);
         }
         const float* ap = p.A + (long long)r * p.lda + k0;
 #pragma unroll
@@ -151,6 +154,7 @@ void gemm_f16_kernel(const pd_gemm_args p) {
     f16x8 wf[2][TN][NPARTS];
     auto wfrag = [&](int buf, int bn0, int ks) {
         if constexpr (F16_ABL & 2) { bn0 = 0; ks = 0; }
+        if constexpr (F16_ABL & 64) { if (ks > 1) return; }      // no B requests inside the slice loop
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const f16x8* base = W2 + ((long long)((bn0 + wn * (32 * TN) + j * 32) >> 5) * nks + ks) * 64 + lane;
@@ -227,7 +231,7 @@ void gemm_f16_kernel(const pd_gemm_args p) {
                 if ((a_q >> 1) == h) {
 #pragma unroll
                     for (int part = 0; part < NPARTS; ++part)
-                        *reinterpret_cast<f16x8*>(sA(h, part) + a_row * PITCH + 8 * (a_q & 1)) = ra2[part];
+                        *reinterpret_cast<f16x8*>(sA(h, part) + a_row * PITCH + 8 * (a_q & 1)) = ra2[part][0];
                 }
             }
 #pragma unroll
@@ -276,7 +280,9 @@ void gemm_f16_kernel(const pd_gemm_args p) {
             _Float16* base = lds + s * TL::STAGE + a_row * PITCH2;
             if constexpr (AS) {
 #pragma unroll
-                for (int part = 0; part < NPARTS; ++part) *reinterpret_cast<f16x8*>(base + part * BM * PITCH2 + 8 * a_q) = ra2[part];
+                for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                    for (int i = 0; i < CPA; ++i) *reinterpret_cast<f16x8*>(base + part * BM * PITCH2 + 8 * (a_q + TPR_A * i)) = ra2[part][i];
             }
 #pragma unroll
             for (int h = 0; h < (AS ? 0 : 2); ++h)
@@ -443,8 +449,19 @@ using F128GD = FTile<128, 128, 4, 8, true>;
 // token projections at ~8-30 samples: w2 / linear_o at 20 samples = 160 tiles of 128 x 128, 320 of these)
 using F64 = FTile<64, 128, 1, 4, true>;
 
+// lab: 256 x 128 tiles, 2 x 4 waves of 128 x 32 (each W fragment feeds four row blocks: half the W requests per MFMA)
+#ifndef PD_F16_T256_BPC
+#define PD_F16_T256_BPC 1
+#endif
+using F256 = FTile<256, 128, 2, 8, true, PD_F16_T256_BPC>;
+
 int dispatch_f16(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s, bool small) {
 #define PD_FCASE(P, E, TL) if (pro == P && epi == E) return run_f16<P, E, TL>(op, p, s);
+#ifdef PD_F16_T256
+    if (!small && (op == 1 || p->M % 256 == 0)) {
+        PD_FCASE(0, EPI_PLAIN, F256) PD_FCASE(3, EPI_PLAIN, F256)
+    }
+#endif
     if (small) {
         PD_FCASE(0, EPI_PLAIN, F64) PD_FCASE(1, EPI_PLAIN, F64) PD_FCASE(3, EPI_PLAIN, F64)
         PD_FCASE(1, EPI_HN, F64) PD_FCASE(2, EPI_HN, F64) PD_FCASE(3, EPI_HN, F64)

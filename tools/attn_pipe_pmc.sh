@@ -36,12 +36,14 @@ for _ in range(5):
 torch.cuda.synchronize()
 PY
 cd /tmp
-for shape in "64 4 2048 1" "256 4 256 0"; do
+IFS=";" read -ra SHAPES <<< "${PD_PMC_SHAPES:-64 4 2048 1;256 4 256 0}"
+for shape in "${SHAPES[@]}"; do
   echo "== attn_pipe_kernel, batch x heads x n x pre-split K/V = $shape"
   for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
              "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU" \
              "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
              "FETCH_SIZE" "WRITE_SIZE"; do
+    if [ -n "${PD_PMC_ONLY:-}" ] && [[ "$set" != $PD_PMC_ONLY ]]; then continue; fi
     tag=$(echo "$shape $set" | cut -c1-28 | tr ' ' '_')
     timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$tag -o p -- python /tmp/attn_one.py $shape > $OUT/$tag.log 2>&1
     python - $OUT/$tag <<'PY'
