@@ -227,7 +227,7 @@ class LaunchTimer:
             name = "gemm_kernel<%s, %s, %s, %s, %d>" % (self.GEMM_NAMES[cfg], "true" if lay >= 1 else "false",
                                                          "true" if lay == 2 else "false", "false" if scalar else "true", pro)
             if streamed:        # persistent direct-epilogue variant (csrc/gemm_stream.hip)
-                name = "gemm_stream_kernel<%d, %d, Tile<%s> >" % (pro, epi, ("128, 128, 2", "64, 64, 2", "128, 64, 4")[tcode])
+                name = "gemm_stream_kernel<%d, %d, Tile<%s> >" % (pro, epi, ("128, 128, 2", "64, 64, 2", "128, 64, 4")[min(tcode, 2)])
                 glu_tile = epi in (2, 5)
                 if nprod == 6:  # 3 x bf16 split-operand variant (csrc/gemm_split.hip); names as rocprofv3 prints them:
                     # PRO = 3 when A arrives pre-split (pd_gemm_args.A3); the STile's last argument = direct-W loop
@@ -236,10 +236,12 @@ class LaunchTimer:
                         (("128, 128, 4, 8, false" if glu_tile else "128, 128, 2, 8, true"), "64, 64, 2, 4, true", "128, 64, 4, 4, true")[tcode])
                 elif nprod == 3:  # 2 x fp16 split-operand variant (csrc/gemm_f16.hip)
                     # (the GLU tile takes direct-W loads - last argument true - when A arrives pre-split)
-                    name = "gemm_f16_kernel<%d, %d, FTile<%s> >" % (
+                    name = "gemm_f16_kernel<%d, %d, FTile<%s, 0> >" % (
                         3 if a.A2 else pro, epi,
                         "64, 128, 1, 4, true" if tcode == 1 else
                         ("128, 128, 4, 8, true" if a.A2 else "128, 128, 4, 8, false") if glu_tile else "128, 128, 2, 8, true")
+                    if tcode in (3, 4):   # K = 128 rows kernel (whole rows in LDS, own statistics): 128- / 64-row tiles
+                        name = "gemm_f16_rows_kernel<%d, %d, %d>" % (pro, epi, 128 if tcode == 3 else 64)
             nb = max(a.batch, 1)
             n_out = a.N // 2 if a.glu else a.N
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))

@@ -671,7 +671,11 @@ PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     pd_gemm_args p = *args;
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
-    if (v >= 0 && !p.stats && p.stats_inline) {       // inline row statistics: the fp32 streaming kernel on the whole problem, or nothing
+    if (v >= 0 && !p.stats && p.stats_inline) {       // inline row statistics: the fp16-format rows kernel or the fp32 streaming kernel on the whole problem, or nothing
+        if (p.W2 && p.w_inv && p.a_amax && !akm && !wkm && vec) {
+            const int q16 = pd_gemm_f16_try(&p, pro, 128, nullptr, 2);
+            if (q16 >= 0) return v + 5000 + 10000 * (q16 & 0xff) + 100000 * (q16 >> 8) + 2000000;
+        }
         const int tile = use_stream() ? stream_tile(cfg, p) : 0;
         const int q = (tile && !p.A3 && !p.A2 && !p.Y2) ? pd_gemm_stream_try(&p, pro, tile, nullptr, 2) : PD_ERR_UNSUPPORTED;
         return q >= 0 ? v + 5000 + 10000 * (q & 0xff) + 100000 * (tile == 128 ? 0 : tile == 64 ? 1 : 2) : PD_ERR_UNSUPPORTED;
@@ -699,7 +703,11 @@ PD_EXPORT int pd_gemm(const pd_gemm_args* args, void* stream) {
     int cfg, pro; bool akm, wkm, vec;
     const int v = select_variant(p, cfg, akm, wkm, vec, pro);
     if (v < 0) return v;
-    if (!p.stats && p.stats_inline) {                 // inline row statistics: only the fp32 streaming kernel computes them (full tiles)
+    if (!p.stats && p.stats_inline) {                 // inline row statistics: the fp16-format rows kernel (K = 128) or the fp32 streaming kernel (full tiles)
+        if (p.W2 && p.w_inv && p.a_amax && !akm && !wkm && vec) {
+            const int r16 = pd_gemm_f16_try(&p, pro, 128, stream, 0);
+            if (r16 != PD_ERR_UNSUPPORTED) return r16;
+        }
         const int tile = use_stream() ? stream_tile(cfg, p) : 0;
         if (!tile || p.A3 || p.A2 || p.Y2) return PD_ERR_UNSUPPORTED;
         return pd_gemm_stream_try(&p, pro, tile, stream, 0);

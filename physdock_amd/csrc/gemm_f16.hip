@@ -435,6 +435,168 @@ int run_f16(int op, const pd_gemm_args* p, hipStream_t s) {
     return pd_check_launch();
 }
 
+
+// ---- "rows" kernel: K = 128 (the atom-level q | k | v projection of a DiT block, transformers.py:149-175 at c_a = 128).
+// As statistics launch + gemm_f16_kernel<1 | 2, HN> this projection read its 67 MB of rows four times (statistics, then once per
+// 128-column tile, each pass normalising and splitting them again in its staging) and ran at 96.7 + 14.7 us for 12.9 GFLOP /
+// 268 MB.  Here a block owns 128 whole rows, as transition_f16.hip does: four threads per row compute its statistics (the
+// arithmetic of pd_rowstats: mean, then centred squares), apply the norm / AdaLN prologue and the operand scale, split, and leave
+// the two fp16 parts of the tile in LDS for ALL column tiles; the weights stream from L2 as MFMA fragments, three 16-k steps
+// ahead.  No barrier after the prologue: the waves walk the column tiles and their epilogues at their own pace.
+constexpr int RLP = 136;                 // LDS row pitch in fp16 (272 bytes = 17 x 16: conflict-free ds_read_b128 fragments)
+// rows per block BM: 128 on eight waves (two blocks per CU: 88 vs 94 us at 64 samples) or 64 on four (four blocks per CU: launches
+// of 256 - 1023 row tiles of 64, 10 - 31 samples: 31.8 vs 42.3 us at 20)
+template <int PRO, int EPI, int BM>
+__global__ __launch_bounds__(4 * BM) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gemm_f16_rows_kernel(const pd_gemm_args p) {
+    constexpr int TM = 2, TN = 1, PART = BM * RLP, NKS = 8, PF = 3, KC = 128;
+#ifdef PD_F16_ROWS_NO_XPF      // lab: the next column tile's first W fragments requested after, not before, this tile's epilogue
+    constexpr bool XPF = false;
+#else
+    constexpr bool XPF = true;
+#endif
+    static_assert(NKS % (PF + 1) == 0, "the fragment ring must be back at buffer 0 when a column tile ends");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float a_s = pd_pow2_scale(*p.a_amax);
+    const float inv_a_s = 1.0f / a_s;
+    const int ntiles = p.M / BM, nNb = p.N / 128;
+    const int wpart = (p.N >> 5) * NKS * 1024;                       // bytes per part of the fragment-major weights
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W2), 0, 2 * wpart, 0x00020000);
+    const int loff = lane * 16;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * BM;
+        {   // ---- prologue: statistics + norm + scale + split of the tile's rows (four threads per row, 16-byte chunks interleaved)
+            const int r = tid >> 2, q = tid & 3;
+            const int m = row0 + r;
+            const float* xr = p.A + (long long)m * p.lda;
+            const int goff = PRO == 2 ? (m / p.pro_rows_per_group) * p.pro_gstride : 0;
+            // (the gain / shift rows are read chunk by chunk in the write loop - cache hits: holding them across the two reductions
+            //  as transition_f16.hip does at 256 registers spills 100 registers at this kernel's 128)
+            f32x4 v[8];
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (q + 4 * i));
+                s1 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+            s1 += __shfl_xor(s1, 1);
+            s1 += __shfl_xor(s1, 2);
+            const float mean = p.stats_inline == 2 ? s1 * (1.0f / KC) : 0.f;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+            sq += __shfl_xor(sq, 1);
+            sq += __shfl_xor(sq, 2);
+            const float rstd = rsqrtf(sq * (1.0f / KC) + p.stats_eps) * a_s;     // the operand scale rides on rstd and on the shift
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 4 * (q + 4 * i);
+                const f32x4 gw = *reinterpret_cast<const f32x4*>(p.pro_w + goff + c), gb = *reinterpret_cast<const f32x4*>(p.pro_b + goff + c);
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (v[i][e] - mean) * rstd * gw[e] + gb[e] * a_s;
+                const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]);
+                *reinterpret_cast<u32x2*>(lds + r * RLP + c) = u32x2{p0.h, p1.h};
+                *reinterpret_cast<u32x2*>(lds + PART + r * RLP + c) = u32x2{p0.l, p1.l};
+            }
+        }
+        lds_barrier();
+        const _Float16* abase = lds + (64 * wm + l31) * RLP + 8 * hh;
+        f16x8 wf[PF + 1][NPARTS];
+        auto wload = [&](int cb, int buf, int ks) {                       // cb: the wave's 32-column block of W
+            const int so = (cb * NKS + ks) * 1024;
+            wf[buf][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so, 0));
+            wf[buf][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so + wpart, 0));
+        };
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) wload(wn, ks, ks);
+#pragma unroll 1
+        for (int nt = 0; nt < nNb; ++nt) {
+            const int bn0 = nt * 128;
+            const int cb = (bn0 >> 5) + wn;
+            if (!XPF && nt > 0) {
+#pragma unroll
+                for (int ks = 0; ks < PF; ++ks) wload(cb, ks, ks);
+            }
+            const int n0 = bn0 + wn * 32 + l31;
+            float c0[TN], c1[TN];
+            c0[0] = p.bias ? p.bias[n0] : 0.f;
+            c1[0] = 1.f;
+            if constexpr (EPI == EPI_HN) c1[0] = p.hn_w[(n0 / p.hn_split) * 32 + l31];
+            const float cs = p.w_inv[n0] * inv_a_s;
+            f32x16 acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks + PF < NKS) wload(cb, (ks + PF) % (PF + 1), ks + PF);
+                // (without the fence hipcc hoists the fragment reads of all eight k-steps - 128 registers - to the head of the tile and spills them)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 32 * i * RLP + 16 * ks);
+                    const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART + 32 * i * RLP + 16 * ks);
+                    f32x16 t = acc[i][0];
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][1], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[ks % (PF + 1)][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][0], t, 0, 0, 0);
+                    acc[i][0] = t;
+                }
+            }
+            // the first fragments of the next column tile travel during this tile's epilogue (NKS % (PF + 1) == 0: buffers 0 .. PF - 1 again)
+            if (XPF && nt + 1 < nNb) {
+#pragma unroll
+                for (int ks = 0; ks < PF; ++ks) wload(cb + 4, ks, ks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][0][r] *= cs;
+            epilogue<EPI, TM, TN>(p, acc, c0, c1, row0, bn0, wm, wn, l31, hh);
+        }
+        lds_barrier();                               // every wave has read the tile: the next one may overwrite it
+    }
+}
+
+template <int PRO, int EPI, int BM>
+int run_f16_rows(int op, const pd_gemm_args* p, hipStream_t s) {
+    auto k = gemm_f16_rows_kernel<PRO, EPI, BM>;
+    constexpr int lds = 2 * BM * RLP * 2;
+    if (op == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    const int ntiles = p->M / BM, grid = 512 * (128 / BM);
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < grid ? ntiles : grid)), dim3(4 * BM), lds, s, *p);
+    return pd_check_launch();
+}
+
+// big: 128-row tiles (op 1 = raise the LDS limit of both instances)
+int dispatch_f16_rows(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s, bool big) {
+#define PD_RCASE(P, E) if (pro == P && epi == E) { \
+        if (op == 1) { const int r = run_f16_rows<P, E, 64>(1, p, s); return r != PD_OK ? r : run_f16_rows<P, E, 128>(1, p, s); } \
+        return big ? run_f16_rows<P, E, 128>(op, p, s) : run_f16_rows<P, E, 64>(op, p, s); }
+    PD_RCASE(1, EPI_HN) PD_RCASE(2, EPI_HN) PD_RCASE(1, EPI_PLAIN) PD_RCASE(2, EPI_PLAIN)
+#undef PD_RCASE
+    return PD_ERR_UNSUPPORTED;
+}
+
+#ifndef PD_F16_ROWS_MIN_TILES
+#define PD_F16_ROWS_MIN_TILES 512      // 128-row tiles from here on (two per block slot) ...
+#endif
+#ifndef PD_F16_ROWS_MIN_TILES64
+#define PD_F16_ROWS_MIN_TILES64 320    // ... else 64-row tiles if there are this many (10 samples of 2048 atoms)
+#endif
+
 using F128 = FTile<128, 128, 2, 8, true>;    // 2 x 4 waves of 64 x 32, direct W
 using F128G = FTile<128, 128, 4, 8, false>;  // 4 x 2 waves of 32 x 64 (GLU: a wave owns both columns of a pair), W through LDS
 #ifdef PD_F16_GLU_LDSW
@@ -489,6 +651,8 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
                     const int r = dispatch_f16(1, P, E, nullptr, nullptr, small != 0);
                     if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
                 }
+                const int r = dispatch_f16_rows(1, P, E, nullptr, nullptr, true);
+                if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
             }
         return rc;
     }
@@ -523,6 +687,22 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
         if (epi != EPI_HN || !p.y2_amax || p.hn_split <= 0 || p.hn_split % 32 != 0 || p.y2_col0 % 32 != 0 ||
             p.ldy2 < 2 * (p.N - p.y2_col0) || p.ldy2 % 8 != 0 || ((uintptr_t)p.Y2 & 15))
             return PD_ERR_UNSUPPORTED;
+    }
+    // row statistics computed by the kernel itself (pd_gemm_args.stats_inline): the rows kernel (K = 128, whole 128-row tiles,
+    // enough of them for two blocks per CU), or nothing
+    if (!p.stats && p.stats_inline) {
+        const bool big = p.M % 128 == 0 && p.M / 128 >= PD_F16_ROWS_MIN_TILES;
+        const bool rows_ok = p.K == 128 && !p.A2 && (pro == 1 || pro == 2) && p.pro_act == PD_ACT_NONE && p.act == PD_ACT_NONE &&
+                             (big || p.M / 64 >= PD_F16_ROWS_MIN_TILES64) && (epi == EPI_HN || epi == EPI_PLAIN) &&
+                             (p.stats_inline == 1 || p.stats_inline == 2) && p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
+                             (((uintptr_t)p.pro_w | (uintptr_t)p.pro_b) & 15) == 0 && p.pro_gstride % 4 == 0 &&
+                             (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 8 * 1024 * 2 < 0x7fffffffll;
+        if (!rows_ok) return PD_ERR_UNSUPPORTED;
+        if (init_only == 2) {
+            const int r = dispatch_f16_rows(1, pro, epi, nullptr, nullptr, big);
+            return r == PD_OK ? epi + (big ? 0x300 : 0x400) : r;          // tile codes 3 / 4: the rows kernel on 128- / 64-row tiles
+        }
+        return dispatch_f16_rows(0, pro, epi, &p, (hipStream_t)stream, big);
     }
     if (init_only == 2) {        // query: the EPI kind, + 0x100 when the launch takes the 64 x 128 tile
         const int r = dispatch_f16(1, pro, epi, nullptr, nullptr, small);

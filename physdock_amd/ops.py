@@ -153,13 +153,22 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
         mode_, eps_ = stats_inline
         key = (M, N, K, a.lda, int(glu), hn_w is not None, mul is not None, res is not None, pro_rows_per_group > 0, out_mode, act, pro_act,
                a.W2 is not None, a.W3 is not None, a.ksplit_ws is not None, bool(a_kmajor), batch)
+        key = key + (INLINE_STATS, F16_ROWS, a.A2 is not None, a.a_amax is not None)
         ok = _INLINE_STATS_OK.get(key)
         if ok is None:
-            v = _lib.init().pd_gemm_variant(C.byref(a))              # with the statistics as an operand: which kernel takes it?
             ok = False
-            if INLINE_STATS and 5000 <= v % 10000 and 0 <= v < 1000000:   # the fp32 streaming kernel: it can compute them itself
+            if F16_ROWS and F16_GEMM and a.W2 and a.a_amax and not a.A2:
+                # rows of 128 channels (the atom q | k | v projection): the fp16-format rows kernel keeps whole rows in LDS and
+                # computes their statistics itself (csrc/gemm_f16.hip: gemm_f16_rows_kernel)
+                saved = a.stats
                 a.stats, a.stats_inline, a.stats_eps = None, (1 if mode_ == RMS else 2), float(eps_)
-                ok = _lib.init().pd_gemm_variant(C.byref(a)) >= 0
+                ok = _lib.init().pd_gemm_variant(C.byref(a)) >= 2000000
+                a.stats, a.stats_inline = saved, 0
+            if not ok:
+                v = _lib.init().pd_gemm_variant(C.byref(a))              # with the statistics as an operand: which kernel takes it?
+                if INLINE_STATS and 5000 <= v % 10000 and 0 <= v < 1000000:   # the fp32 streaming kernel: it can compute them itself
+                    a.stats, a.stats_inline, a.stats_eps = None, (1 if mode_ == RMS else 2), float(eps_)
+                    ok = _lib.init().pd_gemm_variant(C.byref(a)) >= 0
             _INLINE_STATS_OK[key] = ok
         if ok:
             a.stats, a.stats_inline, a.stats_eps = None, (1 if mode_ == RMS else 2), float(eps_)
@@ -198,6 +207,11 @@ PRESPLIT_MIN_C_F16 = 256  # narrowest rows that take the pre-split path when the
 #: OFF: the statistics pass at the head of every block (two dependent sweeps over its rows) costs the consuming kernels more
 #: than the 4.6 us launch it saves - token SwiGLU 11.2 -> 22.2 us, q|k|v 8.7 -> 13.5 us, B = 1 call 88.5 -> 104.4 ms
 INLINE_STATS = False
+
+#: projections of 128-channel rows with a norm prologue (the atom q | k | v of a DiT block) on the fp16-format ROWS kernel: a block
+#: keeps its 128 rows, normalised and split once, in LDS for all column tiles and computes their statistics itself (no pd_rowstats
+#: launch, one pass over the rows instead of four)
+F16_ROWS = True
 
 #: K-split of launches that cannot fill the chip (few samples) when the caller hands pd_gemm a scratch buffer
 KSPLIT_GEMM = True

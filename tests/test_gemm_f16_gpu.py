@@ -350,3 +350,81 @@ def test_fused_atom_transition_vs_three_launches_and_float64(per_sample):
     # shapes the kernel does not cover are declined, not mangled
     assert ops.transition_f16(x1, 128 * 100, Cd, hidden, shift=tabd, scale1p=tabd, gate=tabd, W13=split2_f16(W13), W2=split2_f16(W2d),
                               y_amax=ymax, h_amax=hmax, eps=1e-5) is False
+
+
+@pytest.mark.parametrize("per_sample,mode,with_y2,B", [(False, "ln", True, 64), (True, "ln", True, 64), (False, "rms", False, 64),
+                                                        (True, "ln", False, 64), (False, "ln", True, 20), (True, "ln", True, 24)])
+def test_rows_kernel_of_the_atom_qkv_projection(per_sample, mode, with_y2, B):
+    """gemm_f16_rows_kernel (K = 128: a block keeps its 128 rows, normalised and split once, in LDS for every column tile and computes
+    their statistics itself - ops.gemm(stats_inline=) with fp16-format weights): the atom q | k | v projection of a DiT block at 64
+    samples (128-row tiles) and at 20 / 24 (64-row tiles), against float64 and against the statistics launch + gemm_f16_kernel path
+    it replaces; k | v optionally pre-split (Y2)."""
+    from physdock_amd import ops
+    from physdock_amd.packing import split2_f16
+    N_, Cd = 1024, 128
+    rows = B * N_
+    x = (torch.randn(rows, Cd, generator=g(11)) * torch.exp(torch.randn(rows, 1, generator=g(12))) + 0.5).cuda()
+    ngrp = B if per_sample else 1
+    tab = torch.randn(ngrp, 3 * Cd, generator=g(13)).cuda() * 0.5
+    tab[:, Cd:2 * Cd] += 1.0
+    Wq = (torch.randn(3 * Cd, Cd, generator=g(14)) / math.sqrt(Cd)).cuda()
+    hnw = (1 + 0.1 * torch.randn(2, 32, generator=g(15))).cuda()
+    md, eps = (ops.LN, 1e-5) if mode == "ln" else (ops.RMS, 1e-6)
+    grp = dict(pro_rows_per_group=N_, pro_gstride=3 * Cd) if per_sample else {}
+    ymax = torch.tensor([float(tab[:, Cd:2 * Cd].abs().max()) * math.sqrt(Cd) + float(tab[:, :Cd].abs().max())], device="cuda")
+    hn = dict(hn_w=hnw, hn_cols=2 * Cd, hn_split=Cd, hn_eps=1e-5)
+    # bounds of the pre-split outputs: k after the head norm (|w| sqrt 32), v by Cauchy-Schwarz (|y|_2 <= sqrt C ymax)
+    y2max = torch.tensor([float(hnw[1].abs().max()) * math.sqrt(32.0),
+                          math.sqrt(Cd) * float(ymax) * float(Wq[2 * Cd:].norm(dim=1).max())], device="cuda")
+
+    def run(rows_kernel):
+        seen = []
+        saved = ops.F16_ROWS
+        ops.F16_ROWS = rows_kernel
+        ops._INLINE_STATS_OK.clear()
+        ops.GEMM_HOOK = lambda a, launch: (seen.append((bool(a.stats), a.stats_inline, ops._lib.init().pd_gemm_variant(C_.byref(a)))), launch())
+        try:
+            y = torch.full((rows, 3 * Cd), float("nan"), device="cuda")
+            st = torch.full((rows, 2), float("nan"), device="cuda")
+            kv2 = torch.zeros(rows, 4 * Cd, dtype=torch.float16, device="cuda") if with_y2 else None
+            kw = dict(Y2=kv2, y2_amax=y2max, y2_col0=Cd) if with_y2 else {}
+            ops.gemm(x, Wq, y, rows, 3 * Cd, Cd, stats=st, stats_inline=(md, eps), pro_b=tab, pro_w=tab.data_ptr() + 4 * Cd,
+                     W2=split2_f16(Wq), a_amax=ymax, **hn, **grp, **kw)
+            torch.cuda.synchronize()
+        finally:
+            ops.GEMM_HOOK = None
+            ops.F16_ROWS = saved
+            ops._INLINE_STATS_OK.clear()
+        return y, kv2, st, seen
+    import ctypes as C_
+    y1, kv1, st1, seen1 = run(True)
+    y0, kv0, st0, seen0 = run(False)
+    assert seen1[0][:2] == (False, 1 if mode == "rms" else 2) and tile_code(seen1[0][2]) == (3 if B == 64 else 4) and seen1[0][2] >= 2000000, seen1
+    assert torch.isnan(st1).all()                                  # no pd_rowstats launch
+    assert seen0[0][0] and seen0[0][1] == 0 and torch.isfinite(st0).all()
+    ncmp = Cd if with_y2 else 3 * Cd                              # with Y2 the k | v columns of Y are not written
+    assert torch.isfinite(y1[:, :ncmp]).all()
+    if with_y2:
+        assert torch.isnan(y1[:, Cd:]).all()
+        # the pre-split k | v: both paths split the same head-normalised values up to the rounding of the statistics
+        d = (kv1.float() - kv0.float()).abs()
+        hi_mask = torch.zeros(4 * Cd, dtype=torch.bool, device="cuda").reshape(-1, 8)
+        hi_mask[:, :4] = True
+        assert float(d[:, hi_mask.reshape(-1)].max()) <= 2.0 ** -9 * float(kv0.float().abs().max())     # high parts: within a few fp16 ulps
+    xd = x.double()
+    xn = xd - (xd.mean(-1, keepdim=True) if mode == "ln" else 0)
+    xn = xn * torch.rsqrt(xn.pow(2).mean(-1, keepdim=True) + eps)
+    t = tab.double()
+    sh, sc = (t[:, :Cd], t[:, Cd:2 * Cd])
+    if per_sample:
+        xn = (xn.reshape(B, N_, Cd) * sc[:, None] + sh[:, None]).reshape(rows, Cd)
+    else:
+        xn = xn * sc + sh
+    ref = xn @ Wq.double().t()
+    q = ref[:, :Cd].reshape(rows, Cd // 32, 32)
+    q = q * torch.rsqrt(q.pow(2).mean(-1, keepdim=True) + 1e-5) * hnw[0].double()
+    ref_q = q.reshape(rows, Cd)
+    e1 = float((y1[:, :Cd].double() - ref_q).abs().max()); e0 = float((y0[:, :Cd].double() - ref_q).abs().max())
+    print(f"rows kernel per_sample={per_sample} {mode} y2={with_y2}: max |q error| vs float64 {e1:.2e} (statistics launch + tile kernel {e0:.2e})")
+    assert e1 <= 1.5 * e0 + 1e-6
+    torch.testing.assert_close(y1[:, :ncmp], y0[:, :ncmp], atol=3e-5, rtol=2e-5)
