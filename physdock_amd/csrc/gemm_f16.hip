@@ -486,7 +486,7 @@ void gemm_f16_rows_kernel(const pd_gemm_args p) {
             }
             s1 += __shfl_xor(s1, 1);
             s1 += __shfl_xor(s1, 2);
-            const float mean = p.stats_inline == 2 ? s1 * (1.0f / KC) : 0.f;
+            float mean = p.stats_inline == 2 ? s1 * (1.0f / KC) : 0.f;
             float sq = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -494,7 +494,11 @@ void gemm_f16_rows_kernel(const pd_gemm_args p) {
                 for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
             sq += __shfl_xor(sq, 1);
             sq += __shfl_xor(sq, 2);
-            const float rstd = rsqrtf(sq * (1.0f / KC) + p.stats_eps) * a_s;     // the operand scale rides on rstd and on the shift
+            float rstd = rsqrtf(sq * (1.0f / KC) + p.stats_eps) * a_s;           // the operand scale rides on rstd and on the shift
+            if (p.stats) {                             // statistics supplied (a by-product of another pass over the rows, e.g. pd_pair_bias)
+                mean = p.stats[2 * (long long)m];
+                rstd = p.stats[2 * (long long)m + 1] * a_s;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = 4 * (q + 4 * i);
@@ -593,6 +597,9 @@ int dispatch_f16_rows(int op, int pro, int epi, const pd_gemm_args* p, hipStream
 #ifndef PD_F16_ROWS_MIN_TILES
 #define PD_F16_ROWS_MIN_TILES 512      // 128-row tiles from here on (two per block slot) ...
 #endif
+#ifndef PD_F16_ROWS_GIVEN_STATS
+#define PD_F16_ROWS_GIVEN_STATS 1      // also for launches that bring their statistics (lab: 0 = those stay on the tile kernel)
+#endif
 #ifndef PD_F16_ROWS_MIN_TILES64
 #define PD_F16_ROWS_MIN_TILES64 320    // ... else 64-row tiles if there are this many (10 samples of 2048 atoms)
 #endif
@@ -690,13 +697,15 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
     }
     // row statistics computed by the kernel itself (pd_gemm_args.stats_inline): the rows kernel (K = 128, whole 128-row tiles,
     // enough of them for two blocks per CU), or nothing
-    if (!p.stats && p.stats_inline) {
-        const bool big = p.M % 128 == 0 && p.M / 128 >= PD_F16_ROWS_MIN_TILES;
-        const bool rows_ok = p.K == 128 && !p.A2 && (pro == 1 || pro == 2) && p.pro_act == PD_ACT_NONE && p.act == PD_ACT_NONE &&
-                             (big || p.M / 64 >= PD_F16_ROWS_MIN_TILES64) && (epi == EPI_HN || epi == EPI_PLAIN) &&
-                             (p.stats_inline == 1 || p.stats_inline == 2) && p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
-                             (((uintptr_t)p.pro_w | (uintptr_t)p.pro_b) & 15) == 0 && p.pro_gstride % 4 == 0 &&
-                             (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 8 * 1024 * 2 < 0x7fffffffll;
+    // ... or that the caller supplies (K = 128 with a norm prologue: the rows kernel reads the rows once for all column tiles)
+    const bool rows_big = p.M % 128 == 0 && p.M / 128 >= PD_F16_ROWS_MIN_TILES;
+    const bool rows_ok = p.K == 128 && !p.A2 && (pro == 1 || pro == 2) && p.pro_act == PD_ACT_NONE && p.act == PD_ACT_NONE &&
+                         (rows_big || p.M / 64 >= PD_F16_ROWS_MIN_TILES64) && (epi == EPI_HN || epi == EPI_PLAIN) &&
+                         (p.stats || p.stats_inline == 1 || p.stats_inline == 2) && p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
+                         (((uintptr_t)p.pro_w | (uintptr_t)p.pro_b) & 15) == 0 && p.pro_gstride % 4 == 0 &&
+                         (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 8 * 1024 * 2 < 0x7fffffffll;
+    if ((!p.stats && p.stats_inline) || (rows_ok && PD_F16_ROWS_GIVEN_STATS)) {
+        const bool big = rows_big;
         if (!rows_ok) return PD_ERR_UNSUPPORTED;
         if (init_only == 2) {
             const int r = dispatch_f16_rows(1, pro, epi, nullptr, nullptr, big);
