@@ -23,6 +23,25 @@ __global__ void k(float* out, int iters, float a, float b) {
             else if (KIND == 5) r = r * b;
             else if (KIND == 6) r = r + x[(v + 5) & 15];
             else if (KIND == 7) r = r * 1e-30f;
+            else if (KIND == 9) {            // packed add: two row-sum additions in one instruction
+                f32x2 p = {x[v & 14], x[(v & 14) + 1]}; const f32x2 q = {x[(v + 4) & 14], x[((v + 4) & 14) + 1]};
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p) : "v"(q));
+                x[v & 14] = p[0]; x[(v & 14) + 1] = p[1];
+            } else if (KIND == 10) {         // packed fma, second operand an SGPR pair, third a VGPR pair
+                f32x2 p = {x[v & 14], x[(v & 14) + 1]}; const f32x2 q = {x[(v + 4) & 14], x[((v + 4) & 14) + 1]};
+                const f32x2 c = {a, a};
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p) : "s"(c), "v"(q));
+                x[v & 14] = p[0]; x[(v & 14) + 1] = p[1];
+            } else if (KIND == 11) {         // packed fma, third operand ONE VGPR broadcast to both halves (op_sel_hi = 0 on src2)
+                f32x2 p = {x[v & 14], x[(v & 14) + 1]}; const f32x2 c = {a, a};
+                f32x2 q = {x[(v + 4) & 14], x[((v + 4) & 14) + 1]};
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,1,0]" : "+v"(p) : "s"(c), "v"(q));
+                x[v & 14] = p[0]; x[(v & 14) + 1] = p[1];
+            } else if (KIND == 12) {         // packed mul by an SGPR pair
+                f32x2 p = {x[v & 14], x[(v & 14) + 1]}; const f32x2 c = {b, b};
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p) : "s"(c));
+                x[v & 14] = p[0]; x[(v & 14) + 1] = p[1];
+            }
             else if (KIND == 8) { const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(r), __float_as_uint(r), false, false); r = __uint_as_float(s[0]); }
         }
     }
@@ -57,5 +76,9 @@ int main() {
     run<3>("v_fma_mixlo_f16");
     run<4>("v_max3_f32");
     run<8>("v_permlane32_swap");
+    run<9>("v_pk_add_f32 (2 adds)");
+    run<10>("v_pk_fma_f32 v,s,v (2 fma)");
+    run<11>("v_pk_fma_f32 v,s,v bcast");
+    run<12>("v_pk_mul_f32 v,s (2 mul)");
     return 0;
 }
