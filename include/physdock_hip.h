@@ -106,9 +106,12 @@ typedef struct pd_gemm_args {
     int y2_col0, ldy2;
     /* ABI 7: row statistics computed INSIDE the consuming kernel: stats == NULL and stats_inline = 1 (RMSNorm) or 2 (LayerNorm,
        two passes: mean, then centred squares - the arithmetic of pd_rowstats) with stats_eps; pro_w / pro_b / groups as with
-       stats.  Only the fp32 streaming kernel (csrc/gemm_stream.hip: launches too small to fill the chip - few samples, the
-       trunk's single / MSA tracks) does this: a block re-reads its rows (K floats each, L2-resident) before its main loop,
-       which saves the separate pd_rowstats launch - latency, not bytes.  Anything else answers PD_ERR_UNSUPPORTED.          */
+       stats.  Two kernels do this: the fp32 streaming kernel (csrc/gemm_stream.hip: launches too small to fill the chip - few
+       samples, the trunk's single / MSA tracks): a block re-reads its rows (K floats each, L2-resident) before its main loop,
+       which saves the separate pd_rowstats launch - latency, not bytes; and the fp16-format ROWS kernel (csrc/gemm_f16.hip,
+       gemm_f16_rows_kernel: K == 128, W2 / w_inv / a_amax given, whole 64- / 128-row tiles, plain or head-norm epilogue): a
+       block keeps its rows, normalised and split once, in LDS for every column tile - one pass over A instead of one per
+       column tile plus the statistics pass.  Anything else answers PD_ERR_UNSUPPORTED.                                     */
     int stats_inline;
     float stats_eps;
 } pd_gemm_args;
@@ -117,7 +120,7 @@ int pd_gemm(const pd_gemm_args* args, void* stream);
  * id % 10000 >= 5000: gemm_stream_kernel<id % 10, (id / 10000) % 10, Tile> (csrc/gemm_stream.hip) takes it,
  * Tile = (id / 100000) % 10: 0 -> <128,128,2>, 1 -> <64,64,2>, 2 -> <128,64,4>; id >= 1000000: the split-operand
  * kernel gemm_split_kernel<...> (csrc/gemm_split.hip) with the same template arguments; id >= 2000000: gemm_f16_kernel<...>
- * (csrc/gemm_f16.hip, two-part fp16 operands) */
+ * (csrc/gemm_f16.hip, two-part fp16 operands; tile field (id % 1000000) / 100000 = 3 / 4: gemm_f16_rows_kernel<pro, EPI, 128 / 64>) */
 int pd_gemm_variant(const pd_gemm_args* args);
 
 /* ---- pd_rowstats: per-row (mean, rstd) for the GEMM prologue --------------------------

@@ -664,7 +664,7 @@ extern "C" __attribute__((visibility("default"))) int pd_lab_set_gemm_trace(void
 }
 #endif
 
-// variant id as documented above; + 5000 + 10000 * EPI + 100000 * tile (0: 128x128, 1: 64x64, 2: 128x64) when the launch
+// variant id as documented above; + 5000 + 10000 * EPI + 100000 * tile (0: 128x128, 1: 64x64 [64x128 for the fp16 kernel], 2: 128x64, 3 / 4: the fp16 ROWS kernel on 128- / 64-row tiles) when the launch
 // goes to gemm_stream_kernel<pro, EPI, Tile<...>>, + 1000000 more when it goes to gemm_split_kernel<pro, EPI, STile<...>>
 PD_EXPORT int pd_gemm_variant(const pd_gemm_args* args) {
     if (!args) return PD_ERR_ARG;
