@@ -426,5 +426,5 @@ def test_rows_kernel_of_the_atom_qkv_projection(per_sample, mode, with_y2, B):
     ref_q = q.reshape(rows, Cd)
     e1 = float((y1[:, :Cd].double() - ref_q).abs().max()); e0 = float((y0[:, :Cd].double() - ref_q).abs().max())
     print(f"rows kernel per_sample={per_sample} {mode} y2={with_y2}: max |q error| vs float64 {e1:.2e} (statistics launch + tile kernel {e0:.2e})")
-    assert e1 <= 1.5 * e0 + 1e-6
+    assert e1 <= 1.5 * e0 + 1e-6 and e1 <= 5e-5          # (absolute too: both paths share the head-norm epilogue)
     torch.testing.assert_close(y1[:, :ncmp], y0[:, :ncmp], atol=3e-5, rtol=2e-5)
