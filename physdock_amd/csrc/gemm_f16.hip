@@ -572,6 +572,160 @@ void gemm_f16_rows_kernel(const pd_gemm_args p) {
     }
 }
 
+
+// ---- "wide rows" kernel: K = 512 (the token-level q | k | v projection of a DiT block, transformers.py:149-175 at c_s = 512).
+// The A-stationary form of the rows kernel above for rows that fill LDS: a block of SIXTEEN waves owns 64 whole rows (2 x 64 x
+// 1040 bytes = 130 KB of LDS, one block per CU, four waves per SIMD), sixteen threads per row compute the statistics, normalise,
+// modulate, scale and split them ONCE; then every wave takes every sixteenth 32-column block of the output and runs its whole
+// K = 512 contraction against the resident tile - 192 MFMAs per block with nothing but LDS fragment reads and W fragments from
+// L2 (four 16-k steps in flight, the ring runs on into the wave's next column block) - and the shared epilogue.  Against
+// pd_norm_split2 + gemm_f16_kernel<3, .>: no normalised copy of the activations through HBM (33 MB out, 12 x re-read), no A
+// requests, LDS stores or block barriers in the main loop.  The price: every CU streams the whole weight matrix once per 64 rows.
+constexpr int WLP = 520;                 // LDS row pitch in fp16 (1040 bytes = 65 x 16: conflict-free ds_read_b128 fragments)
+constexpr int WROWS_LDS_BYTES = 2 * 64 * WLP * 2;
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gemm_f16_wrows_kernel(const pd_gemm_args p) {
+    constexpr int BM = 64, KC = 512, TM = 2, TN = 1, PART = BM * WLP, NKS = KC / 16, PF = 3, NWV = 16;
+    static_assert(NKS % (PF + 1) == 0, "the fragment ring must be back at buffer 0 when a column block ends");
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float a_s = pd_pow2_scale(*p.a_amax);
+    const float inv_a_s = 1.0f / a_s;
+    const int ntiles = p.M / BM, ncb = p.N >> 5;
+    const int wpart = ncb * NKS * 1024;                              // bytes per part of the fragment-major weights
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W2), 0, 2 * wpart, 0x00020000);
+    const int loff = lane * 16;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * BM;
+        {   // ---- prologue: sixteen threads (one DPP row) per row, 16-byte chunks interleaved
+            const int r = tid >> 4, q = tid & 15;
+            const int m = row0 + r;
+            const float* xr = p.A + (long long)m * p.lda;
+            const int goff = PRO == 2 ? (m / p.pro_rows_per_group) * p.pro_gstride : 0;
+            f32x4 v[8];
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (q + 16 * i));
+                s1 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+            auto row16 = [](float x) {                  // sum over the 16 lanes of a DPP row, in every lane
+                x += pd_dpp<0xB1>(x); x += pd_dpp<0x4E>(x); x += pd_dpp<0x141>(x); x += pd_dpp<0x140>(x);
+                return x;
+            };
+            s1 = row16(s1);
+            float mean = p.stats_inline == 2 ? s1 * (1.0f / KC) : 0.f;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+            sq = row16(sq);
+            float rstd = rsqrtf(sq * (1.0f / KC) + p.stats_eps) * a_s;           // the operand scale rides on rstd and on the shift
+            if (p.stats) {
+                mean = p.stats[2 * (long long)m];
+                rstd = p.stats[2 * (long long)m + 1] * a_s;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 4 * (q + 16 * i);
+                const f32x4 gw = *reinterpret_cast<const f32x4*>(p.pro_w + goff + c), gb = *reinterpret_cast<const f32x4*>(p.pro_b + goff + c);
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (v[i][e] - mean) * rstd * gw[e] + gb[e] * a_s;
+                const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]);
+                *reinterpret_cast<u32x2*>(lds + r * WLP + c) = u32x2{p0.h, p1.h};
+                *reinterpret_cast<u32x2*>(lds + PART + r * WLP + c) = u32x2{p0.l, p1.l};
+            }
+        }
+        lds_barrier();
+        const _Float16* abase = lds + l31 * WLP + 8 * hh;
+        f16x8 wf[PF + 1][NPARTS];
+        auto wload = [&](int cb, int buf, int ks) {                       // cb: 32-column block of W
+            const int so = (cb * NKS + ks) * 1024;
+            wf[buf][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so, 0));
+            wf[buf][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so + wpart, 0));
+        };
+        if (wave < ncb) {
+#pragma unroll
+            for (int ks = 0; ks < PF; ++ks) wload(wave, ks, ks);
+        }
+#pragma unroll 1
+        for (int cb = wave; cb < ncb; cb += NWV) {
+            const int n0 = cb * 32 + l31;
+            float c0[TN], c1[TN];
+            c0[0] = p.bias ? p.bias[n0] : 0.f;
+            c1[0] = 1.f;
+            if constexpr (EPI == EPI_HN) c1[0] = p.hn_w[(n0 / p.hn_split) * 32 + l31];
+            const float cs = p.w_inv[n0] * inv_a_s;
+            f32x16 acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+            // four 16-k steps per trip (one turn of the fragment ring); the last trip's requests are the next column block's first
+            auto group = [&](int ks0, auto last_c) {
+                constexpr bool last = decltype(last_c)::value;
+#pragma unroll
+                for (int j = 0; j < PF + 1; ++j) {
+                    const int ks = ks0 + j;
+                    if constexpr (!last) wload(cb, (j + PF) % (PF + 1), ks + PF);
+                    else if (j == 0) wload(cb, PF % (PF + 1), ks + PF);              // ks0 + PF = NKS - 1: still this block
+                    else if (cb + NWV < ncb) wload(cb + NWV, (j + PF) % (PF + 1), j - 1);
+                    __builtin_amdgcn_sched_barrier(0);          // keeps the fragment reads of later steps where they are (registers)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 32 * i * WLP + 16 * ks);
+                        const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART + 32 * i * WLP + 16 * ks);
+                        f32x16 t = acc[i][0];
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[j][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[j][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[j][0], t, 0, 0, 0);
+                        acc[i][0] = t;
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int ks0 = 0; ks0 < NKS - (PF + 1); ks0 += PF + 1) group(ks0, std::false_type{});
+            group(NKS - (PF + 1), std::true_type{});
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][0][r] *= cs;
+            epilogue<EPI, TM, TN>(p, acc, c0, c1, row0, cb * 32, 0, 0, l31, hh);
+        }
+        lds_barrier();                               // every wave has read the tile: the next one may overwrite it
+    }
+}
+
+template <int PRO, int EPI>
+int run_f16_wrows(int op, const pd_gemm_args* p, hipStream_t s) {
+    auto k = gemm_f16_wrows_kernel<PRO, EPI>;
+    if (op == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WROWS_LDS_BYTES) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    const int ntiles = p->M / 64;
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(1024), WROWS_LDS_BYTES, s, *p);
+    return pd_check_launch();
+}
+
+int dispatch_f16_wrows(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s) {
+    if (pro == 1 && epi == EPI_HN) return run_f16_wrows<1, EPI_HN>(op, p, s);
+    if (pro == 2 && epi == EPI_HN) return run_f16_wrows<2, EPI_HN>(op, p, s);
+    if (pro == 1 && epi == EPI_PLAIN) return run_f16_wrows<1, EPI_PLAIN>(op, p, s);
+    if (pro == 2 && epi == EPI_PLAIN) return run_f16_wrows<2, EPI_PLAIN>(op, p, s);
+    return PD_ERR_UNSUPPORTED;
+}
+
+#ifndef PD_F16_WROWS_MIN_TILES
+#define PD_F16_WROWS_MIN_TILES 256     // 64-row tiles: one block per CU and round
+#endif
+
 template <int PRO, int EPI, int BM>
 int run_f16_rows(int op, const pd_gemm_args* p, hipStream_t s) {
     auto k = gemm_f16_rows_kernel<PRO, EPI, BM>;
@@ -660,6 +814,8 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
                 }
                 const int r = dispatch_f16_rows(1, P, E, nullptr, nullptr, true);
                 if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
+                const int rw = dispatch_f16_wrows(1, P, E, nullptr, nullptr);
+                if (rw != PD_OK && rw != PD_ERR_UNSUPPORTED) rc = rw;
             }
         return rc;
     }
@@ -704,6 +860,19 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
                          (p.stats || p.stats_inline == 1 || p.stats_inline == 2) && p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
                          (((uintptr_t)p.pro_w | (uintptr_t)p.pro_b) & 15) == 0 && p.pro_gstride % 4 == 0 &&
                          (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 8 * 1024 * 2 < 0x7fffffffll;
+    // K = 512: the wide-rows kernel (64-row tiles on sixteen waves; only with inline statistics: callers that pre-split A keep that path)
+    const bool wrows_ok = p.K == 512 && !p.A2 && !p.stats && (pro == 1 || pro == 2) && p.pro_act == PD_ACT_NONE && p.act == PD_ACT_NONE &&
+                          p.M / 64 >= PD_F16_WROWS_MIN_TILES && (epi == EPI_HN || epi == EPI_PLAIN) &&
+                          (p.stats_inline == 1 || p.stats_inline == 2) && p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
+                          (((uintptr_t)p.pro_w | (uintptr_t)p.pro_b) & 15) == 0 && p.pro_gstride % 4 == 0 &&
+                          (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 32 * 1024 * 2 < 0x7fffffffll;
+    if (wrows_ok) {
+        if (init_only == 2) {
+            const int r = dispatch_f16_wrows(1, pro, epi, nullptr, nullptr);
+            return r == PD_OK ? epi + 0x500 : r;          // tile code 5: the wide-rows kernel
+        }
+        return dispatch_f16_wrows(0, pro, epi, &p, (hipStream_t)stream);
+    }
     if ((!p.stats && p.stats_inline) || (rows_ok && PD_F16_ROWS_GIVEN_STATS)) {
         const bool big = rows_big;
         if (!rows_ok) return PD_ERR_UNSUPPORTED;

@@ -610,7 +610,11 @@ class Engine:
         # fp16 operand format too - and write their output already split for linear_o (no split VALU in that GEMM's staging)
         akw = dict(nq=N, nk=nk, nbatch=B, nheads=H, q_strides=st3, k_strides=st3, v_strides=st3, o_strides=(N * C, C), bias=bias,
                    bias_nk=N, ws=self.attn_ws(B, N, nk, H), f16_amax=bnd, bias_prescale=bias_prescale)
-        qkv_presplit = bool(presplit and ops.PRESPLIT_QKV)
+        # (K = 512 rows in chip-filling launches: the wide-rows kernel normalises and splits a block's rows inside the projection -
+        #  no pre-split copy for q | k | v at all; asked of the library)
+        wrows = bool(f16 and ops.F16_ROWS and ops.F16_WIDE_ROWS and C == 512 and ops.rows_inline_supported(
+            rows, 3 * C, C, hn=True, per_group_rows=N if per_sample else 0, gstride=tab_ld if per_sample else 0))
+        qkv_presplit = bool(presplit and ops.PRESPLIT_QKV and not wrows)
         # k | v leave the projection already scaled and split for that attention kernel (bounds bnd[1], bnd[2]): only when BOTH
         # launches are the fp16-format kernels - asked of the library, never assumed
         kv2 = None

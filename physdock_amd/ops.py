@@ -96,6 +96,34 @@ def kv2_supported(M, Cdim, *, a2, per_group_rows=0):
     return r
 
 
+_ROWS_OK = {}
+
+
+def rows_inline_supported(M, N, K, *, hn=False, y2=False, per_group_rows=0, gstride=0):
+    """Does the library run this norm-prologue projection on one of the fp16-format ROWS kernels (whole rows resident in LDS, own
+    statistics: csrc/gemm_f16.hip gemm_f16_rows_kernel at K = 128, gemm_f16_wrows_kernel at K = 512)?  Asked of the library
+    (pd_gemm_variant with stats_inline), as presplit_supported."""
+    key = (M, N, K, bool(hn), bool(y2), int(per_group_rows), int(gstride))
+    r = _ROWS_OK.get(key)
+    if r is None:
+        a = GemmArgs()
+        a.A = a.W = a.Y = a.W2 = a.w_inv = a.a_amax = a.pro_w = a.pro_b = 1 << 20
+        a.M, a.N, a.K = M, N, K
+        a.lda, a.ldw, a.ldy = K, K, N
+        a.batch, a.out_scale = 1, 1.0
+        a.stats_inline, a.stats_eps = 2, 1e-5
+        a.pro_rows_per_group, a.pro_gstride = int(per_group_rows), int(gstride)
+        if hn:
+            a.hn_w, a.hn_cols, a.hn_split = 1 << 20, 2 * (N // 3), N // 3
+        if y2:
+            a.Y2 = a.y2_amax = 1 << 20
+            a.y2_col0, a.ldy2 = N // 3, 4 * (N // 3)
+        v = _lib.init().pd_gemm_variant(C.byref(a))
+        r = v >= 2000000 and (v % 1000000) // 100000 >= 3
+        _ROWS_OK[key] = r
+    return r
+
+
 def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0, sY=0,
          a_kmajor=False, w_kmajor=False, stats=None, pro_w=None, pro_b=None, pro_rows_per_group=0,
          pro_gstride=0, pro_act=ACT_NONE, rowscale_acc=None, bias=None, sBias=0, hn_w=None, hn_cols=0,
@@ -212,6 +240,8 @@ INLINE_STATS = False
 #: keeps its 128 rows, normalised and split once, in LDS for all column tiles and computes their statistics itself (no pd_rowstats
 #: launch, one pass over the rows instead of four)
 F16_ROWS = True
+#: ... and the token-level q | k | v projection (K = 512) on the wide-rows kernel instead of pd_norm_split2 + the tile kernel
+F16_WIDE_ROWS = True
 
 #: K-split of launches that cannot fill the chip (few samples) when the caller hands pd_gemm a scratch buffer
 KSPLIT_GEMM = True

@@ -352,16 +352,17 @@ def test_fused_atom_transition_vs_three_launches_and_float64(per_sample):
                               y_amax=ymax, h_amax=hmax, eps=1e-5) is False
 
 
-@pytest.mark.parametrize("per_sample,mode,with_y2,B", [(False, "ln", True, 64), (True, "ln", True, 64), (False, "rms", False, 64),
-                                                        (True, "ln", False, 64), (False, "ln", True, 20), (True, "ln", True, 24)])
-def test_rows_kernel_of_the_atom_qkv_projection(per_sample, mode, with_y2, B):
+@pytest.mark.parametrize("per_sample,mode,with_y2,B,Cd", [(False, "ln", True, 64, 128), (True, "ln", True, 64, 128), (False, "rms", False, 64, 128),
+                                                           (True, "ln", False, 64, 128), (False, "ln", True, 20, 128), (True, "ln", True, 24, 128),
+                                                           (False, "ln", True, 64, 512), (True, "ln", True, 64, 512), (False, "rms", False, 80, 512)])
+def test_rows_kernel_of_the_atom_qkv_projection(per_sample, mode, with_y2, B, Cd):
     """gemm_f16_rows_kernel (K = 128: a block keeps its 128 rows, normalised and split once, in LDS for every column tile and computes
     their statistics itself - ops.gemm(stats_inline=) with fp16-format weights): the atom q | k | v projection of a DiT block at 64
     samples (128-row tiles) and at 20 / 24 (64-row tiles), against float64 and against the statistics launch + gemm_f16_kernel path
     it replaces; k | v optionally pre-split (Y2)."""
     from physdock_amd import ops
     from physdock_amd.packing import split2_f16
-    N_, Cd = 1024, 128
+    N_ = 1024 if Cd == 128 else 256            # Cd = 512: the token-level projection on the wide-rows kernel (64 rows on 16 waves)
     rows = B * N_
     x = (torch.randn(rows, Cd, generator=g(11)) * torch.exp(torch.randn(rows, 1, generator=g(12))) + 0.5).cuda()
     ngrp = B if per_sample else 1
@@ -399,7 +400,7 @@ def test_rows_kernel_of_the_atom_qkv_projection(per_sample, mode, with_y2, B):
     import ctypes as C_
     y1, kv1, st1, seen1 = run(True)
     y0, kv0, st0, seen0 = run(False)
-    assert seen1[0][:2] == (False, 1 if mode == "rms" else 2) and tile_code(seen1[0][2]) == (3 if B == 64 else 4) and seen1[0][2] >= 2000000, seen1
+    assert seen1[0][:2] == (False, 1 if mode == "rms" else 2) and tile_code(seen1[0][2]) == (5 if Cd == 512 else 3 if B == 64 else 4) and seen1[0][2] >= 2000000, seen1
     assert torch.isnan(st1).all()                                  # no pd_rowstats launch
     assert seen0[0][0] and seen0[0][1] == 0 and torch.isfinite(st0).all()
     ncmp = Cd if with_y2 else 3 * Cd                              # with Y2 the k | v columns of Y are not written

@@ -19,7 +19,7 @@ def timeit(fn, n=30, warm=5):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-Cd, N_ = 128, 2048
+Cd, N_ = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (128, 2048)
 for B in (64, 48, 32, 20, 16, 8, 4):
     rows = B * N_
     x = torch.randn(rows, Cd, device="cuda")
