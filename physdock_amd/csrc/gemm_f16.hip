@@ -584,11 +584,15 @@ void gemm_f16_rows_kernel(const pd_gemm_args p) {
 constexpr int WLP = 520;                 // LDS row pitch in fp16 (1040 bytes = 65 x 16: conflict-free ds_read_b128 fragments)
 constexpr int WROWS_LDS_BYTES = 2 * 64 * WLP * 2;
 
-template <int PRO, int EPI>
+// Wave tile: 64 rows x 32 columns (TM = 2, TN = 1: a W fragment feeds two row blocks) for the plain / head-norm epilogues; 32 rows x
+// 64 packed columns (TM = 1, TN = 2: a GLU pair needs both of its columns in one wave; two waves then stream the same W block, as
+// in the 128 x 128 GLU tile) for the SwiGLU up-projection.  Work items (row group, column unit) are dealt to the waves round-robin.
+template <int PRO, int EPI, int TM, int TN>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void gemm_f16_wrows_kernel(const pd_gemm_args p) {
-    constexpr int BM = 64, KC = 512, TM = 2, TN = 1, PART = BM * WLP, NKS = KC / 16, PF = 3, NWV = 16;
-    static_assert(NKS % (PF + 1) == 0, "the fragment ring must be back at buffer 0 when a column block ends");
+    constexpr int BM = 64, KC = 512, PART = BM * WLP, NKS = KC / 16, PF = 3, NWV = 16, RG = 2 / TM;
+    static_assert(NKS % (PF + 1) == 0, "the fragment ring must be back at buffer 0 when a work item ends");
+    static_assert(TM * RG == 2 && NWV % RG == 0, "a wave keeps its row group");
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -596,9 +600,11 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
     const float a_s = pd_pow2_scale(*p.a_amax);
     const float inv_a_s = 1.0f / a_s;
     const int ntiles = p.M / BM, ncb = p.N >> 5;
+    const int nitems = RG * (ncb / TN);
     const int wpart = ncb * NKS * 1024;                              // bytes per part of the fragment-major weights
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W2), 0, 2 * wpart, 0x00020000);
     const int loff = lane * 16;
+    const int rh = wave % RG;                                        // this wave's row group (32 TM rows)
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * BM;
@@ -644,49 +650,61 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
             }
         }
         lds_barrier();
-        const _Float16* abase = lds + l31 * WLP + 8 * hh;
-        f16x8 wf[PF + 1][NPARTS];
-        auto wload = [&](int cb, int buf, int ks) {                       // cb: 32-column block of W
-            const int so = (cb * NKS + ks) * 1024;
-            wf[buf][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so, 0));
-            wf[buf][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so + wpart, 0));
-        };
-        if (wave < ncb) {
+        const _Float16* abase = lds + (32 * TM * rh + l31) * WLP + 8 * hh;
+        f16x8 wf[PF + 1][TN][NPARTS];
+        auto wload = [&](int cu, int buf, int ks) {                       // cu: column unit = TN consecutive 32-column blocks of W
 #pragma unroll
-            for (int ks = 0; ks < PF; ++ks) wload(wave, ks, ks);
+            for (int j = 0; j < TN; ++j) {
+                const int so = ((cu * TN + j) * NKS + ks) * 1024;
+                wf[buf][j][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so, 0));
+                wf[buf][j][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so + wpart, 0));
+            }
+        };
+        if (wave < nitems) {
+#pragma unroll
+            for (int ks = 0; ks < PF; ++ks) wload(wave / RG, ks, ks);
         }
 #pragma unroll 1
-        for (int cb = wave; cb < ncb; cb += NWV) {
-            const int n0 = cb * 32 + l31;
-            float c0[TN], c1[TN];
-            c0[0] = p.bias ? p.bias[n0] : 0.f;
-            c1[0] = 1.f;
-            if constexpr (EPI == EPI_HN) c1[0] = p.hn_w[(n0 / p.hn_split) * 32 + l31];
-            const float cs = p.w_inv[n0] * inv_a_s;
+        for (int item = wave; item < nitems; item += NWV) {
+            const int cu = item / RG;
+            const int n0 = cu * (32 * TN) + l31;
+            float c0[TN], c1[TN], cs[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                c0[j] = p.bias ? p.bias[n0 + 32 * j] : 0.f;
+                c1[j] = 1.f;
+                if constexpr (EPI == EPI_HN) c1[j] = p.hn_w[((n0 + 32 * j) / p.hn_split) * 32 + l31];
+                cs[j] = p.w_inv[n0 + 32 * j] * inv_a_s;
+            }
             f32x16 acc[TM][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-            // four 16-k steps per trip (one turn of the fragment ring); the last trip's requests are the next column block's first
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            // four 16-k steps per trip (one turn of the fragment ring); the last trip's requests are the next work item's first
             auto group = [&](int ks0, auto last_c) {
                 constexpr bool last = decltype(last_c)::value;
 #pragma unroll
-                for (int j = 0; j < PF + 1; ++j) {
-                    const int ks = ks0 + j;
-                    if constexpr (!last) wload(cb, (j + PF) % (PF + 1), ks + PF);
-                    else if (j == 0) wload(cb, PF % (PF + 1), ks + PF);              // ks0 + PF = NKS - 1: still this block
-                    else if (cb + NWV < ncb) wload(cb + NWV, (j + PF) % (PF + 1), j - 1);
+                for (int jj = 0; jj < PF + 1; ++jj) {
+                    const int ks = ks0 + jj;
+                    if constexpr (!last) wload(cu, (jj + PF) % (PF + 1), ks + PF);
+                    else if (jj == 0) wload(cu, PF % (PF + 1), ks + PF);              // ks0 + PF = NKS - 1: still this item
+                    else if (item + NWV < nitems) wload((item + NWV) / RG, (jj + PF) % (PF + 1), jj - 1);
                     __builtin_amdgcn_sched_barrier(0);          // keeps the fragment reads of later steps where they are (registers)
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 32 * i * WLP + 16 * ks);
                         const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART + 32 * i * WLP + 16 * ks);
-                        f32x16 t = acc[i][0];
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[j][1], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[j][0], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[j][0], t, 0, 0, 0);
-                        acc[i][0] = t;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            f32x16 t = acc[i][j];
+                            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[jj][j][1], t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[jj][j][0], t, 0, 0, 0);
+                            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[jj][j][0], t, 0, 0, 0);
+                            acc[i][j] = t;
+                        }
                     }
                 }
             };
@@ -696,16 +714,18 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][0][r] *= cs;
-            epilogue<EPI, TM, TN>(p, acc, c0, c1, row0, cb * 32, 0, 0, l31, hh);
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= cs[j];
+            epilogue<EPI, TM, TN>(p, acc, c0, c1, row0, cu * (32 * TN), rh, 0, l31, hh);
         }
         lds_barrier();                               // every wave has read the tile: the next one may overwrite it
     }
 }
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, int TM, int TN>
 int run_f16_wrows(int op, const pd_gemm_args* p, hipStream_t s) {
-    auto k = gemm_f16_wrows_kernel<PRO, EPI>;
+    auto k = gemm_f16_wrows_kernel<PRO, EPI, TM, TN>;
     if (op == 1)
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WROWS_LDS_BYTES) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
@@ -715,10 +735,12 @@ int run_f16_wrows(int op, const pd_gemm_args* p, hipStream_t s) {
 }
 
 int dispatch_f16_wrows(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s) {
-    if (pro == 1 && epi == EPI_HN) return run_f16_wrows<1, EPI_HN>(op, p, s);
-    if (pro == 2 && epi == EPI_HN) return run_f16_wrows<2, EPI_HN>(op, p, s);
-    if (pro == 1 && epi == EPI_PLAIN) return run_f16_wrows<1, EPI_PLAIN>(op, p, s);
-    if (pro == 2 && epi == EPI_PLAIN) return run_f16_wrows<2, EPI_PLAIN>(op, p, s);
+    if (pro == 1 && epi == EPI_HN) return run_f16_wrows<1, EPI_HN, 2, 1>(op, p, s);
+    if (pro == 2 && epi == EPI_HN) return run_f16_wrows<2, EPI_HN, 2, 1>(op, p, s);
+    if (pro == 1 && epi == EPI_PLAIN) return run_f16_wrows<1, EPI_PLAIN, 2, 1>(op, p, s);
+    if (pro == 2 && epi == EPI_PLAIN) return run_f16_wrows<2, EPI_PLAIN, 2, 1>(op, p, s);
+    if (pro == 1 && epi == EPI_GLU) return run_f16_wrows<1, EPI_GLU, 1, 2>(op, p, s);
+    if (pro == 2 && epi == EPI_GLU) return run_f16_wrows<2, EPI_GLU, 1, 2>(op, p, s);
     return PD_ERR_UNSUPPORTED;
 }
 
@@ -862,7 +884,7 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
                          (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 8 * 1024 * 2 < 0x7fffffffll;
     // K = 512: the wide-rows kernel (64-row tiles on sixteen waves; only with inline statistics: callers that pre-split A keep that path)
     const bool wrows_ok = p.K == 512 && !p.A2 && !p.stats && (pro == 1 || pro == 2) && p.pro_act == PD_ACT_NONE && p.act == PD_ACT_NONE &&
-                          p.M / 64 >= PD_F16_WROWS_MIN_TILES && (epi == EPI_HN || epi == EPI_PLAIN) &&
+                          p.M / 64 >= PD_F16_WROWS_MIN_TILES && (epi == EPI_HN || epi == EPI_PLAIN || (epi == EPI_GLU && p.N % 64 == 0)) &&
                           (p.stats_inline == 1 || p.stats_inline == 2) && p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
                           (((uintptr_t)p.pro_w | (uintptr_t)p.pro_b) & 15) == 0 && p.pro_gstride % 4 == 0 &&
                           (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 32 * 1024 * 2 < 0x7fffffffll;

@@ -650,7 +650,9 @@ class Engine:
                                        rows_per_group=N if per_sample else 0, gstride=tab_ld if per_sample else 0):
             return                       # atom rows: statistics + SwiGLU + down-projection + gate + residual in one launch
         h = self.lws("dit_h", rows, hidden)
-        if presplit:
+        wrows_glu = bool(f16 and ops.F16_ROWS and ops.F16_WIDE_ROWS and ops.F16_WIDE_ROWS_GLU and C == 512 and ops.rows_inline_supported(
+            rows, 2 * hidden, C, glu=1, per_group_rows=N if per_sample else 0, gstride=tab_ld if per_sample else 0))
+        if presplit and not wrows_glu:
             self.gemm(x, W13, h, rows, 2 * hidden, C, glu=1, a_amax=b_y2, **norm_split(t2, b_y2))
         else:
             self.gemm(x, W13, h, rows, 2 * hidden, C, stats=self.stats_buf(rows), stats_inline=(LN, eps), pro_b=off(tab, t2),

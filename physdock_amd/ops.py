@@ -99,18 +99,18 @@ def kv2_supported(M, Cdim, *, a2, per_group_rows=0):
 _ROWS_OK = {}
 
 
-def rows_inline_supported(M, N, K, *, hn=False, y2=False, per_group_rows=0, gstride=0):
+def rows_inline_supported(M, N, K, *, hn=False, y2=False, glu=0, per_group_rows=0, gstride=0):
     """Does the library run this norm-prologue projection on one of the fp16-format ROWS kernels (whole rows resident in LDS, own
     statistics: csrc/gemm_f16.hip gemm_f16_rows_kernel at K = 128, gemm_f16_wrows_kernel at K = 512)?  Asked of the library
     (pd_gemm_variant with stats_inline), as presplit_supported."""
-    key = (M, N, K, bool(hn), bool(y2), int(per_group_rows), int(gstride))
+    key = (M, N, K, bool(hn), bool(y2), int(glu), int(per_group_rows), int(gstride))
     r = _ROWS_OK.get(key)
     if r is None:
         a = GemmArgs()
         a.A = a.W = a.Y = a.W2 = a.w_inv = a.a_amax = a.pro_w = a.pro_b = 1 << 20
         a.M, a.N, a.K = M, N, K
-        a.lda, a.ldw, a.ldy = K, K, N
-        a.batch, a.out_scale = 1, 1.0
+        a.lda, a.ldw, a.ldy = K, K, (N // 2 if glu else N)
+        a.batch, a.glu, a.out_scale = 1, int(glu), 1.0
         a.stats_inline, a.stats_eps = 2, 1e-5
         a.pro_rows_per_group, a.pro_gstride = int(per_group_rows), int(gstride)
         if hn:
@@ -240,8 +240,9 @@ INLINE_STATS = False
 #: keeps its 128 rows, normalised and split once, in LDS for all column tiles and computes their statistics itself (no pd_rowstats
 #: launch, one pass over the rows instead of four)
 F16_ROWS = True
-#: ... and the token-level q | k | v projection (K = 512) on the wide-rows kernel instead of pd_norm_split2 + the tile kernel
+#: ... and the token-level q | k | v and SwiGLU up-projections (K = 512) on the wide-rows kernel instead of pd_norm_split2 + the tile kernel
 F16_WIDE_ROWS = True
+F16_WIDE_ROWS_GLU = True
 
 #: K-split of launches that cannot fill the chip (few samples) when the caller hands pd_gemm a scratch buffer
 KSPLIT_GEMM = True

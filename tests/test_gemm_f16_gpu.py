@@ -429,3 +429,54 @@ def test_rows_kernel_of_the_atom_qkv_projection(per_sample, mode, with_y2, B, Cd
     print(f"rows kernel per_sample={per_sample} {mode} y2={with_y2}: max |q error| vs float64 {e1:.2e} (statistics launch + tile kernel {e0:.2e})")
     assert e1 <= 1.5 * e0 + 1e-6 and e1 <= 5e-5          # (absolute too: both paths share the head-norm epilogue)
     torch.testing.assert_close(y1[:, :ncmp], y0[:, :ncmp], atol=3e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("per_sample,B", [(False, 64), (True, 64), (False, 72)])
+def test_wide_rows_kernel_of_the_token_swiglu_projection(per_sample, B):
+    """gemm_f16_wrows_kernel<., GLU, 1, 2> (K = 512: 64 rows resident in LDS on sixteen waves, own statistics, SwiGLU epilogue): the
+    token-level up-projection of a DiT block against float64 and against pd_norm_split2 + the 128 x 128 GLU tile kernel it replaces."""
+    import ctypes as C_
+    from physdock_amd import ops
+    from physdock_amd.packing import pack_glu, split2_f16
+    N_, Cd, hidden = 256, 512, 1408
+    rows = B * N_
+    x = (torch.randn(rows, Cd, generator=g(21)) * torch.exp(0.5 * torch.randn(rows, 1, generator=g(22))) + 0.3).cuda()
+    ngrp = B if per_sample else 1
+    tab = torch.randn(ngrp, 3 * Cd, generator=g(23)).cuda() * 0.5
+    tab[:, Cd:2 * Cd] += 1.0
+    W1 = torch.randn(hidden, Cd, generator=g(24)) / math.sqrt(Cd); W3 = torch.randn(hidden, Cd, generator=g(25)) / math.sqrt(Cd)
+    W13 = pack_glu(W1, W3)[0].cuda()
+    w2g = split2_f16(W13)
+    ymax = torch.tensor([float(tab[:, Cd:2 * Cd].abs().max()) * math.sqrt(Cd) + float(tab[:, :Cd].abs().max())], device="cuda")
+    grp = dict(pro_rows_per_group=N_, pro_gstride=3 * Cd) if per_sample else {}
+    seen = []
+    L = ops._lib.init()
+    ops.GEMM_HOOK = lambda a, launch: (seen.append((bool(a.stats), a.stats_inline, L.pd_gemm_variant(C_.byref(a)))), launch())
+    ops._INLINE_STATS_OK.clear()
+    try:
+        h1 = torch.full((rows, hidden), float("nan"), device="cuda")
+        st = torch.full((rows, 2), float("nan"), device="cuda")
+        ops.gemm(x, W13, h1, rows, 2 * hidden, Cd, stats=st, stats_inline=(ops.LN, 1e-5), pro_b=tab, pro_w=tab.data_ptr() + 4 * Cd,
+                 glu=1, W2=w2g, a_amax=ymax, **grp)
+        a2 = torch.empty(2, rows, Cd, dtype=torch.float16, device="cuda")
+        ops.norm_split2(x, a2, rows, Cd, ymax, mode=ops.LN, eps=1e-5, b=tab, w=tab.data_ptr() + 4 * Cd,
+                        rows_per_group=N_ if per_sample else 0, gstride=3 * Cd if per_sample else 0)
+        h0 = torch.empty(rows, hidden, device="cuda")
+        ops.gemm(x, W13, h0, rows, 2 * hidden, Cd, glu=1, W2=w2g, a_amax=ymax, A2=a2)
+        torch.cuda.synchronize()
+    finally:
+        ops.GEMM_HOOK = None
+        ops._INLINE_STATS_OK.clear()
+    assert seen[0][:2] == (False, 2) and tile_code(seen[0][2]) == 5 and seen[0][2] >= 2000000, seen
+    assert torch.isnan(st).all() and seen[1][2] >= 2000000 and tile_code(seen[1][2]) == 0
+    xd = x.double()
+    xn = xd - xd.mean(-1, keepdim=True)
+    xn = xn * torch.rsqrt(xn.pow(2).mean(-1, keepdim=True) + 1e-5)
+    t = tab.double()
+    xn = (xn.reshape(B, N_, Cd) * t[:, None, Cd:2 * Cd] + t[:, None, :Cd]).reshape(rows, Cd) if per_sample else xn * t[:, Cd:2 * Cd] + t[:, :Cd]
+    a_, b_ = xn @ W1.double().cuda().t(), xn @ W3.double().cuda().t()
+    ref = torch.nn.functional.silu(a_) * b_
+    e1, e0 = float((h1.double() - ref).abs().max()), float((h0.double() - ref).abs().max())
+    print(f"wide-rows SwiGLU per_sample={per_sample} B={B}: max error vs float64 {e1:.2e} (norm_split2 + tile kernel {e0:.2e})")
+    assert e1 <= 1.5 * e0 + 1e-6 and e1 <= 2e-4
+    torch.testing.assert_close(h1, h0, atol=1e-4, rtol=3e-5)
