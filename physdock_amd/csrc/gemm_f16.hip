@@ -745,7 +745,7 @@ int dispatch_f16_wrows(int op, int pro, int epi, const pd_gemm_args* p, hipStrea
 }
 
 #ifndef PD_F16_WROWS_MIN_TILES
-#define PD_F16_WROWS_MIN_TILES 256     // 64-row tiles: one block per CU and round
+#define PD_F16_WROWS_MIN_TILES 128     // 64-row tiles, one block per CU: from half the chip on (32 samples of 256 tokens: 72 -> 66 us + the split pass; 48: 105 -> 74; 20: 49 -> 61, stays on the tile kernel)
 #endif
 
 template <int PRO, int EPI, int BM>
