@@ -243,7 +243,7 @@ class LaunchTimer:
                     if tcode in (3, 4):   # K = 128 rows kernel (whole rows in LDS, own statistics): 128- / 64-row tiles
                         name = "gemm_f16_rows_kernel<%d, %d, %d>" % (pro, epi, 128 if tcode == 3 else 64)
                     elif tcode == 5:      # K = 512 wide-rows kernel (64 rows on sixteen waves)
-                        name = "gemm_f16_wrows_kernel<%d, %d, %s>" % (pro, epi, "1, 2" if glu_tile else "2, 1")
+                        name = "gemm_f16_wrows_kernel<%d, %d, %s>" % (3 if a.A2 else pro, epi, "1, 2" if glu_tile else "2, 1")
             nb = max(a.batch, 1)
             n_out = a.N // 2 if a.glu else a.N
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))

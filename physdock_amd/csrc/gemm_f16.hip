@@ -608,7 +608,20 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * BM;
-        {   // ---- prologue: sixteen threads (one DPP row) per row, 16-byte chunks interleaved
+        if constexpr (PRO == 3) {
+            // A arrives pre-split and pre-scaled ([2][M][512] fp16: pd_norm_split2, or the attention kernel's O2): 16-byte copies
+            const int r = tid >> 4, q = tid & 15;
+            const _Float16* a2 = reinterpret_cast<const _Float16*>(p.A2) + (long long)(row0 + r) * KC;
+            f16x8 c[NPARTS][4];
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[part][i] = *reinterpret_cast<const f16x8*>(a2 + (long long)part * p.M * KC + 8 * (q + 16 * i));
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + part * PART + r * WLP + 8 * (q + 16 * i)) = c[part][i];
+        } else {   // ---- prologue: sixteen threads (one DPP row) per row, 16-byte chunks interleaved
             const int r = tid >> 4, q = tid & 15;
             const int m = row0 + r;
             const float* xr = p.A + (long long)m * p.lda;
@@ -674,6 +687,8 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
                 c0[j] = p.bias ? p.bias[n0 + 32 * j] : 0.f;
                 c1[j] = 1.f;
                 if constexpr (EPI == EPI_HN) c1[j] = p.hn_w[((n0 + 32 * j) / p.hn_split) * 32 + l31];
+                if constexpr (EPI == EPI_GATERES)        // one gate row per row group (groups are whole 64-row tiles)
+                    c1[j] = p.mul ? p.mul[(long long)((row0 + 32 * TM * rh) / p.mul_rows_per_group) * p.mul_gstride + n0 + 32 * j] : 1.f;
                 cs[j] = p.w_inv[n0 + 32 * j] * inv_a_s;
             }
             f32x16 acc[TM][TN];
@@ -739,11 +754,16 @@ int dispatch_f16_wrows(int op, int pro, int epi, const pd_gemm_args* p, hipStrea
     if (pro == 2 && epi == EPI_HN) return run_f16_wrows<2, EPI_HN, 2, 1>(op, p, s);
     if (pro == 1 && epi == EPI_PLAIN) return run_f16_wrows<1, EPI_PLAIN, 2, 1>(op, p, s);
     if (pro == 2 && epi == EPI_PLAIN) return run_f16_wrows<2, EPI_PLAIN, 2, 1>(op, p, s);
+    if (pro == 3 && epi == EPI_GATERES) return run_f16_wrows<3, EPI_GATERES, 2, 1>(op, p, s);
+    if (pro == 3 && epi == EPI_PLAIN) return run_f16_wrows<3, EPI_PLAIN, 2, 1>(op, p, s);
     if (pro == 1 && epi == EPI_GLU) return run_f16_wrows<1, EPI_GLU, 1, 2>(op, p, s);
     if (pro == 2 && epi == EPI_GLU) return run_f16_wrows<2, EPI_GLU, 1, 2>(op, p, s);
     return PD_ERR_UNSUPPORTED;
 }
 
+#ifndef PD_F16_WROWS_A2
+#define PD_F16_WROWS_A2 1              // lab: 0 = pre-split A stays on the tile kernel
+#endif
 #ifndef PD_F16_WROWS_MIN_TILES
 #define PD_F16_WROWS_MIN_TILES 128     // 64-row tiles, one block per CU: from half the chip on (32 samples of 256 tokens: 72 -> 66 us + the split pass; 48: 105 -> 74; 20: 49 -> 61, stays on the tile kernel)
 #endif
@@ -888,7 +908,11 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
                           (p.stats_inline == 1 || p.stats_inline == 2) && p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
                           (((uintptr_t)p.pro_w | (uintptr_t)p.pro_b) & 15) == 0 && p.pro_gstride % 4 == 0 &&
                           (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 32 * 1024 * 2 < 0x7fffffffll;
-    if (wrows_ok) {
+    // ... or with A already split (K = 512: linear_o behind the attention kernel's split output), plain / gate + residual epilogue
+    const bool wrows_a2 = PD_F16_WROWS_A2 && p.K == 512 && p.A2 && pro == 3 && p.act == PD_ACT_NONE && p.M / 64 >= PD_F16_WROWS_MIN_TILES && p.M % 64 == 0 &&
+                          (epi == EPI_PLAIN || (epi == EPI_GATERES && (!p.mul || p.mul_rows_per_group % 64 == 0))) &&
+                          (long long)(p.N / 32) * 32 * 1024 * 2 < 0x7fffffffll;
+    if (wrows_ok || wrows_a2) {
         if (init_only == 2) {
             const int r = dispatch_f16_wrows(1, pro, epi, nullptr, nullptr);
             return r == PD_OK ? epi + 0x500 : r;          // tile code 5: the wide-rows kernel

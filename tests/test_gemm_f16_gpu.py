@@ -480,3 +480,42 @@ def test_wide_rows_kernel_of_the_token_swiglu_projection(per_sample, B):
     print(f"wide-rows SwiGLU per_sample={per_sample} B={B}: max error vs float64 {e1:.2e} (norm_split2 + tile kernel {e0:.2e})")
     assert e1 <= 1.5 * e0 + 1e-6 and e1 <= 2e-4
     torch.testing.assert_close(h1, h0, atol=1e-4, rtol=3e-5)
+
+
+@pytest.mark.parametrize("per_sample,B", [(False, 64), (True, 64), (False, 40)])
+def test_wide_rows_kernel_with_presplit_rows_gate_and_residual(per_sample, B):
+    """gemm_f16_wrows_kernel<3, GATERES, 2, 1>: the token linear_o of a DiT block - A arrives as two fp16 parts (the attention kernel's
+    split output), 64 rows per block copied into LDS once, gate x (acc + bias) + residual in place - against float64."""
+    import ctypes as C_
+    from physdock_amd import ops
+    from physdock_amd.packing import split2_f16
+    N_, Cd = 256, 512
+    rows = B * N_
+    o = (torch.randn(rows, Cd, generator=g(31)) * 2).cuda()
+    res = torch.randn(rows, Cd, generator=g(32)).cuda()
+    Wo = (torch.randn(Cd, Cd, generator=g(33)) / math.sqrt(Cd)).cuda()
+    bo = torch.randn(Cd, generator=g(34)).cuda()
+    ngrp = B if per_sample else 1
+    gate = torch.randn(ngrp, 3 * Cd, generator=g(35)).cuda()
+    amax = torch.tensor([float(o.abs().max()) * 1.5], device="cuda")
+    sc = 2.0 ** (14 - math.floor(math.log2(float(amax))))
+    os_ = o * sc
+    hi = os_.half(); lo = (os_ - hi.float()).half()
+    a2 = torch.stack([hi, lo]).contiguous()
+    mgrp = dict(mul_rows_per_group=N_ if per_sample else rows, mul_gstride=3 * Cd if per_sample else 0)
+    seen = []
+    L = ops._lib.init()
+    ops.GEMM_HOOK = lambda a, launch: (seen.append(L.pd_gemm_variant(C_.byref(a))), launch())
+    try:
+        y = res.clone()
+        ops.gemm(o, Wo, y, rows, Cd, Cd, bias=bo, mul=gate.data_ptr() + 8 * Cd, res=y, W2=split2_f16(Wo), a_amax=amax, A2=a2, **mgrp)
+        torch.cuda.synchronize()
+    finally:
+        ops.GEMM_HOOK = None
+    assert seen[0] >= 2000000 and tile_code(seen[0]) == 5, seen
+    gd = gate[:, 2 * Cd:].double()
+    acc = o.double() @ Wo.double().t() + bo.double()
+    ref = res.double() + (acc.reshape(B, N_, Cd) * gd[:, None]).reshape(rows, Cd) if per_sample else res.double() + acc * gd
+    err = float((y.double() - ref).abs().max())
+    print(f"wide-rows linear_o per_sample={per_sample} B={B}: max error vs float64 {err:.2e}")
+    assert err <= 5e-5
