@@ -242,6 +242,8 @@ class LaunchTimer:
                         ("128, 128, 4, 8, true" if a.A2 else "128, 128, 4, 8, false") if glu_tile else "128, 128, 2, 8, true")
                     if tcode in (3, 4):   # K = 128 rows kernel (whole rows in LDS, own statistics): 128- / 64-row tiles
                         name = "gemm_f16_rows_kernel<%d, %d, %d>" % (pro, epi, 128 if tcode == 3 else 64)
+                    elif tcode == 6:      # N = 512, long K: one accumulator tile per wave, K in double-buffered chunks
+                        name = "gemm_f16_wchunk_kernel<%d>" % epi
                     elif tcode == 5:      # K = 512 wide-rows kernel (64 rows on sixteen waves)
                         name = "gemm_f16_wrows_kernel<%d, %d, %s>" % (3 if a.A2 else pro, epi, "1, 2" if glu_tile else "2, 1")
             nb = max(a.batch, 1)

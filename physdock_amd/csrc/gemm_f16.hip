@@ -761,6 +761,133 @@ int dispatch_f16_wrows(int op, int pro, int epi, const pd_gemm_args* p, hipStrea
     return PD_ERR_UNSUPPORTED;
 }
 
+
+// ---- "wide rows, chunked K" kernel: N = 512, K > 512 (the token-level down-projection w2 of a DiT block, K = 1408,
+// feed_forward.py:30-31 behind transitions.py:27-30).  A row of K values does not fit LDS, but N / 32 = 16 column blocks are exactly
+// the sixteen waves of a block: every wave keeps ONE 64 x 32 accumulator tile for the whole launch and the block walks K in chunks
+// of 256 - scaled, split and staged ONCE per 64 rows (the 128 x 128 tile kernel does that once per column tile: four times, with
+// a barrier every 32 k), double-buffered in LDS with one block barrier per chunk (96 MFMAs per wave).
+constexpr int CLP = 264;                 // LDS row pitch in fp16 of a 256-k chunk (528 bytes = 33 x 16)
+constexpr int WCHUNK_LDS_BYTES = 2 * 2 * 64 * CLP * 2;
+
+template <int EPI>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gemm_f16_wchunk_kernel(const pd_gemm_args p) {
+    constexpr int BM = 64, KCH = 256, TM = 2, TN = 1, PART = BM * CLP, BUF = NPARTS * PART, PF = 3, GK = PF + 1;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float a_s = pd_pow2_scale(*p.a_amax);
+    const float inv_a_s = 1.0f / a_s;
+    const int ntiles = p.M / BM;
+    const int nks = p.K >> 4;                                        // 16-k steps (K % 64 == 0: whole groups of four)
+    const int nch = (p.K + KCH - 1) / KCH;
+    const int wpart = (p.N >> 5) * nks * 1024;                       // bytes per part of the fragment-major weights
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W2), 0, 2 * wpart, 0x00020000);
+    const int loff = lane * 16;
+    const int sr = tid >> 4, sq = tid & 15;                          // staging: row, 16-byte chunk phase
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * BM;
+        const float* xr = p.A + (long long)(row0 + sr) * p.lda;
+        f32x4 ra[4];
+        auto gload = [&](int c) {                                    // chunk c of the thread's row: columns 256 c + 4 (sq + 16 i)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = KCH * c + 4 * (sq + 16 * i);
+                ra[i] = col < p.K ? *reinterpret_cast<const f32x4*>(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto sstore = [&](int buf) {
+            _Float16* base = lds + buf * BUF + sr * CLP;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = 4 * (sq + 16 * i);
+                const pd_parts2 p0 = pd_split2h(ra[i][0] * a_s, ra[i][1] * a_s), p1 = pd_split2h(ra[i][2] * a_s, ra[i][3] * a_s);
+                *reinterpret_cast<u32x2*>(base + c) = u32x2{p0.h, p1.h};
+                *reinterpret_cast<u32x2*>(base + PART + c) = u32x2{p0.l, p1.l};
+            }
+        };
+        f16x8 wf[GK][NPARTS];
+        auto wload = [&](int buf, int ks) {                           // this wave's column block = its index
+            const int so = (wave * nks + ks) * 1024;
+            wf[buf][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so, 0));
+            wf[buf][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so + wpart, 0));
+        };
+        gload(0);
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) wload(ks, ks);
+        const int n0 = wave * 32 + l31;
+        float c0[TN], c1[TN];
+        c0[0] = p.bias ? p.bias[n0] : 0.f;
+        c1[0] = 1.f;
+        if constexpr (EPI == EPI_GATERES) c1[0] = p.mul ? p.mul[(long long)(row0 / p.mul_rows_per_group) * p.mul_gstride + n0] : 1.f;
+        const float cs = p.w_inv[n0] * inv_a_s;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        sstore(0);
+        lds_barrier();
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            gload(c + 1);                                            // the next chunk travels under this one's MFMAs (columns >= K: zeros, not stored)
+            __builtin_amdgcn_sched_barrier(0);
+            const _Float16* abase = lds + (c & 1) * BUF + l31 * CLP + 8 * hh;
+            const int ng = (c + 1 < nch ? KCH / 16 : nks - c * (KCH / 16)) / GK;      // groups of four 16-k steps in this chunk
+#pragma unroll 1
+            for (int gi = 0; gi < ng; ++gi) {
+                const int ksl = gi * GK, ksg = c * (KCH / 16) + ksl;                  // k-step inside the chunk / of the launch
+#pragma unroll
+                for (int jj = 0; jj < GK; ++jj) {
+                    wload((jj + PF) % GK, ksg + jj + PF);      // (beyond the last k-step: another block's fragment or, past the range, zeros - never used; no run-time condition around a request)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 32 * i * CLP + 16 * (ksl + jj));
+                        const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART + 32 * i * CLP + 16 * (ksl + jj));
+                        f32x16 t = acc[i][0];
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[jj][1], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[jj][0], t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[jj][0], t, 0, 0, 0);
+                        acc[i][0] = t;
+                    }
+                }
+            }
+            if (c + 1 < nch) sstore((c + 1) & 1);                    // (that buffer was last read in chunk c - 1: every wave is past its barrier)
+            lds_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] *= cs;
+        epilogue<EPI, TM, TN>(p, acc, c0, c1, row0, wave * 32, 0, 0, l31, hh);
+    }
+}
+
+template <int EPI>
+int run_f16_wchunk(int op, const pd_gemm_args* p, hipStream_t s) {
+    auto k = gemm_f16_wchunk_kernel<EPI>;
+    if (op == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WCHUNK_LDS_BYTES) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    const int ntiles = p->M / 64;
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(1024), WCHUNK_LDS_BYTES, s, *p);
+    return pd_check_launch();
+}
+
+int dispatch_f16_wchunk(int op, int epi, const pd_gemm_args* p, hipStream_t s) {
+    if (epi == EPI_GATERES) return run_f16_wchunk<EPI_GATERES>(op, p, s);
+    if (epi == EPI_PLAIN) return run_f16_wchunk<EPI_PLAIN>(op, p, s);
+    return PD_ERR_UNSUPPORTED;
+}
+
+#ifndef PD_F16_WCHUNK
+#define PD_F16_WCHUNK 1                // lab: 0 = those launches stay on the tile kernel
+#endif
+
 #ifndef PD_F16_WROWS_A2
 #define PD_F16_WROWS_A2 1              // lab: 0 = pre-split A stays on the tile kernel
 #endif
@@ -858,6 +985,8 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
                 if (r != PD_OK && r != PD_ERR_UNSUPPORTED) rc = r;
                 const int rw = dispatch_f16_wrows(1, P, E, nullptr, nullptr);
                 if (rw != PD_OK && rw != PD_ERR_UNSUPPORTED) rc = rw;
+                const int rc2 = P == 0 ? dispatch_f16_wchunk(1, E, nullptr, nullptr) : PD_ERR_UNSUPPORTED;
+                if (rc2 != PD_OK && rc2 != PD_ERR_UNSUPPORTED) rc = rc2;
             }
         return rc;
     }
@@ -912,6 +1041,19 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
     const bool wrows_a2 = PD_F16_WROWS_A2 && p.K == 512 && p.A2 && pro == 3 && p.act == PD_ACT_NONE && p.M / 64 >= PD_F16_WROWS_MIN_TILES && p.M % 64 == 0 &&
                           (epi == EPI_PLAIN || (epi == EPI_GATERES && (!p.mul || p.mul_rows_per_group % 64 == 0))) &&
                           (long long)(p.N / 32) * 32 * 1024 * 2 < 0x7fffffffll;
+    // N = 512 with a long K and fp32 rows (the token w2): one accumulator tile per wave, K in double-buffered chunks
+    const bool wchunk_ok = PD_F16_WCHUNK && p.N == 512 && p.K > 512 && p.K % 64 == 0 && !p.A2 && !p.stats && !p.stats_inline && pro == 0 &&
+                           p.pro_act == PD_ACT_NONE && p.act == PD_ACT_NONE && p.M % 64 == 0 && p.M / 64 >= PD_F16_WROWS_MIN_TILES &&
+                           p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
+                           (epi == EPI_PLAIN || (epi == EPI_GATERES && (!p.mul || p.mul_rows_per_group % 64 == 0))) &&
+                           (long long)16 * (p.K / 16) * 1024 * 2 < 0x7fffffffll;
+    if (wchunk_ok) {
+        if (init_only == 2) {
+            const int r = dispatch_f16_wchunk(1, epi, nullptr, nullptr);
+            return r == PD_OK ? epi + 0x600 : r;          // tile code 6: the chunked wide-rows kernel
+        }
+        return dispatch_f16_wchunk(0, epi, &p, (hipStream_t)stream);
+    }
     if (wrows_ok || wrows_a2) {
         if (init_only == 2) {
             const int r = dispatch_f16_wrows(1, pro, epi, nullptr, nullptr);

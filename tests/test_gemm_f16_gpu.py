@@ -519,3 +519,37 @@ def test_wide_rows_kernel_with_presplit_rows_gate_and_residual(per_sample, B):
     err = float((y.double() - ref).abs().max())
     print(f"wide-rows linear_o per_sample={per_sample} B={B}: max error vs float64 {err:.2e}")
     assert err <= 5e-5
+
+
+@pytest.mark.parametrize("per_sample,B,K", [(False, 64, 1408), (True, 64, 1408), (False, 40, 1408), (False, 64, 576)])
+def test_chunked_wide_rows_kernel_of_the_token_down_projection(per_sample, B, K):
+    """gemm_f16_wchunk_kernel<GATERES>: N = 512, K > 512 (the token w2 of a DiT block): one accumulator tile per wave, the fp32 rows
+    scaled / split / staged once per 64 rows in double-buffered chunks of 256 k - against float64 (incl. a K that ends mid-chunk)."""
+    import ctypes as C_
+    from physdock_amd import ops
+    from physdock_amd.packing import split2_f16
+    N_, Cd = 256, 512
+    rows = B * N_
+    h = (torch.randn(rows, K, generator=g(41)) * torch.exp(0.5 * torch.randn(rows, 1, generator=g(42)))).cuda()
+    res = torch.randn(rows, Cd, generator=g(43)).cuda()
+    W2_ = (torch.randn(Cd, K, generator=g(44)) / math.sqrt(K)).cuda()
+    ngrp = B if per_sample else 1
+    gate = torch.randn(ngrp, 3 * Cd, generator=g(45)).cuda()
+    amax = torch.tensor([float(h.abs().max()) * 3], device="cuda")
+    mgrp = dict(mul_rows_per_group=N_ if per_sample else rows, mul_gstride=3 * Cd if per_sample else 0)
+    seen = []
+    L = ops._lib.init()
+    ops.GEMM_HOOK = lambda a, launch: (seen.append(L.pd_gemm_variant(C_.byref(a))), launch())
+    try:
+        y = res.clone()
+        ops.gemm(h, W2_, y, rows, Cd, K, mul=gate.data_ptr() + 8 * Cd, res=y, W2=split2_f16(W2_), a_amax=amax, **mgrp)
+        torch.cuda.synchronize()
+    finally:
+        ops.GEMM_HOOK = None
+    assert seen[0] >= 2000000 and tile_code(seen[0]) == 6, seen
+    gd = gate[:, 2 * Cd:].double()
+    acc = h.double() @ W2_.double().t()
+    ref = res.double() + (acc.reshape(B, N_, Cd) * gd[:, None]).reshape(rows, Cd) if per_sample else res.double() + acc * gd
+    err = float((y.double() - ref).abs().max())
+    print(f"chunked wide-rows w2 per_sample={per_sample} B={B} K={K}: max error vs float64 {err:.2e}")
+    assert err <= 1e-4
