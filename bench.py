@@ -245,7 +245,8 @@ class LaunchTimer:
                     elif tcode == 6:      # N = 512, long K: one accumulator tile per wave, K in double-buffered chunks
                         name = "gemm_f16_wchunk_kernel<%d>" % epi
                     elif tcode == 5:      # K = 512 wide-rows kernel (64 rows on sixteen waves)
-                        name = "gemm_f16_wrows_kernel<%d, %d, %s>" % (3 if a.A2 else pro, epi, "1, 2" if glu_tile else "2, 1")
+                        name = "gemm_f16_wrows_kernel<%d, %d, %s>" % (3 if a.A2 else pro, epi, "2, 2, 2, 16" if glu_tile else
+                                                                       "2, 1, 4, 16")
             nb = max(a.batch, 1)
             n_out = a.N // 2 if a.glu else a.N
             byt = 4.0 * nb * (a.M * a.K + a.N * a.K + a.M * n_out * (1 + bool(a.res) + (bool(a.mul) and a.mul_rows_per_group == 0)))

@@ -584,13 +584,14 @@ void gemm_f16_rows_kernel(const pd_gemm_args p) {
 constexpr int WLP = 520;                 // LDS row pitch in fp16 (1040 bytes = 65 x 16: conflict-free ds_read_b128 fragments)
 constexpr int WROWS_LDS_BYTES = 2 * 64 * WLP * 2;
 
-// Wave tile: 64 rows x 32 columns (TM = 2, TN = 1: a W fragment feeds two row blocks) for the plain / head-norm epilogues; 32 rows x
-// 64 packed columns (TM = 1, TN = 2: a GLU pair needs both of its columns in one wave; two waves then stream the same W block, as
-// in the 128 x 128 GLU tile) for the SwiGLU up-projection.  Work items (row group, column unit) are dealt to the waves round-robin.
-template <int PRO, int EPI, int TM, int TN>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// Wave tile: 64 rows x 32 columns (TM = 2, TN = 1) for the plain / head-norm epilogues, 64 x 64 packed columns (TM = 2, TN = 2: a GLU
+// pair needs both of its columns in one wave) for the SwiGLU up-projection.  Work items (row group, column unit) are dealt to the
+// waves round-robin; GK = depth of the W fragment ring.
+template <int PRO, int EPI, int TM, int TN, int GK = 4, int NWV = 16>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(NWV / 4, 4)))
 void gemm_f16_wrows_kernel(const pd_gemm_args p) {
-    constexpr int BM = 64, KC = 512, PART = BM * WLP, NKS = KC / 16, PF = 3, NWV = 16, RG = 2 / TM;
+    constexpr int BM = 64, KC = 512, PART = BM * WLP, NKS = KC / 16, PF = GK - 1, RG = 2 / TM;
+    constexpr int RPP = 4 * NWV;                   // rows per prologue pass (sixteen threads per row)
     static_assert(NKS % (PF + 1) == 0, "the fragment ring must be back at buffer 0 when a work item ends");
     static_assert(TM * RG == 2 && NWV % RG == 0, "a wave keeps its row group");
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
@@ -610,7 +611,9 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
         const int row0 = tile * BM;
         if constexpr (PRO == 3) {
             // A arrives pre-split and pre-scaled ([2][M][512] fp16: pd_norm_split2, or the attention kernel's O2): 16-byte copies
-            const int r = tid >> 4, q = tid & 15;
+            const int q = tid & 15;
+#pragma unroll 1
+            for (int r = tid >> 4; r < BM; r += RPP) {
             const _Float16* a2 = reinterpret_cast<const _Float16*>(p.A2) + (long long)(row0 + r) * KC;
             f16x8 c[NPARTS][4];
 #pragma unroll
@@ -621,8 +624,11 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
             for (int part = 0; part < NPARTS; ++part)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + part * PART + r * WLP + 8 * (q + 16 * i)) = c[part][i];
-        } else {   // ---- prologue: sixteen threads (one DPP row) per row, 16-byte chunks interleaved
-            const int r = tid >> 4, q = tid & 15;
+            }
+        } else {   // ---- prologue: sixteen threads (one DPP row) per row, 16-byte chunks interleaved; 4 NWV rows per pass
+            const int q = tid & 15;
+#pragma unroll 1
+            for (int r = tid >> 4; r < BM; r += RPP) {
             const int m = row0 + r;
             const float* xr = p.A + (long long)m * p.lda;
             const int goff = PRO == 2 ? (m / p.pro_rows_per_group) * p.pro_gstride : 0;
@@ -660,6 +666,7 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
                 const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]);
                 *reinterpret_cast<u32x2*>(lds + r * WLP + c) = u32x2{p0.h, p1.h};
                 *reinterpret_cast<u32x2*>(lds + PART + r * WLP + c) = u32x2{p0.l, p1.l};
+            }
             }
         }
         lds_barrier();
@@ -738,26 +745,46 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
     }
 }
 
-template <int PRO, int EPI, int TM, int TN>
+template <int PRO, int EPI, int TM, int TN, int GK = 4, int NWV = 16>
 int run_f16_wrows(int op, const pd_gemm_args* p, hipStream_t s) {
-    auto k = gemm_f16_wrows_kernel<PRO, EPI, TM, TN>;
+    auto k = gemm_f16_wrows_kernel<PRO, EPI, TM, TN, GK, NWV>;
     if (op == 1)
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WROWS_LDS_BYTES) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
     const int ntiles = p->M / 64;
-    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(1024), WROWS_LDS_BYTES, s, *p);
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(64 * NWV), WROWS_LDS_BYTES, s, *p);
     return pd_check_launch();
 }
 
 int dispatch_f16_wrows(int op, int pro, int epi, const pd_gemm_args* p, hipStream_t s) {
+#ifdef PD_F16_WROWS_12
+    // lab: head-norm / plain epilogues with N a multiple of 768 (q | k | v: 1536 = 24 units of 64 columns) on TWELVE waves (three per
+    // SIMD) x two 64 x 64 units each.  Measured 88.9 - 91.9 us against 92.6 - 94.9 us for sixteen waves x three 64 x 32 items, bench
+    // unchanged: what the larger unit gains per wave (+ 25 % MFMA throughput) the fourth wave per SIMD gave anyway.  Off.
+    if ((pro == 1 || pro == 2) && (epi == EPI_HN || epi == EPI_PLAIN) && (op == 1 || p->N % 768 == 0)) {
+        int r = PD_ERR_UNSUPPORTED;
+        if (pro == 1 && epi == EPI_HN) r = run_f16_wrows<1, EPI_HN, 2, 2, 2, 12>(op, p, s);
+        if (pro == 2 && epi == EPI_HN) r = run_f16_wrows<2, EPI_HN, 2, 2, 2, 12>(op, p, s);
+        if (pro == 1 && epi == EPI_PLAIN) r = run_f16_wrows<1, EPI_PLAIN, 2, 2, 2, 12>(op, p, s);
+        if (pro == 2 && epi == EPI_PLAIN) r = run_f16_wrows<2, EPI_PLAIN, 2, 2, 2, 12>(op, p, s);
+        if (op != 1 || r != PD_OK) return r;
+    }
+#endif
     if (pro == 1 && epi == EPI_HN) return run_f16_wrows<1, EPI_HN, 2, 1>(op, p, s);
     if (pro == 2 && epi == EPI_HN) return run_f16_wrows<2, EPI_HN, 2, 1>(op, p, s);
     if (pro == 1 && epi == EPI_PLAIN) return run_f16_wrows<1, EPI_PLAIN, 2, 1>(op, p, s);
     if (pro == 2 && epi == EPI_PLAIN) return run_f16_wrows<2, EPI_PLAIN, 2, 1>(op, p, s);
     if (pro == 3 && epi == EPI_GATERES) return run_f16_wrows<3, EPI_GATERES, 2, 1>(op, p, s);
     if (pro == 3 && epi == EPI_PLAIN) return run_f16_wrows<3, EPI_PLAIN, 2, 1>(op, p, s);
+#ifdef PD_F16_WROWS_GLU12      // lab: 32 x 64 wave tiles, four-deep fragment ring (163 vs 128 us at 64 samples)
     if (pro == 1 && epi == EPI_GLU) return run_f16_wrows<1, EPI_GLU, 1, 2>(op, p, s);
     if (pro == 2 && epi == EPI_GLU) return run_f16_wrows<2, EPI_GLU, 1, 2>(op, p, s);
+#endif
+    // SwiGLU: 64 x 64 wave tiles (a W fragment pair feeds two row blocks, an A fragment two column blocks: 24 MFMAs per 16-k step
+    // and wave), two-deep fragment ring (64 accumulator registers leave room for no more; four waves per SIMD cover the L2 latency)
+    if (pro == 1 && epi == EPI_GLU) return run_f16_wrows<1, EPI_GLU, 2, 2, 2>(op, p, s);
+    if (pro == 2 && epi == EPI_GLU) return run_f16_wrows<2, EPI_GLU, 2, 2, 2>(op, p, s);
+
     return PD_ERR_UNSUPPORTED;
 }
 
