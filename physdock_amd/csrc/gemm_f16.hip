@@ -607,7 +607,12 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
     const int loff = lane * 16;
     const int rh = wave % RG;                                        // this wave's row group (32 TM rows)
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Launches with fewer row tiles than CUs: nsplit blocks share a row tile - each stages the rows (the norm is cheap) and takes its
+    // share of the column units - so that 80 tiles (20 samples) still put 240 blocks on the chip.  The launcher's grid says so.
+    const int nsplit = (int)gridDim.x > ntiles ? (int)gridDim.x / ntiles : 1;
+    for (int work = blockIdx.x; work < ntiles * nsplit; work += gridDim.x) {
+        const int tile = work / nsplit, part = work - tile * nsplit;
+        const int item0 = part * nitems / nsplit, item1 = (part + 1) * nitems / nsplit;
         const int row0 = tile * BM;
         if constexpr (PRO == 3) {
             // A arrives pre-split and pre-scaled ([2][M][512] fp16: pd_norm_split2, or the attention kernel's O2): 16-byte copies
@@ -680,12 +685,12 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
                 wf[buf][j][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so + wpart, 0));
             }
         };
-        if (wave < nitems) {
+        if (item0 + wave < item1) {
 #pragma unroll
-            for (int ks = 0; ks < PF; ++ks) wload(wave / RG, ks, ks);
+            for (int ks = 0; ks < PF; ++ks) wload((item0 + wave) / RG, ks, ks);
         }
 #pragma unroll 1
-        for (int item = wave; item < nitems; item += NWV) {
+        for (int item = item0 + wave; item < item1; item += NWV) {
             const int cu = item / RG;
             const int n0 = cu * (32 * TN) + l31;
             float c0[TN], c1[TN], cs[TN];
@@ -713,7 +718,7 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
                     const int ks = ks0 + jj;
                     if constexpr (!last) wload(cu, (jj + PF) % (PF + 1), ks + PF);
                     else if (jj == 0) wload(cu, PF % (PF + 1), ks + PF);              // ks0 + PF = NKS - 1: still this item
-                    else if (item + NWV < nitems) wload((item + NWV) / RG, (jj + PF) % (PF + 1), jj - 1);
+                    else if (item + NWV < item1) wload((item + NWV) / RG, (jj + PF) % (PF + 1), jj - 1);
                     __builtin_amdgcn_sched_barrier(0);          // keeps the fragment reads of later steps where they are (registers)
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
@@ -752,7 +757,12 @@ int run_f16_wrows(int op, const pd_gemm_args* p, hipStream_t s) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WROWS_LDS_BYTES) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
     const int ntiles = p->M / 64;
-    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(64 * NWV), WROWS_LDS_BYTES, s, *p);
+    // fewer row tiles than CUs: up to four blocks share a tile's columns (norm-prologue forms: re-staging the rows is cheap)
+    const int nitems = (2 / TM) * ((p->N >> 5) / TN);
+    int nsplit = (PRO != 3 && ntiles < 256) ? 256 / ntiles : 1;
+    nsplit = nsplit > 4 ? 4 : nsplit;
+    while (nsplit > 1 && nitems / nsplit < 8) --nsplit;
+    hipLaunchKernelGGL(k, dim3((unsigned)(nsplit > 1 ? ntiles * nsplit : (ntiles < 256 ? ntiles : 256))), dim3(64 * NWV), WROWS_LDS_BYTES, s, *p);
     return pd_check_launch();
 }
 
@@ -918,6 +928,9 @@ int dispatch_f16_wchunk(int op, int epi, const pd_gemm_args* p, hipStream_t s) {
 #ifndef PD_F16_WROWS_A2
 #define PD_F16_WROWS_A2 1              // lab: 0 = pre-split A stays on the tile kernel
 #endif
+#ifndef PD_F16_WROWS_MIN_TILES_SPLIT
+#define PD_F16_WROWS_MIN_TILES_SPLIT 32   // norm-prologue forms (blocks may share a row tile): from 8 samples of 256 tokens on
+#endif
 #ifndef PD_F16_WROWS_MIN_TILES
 #define PD_F16_WROWS_MIN_TILES 128     // 64-row tiles, one block per CU: from half the chip on (32 samples of 256 tokens: 72 -> 66 us + the split pass; 48: 105 -> 74; 20: 49 -> 61, stays on the tile kernel)
 #endif
@@ -1060,7 +1073,7 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
                          (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 8 * 1024 * 2 < 0x7fffffffll;
     // K = 512: the wide-rows kernel (64-row tiles on sixteen waves; only with inline statistics: callers that pre-split A keep that path)
     const bool wrows_ok = p.K == 512 && !p.A2 && !p.stats && (pro == 1 || pro == 2) && p.pro_act == PD_ACT_NONE && p.act == PD_ACT_NONE &&
-                          p.M / 64 >= PD_F16_WROWS_MIN_TILES && (epi == EPI_HN || epi == EPI_PLAIN || (epi == EPI_GLU && p.N % 64 == 0)) &&
+                          p.M % 64 == 0 && p.M / 64 >= PD_F16_WROWS_MIN_TILES_SPLIT && (epi == EPI_HN || epi == EPI_PLAIN || (epi == EPI_GLU && p.N % 64 == 0)) &&
                           (p.stats_inline == 1 || p.stats_inline == 2) && p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
                           (((uintptr_t)p.pro_w | (uintptr_t)p.pro_b) & 15) == 0 && p.pro_gstride % 4 == 0 &&
                           (pro != 2 || p.pro_rows_per_group > 0) && (long long)(p.N / 32) * 32 * 1024 * 2 < 0x7fffffffll;
