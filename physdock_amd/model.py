@@ -133,10 +133,14 @@ class PhysDock(nn.Module):
         b = dict(batch)
         A, T = b["ref_pos"].shape[0], b["target_feat"].shape[0]
         b["_A_real"], b["_T_real"] = A, T
-        pa = (-A) % 4
+        # atoms: to a multiple of 64 for systems of DiT size - sample-major [B * A, C] activations then consist of whole 64-row tiles for
+        # every sample count, which is what the fp16-format rows / tile kernels and the fused transition take (a ragged 1 803-atom system
+        # at 20 samples ran 65 % slower than the LARGER 2 048-atom crop through row-remainder launches); <= 3 % more (masked) rows
+        pa = (-A) % (64 if A >= 512 else 4)
         pt = (-T) % 4
-        if pa and not pt:
-            pt = 4                      # padded atoms need a padded token to belong to
+        # (padded atoms belong to no token segment - token_id_to_chunk_sizes, hence _tok_start, covers the real atoms only, so the pooling
+        #  kernels never see them - and point at token 0 where an index is needed; adding a padded TOKEN for them, as this did, turned a
+        #  256-token system into 260 tokens: sample-major token rows with a remainder in every projection)
         if pa or pt:
             import torch.nn.functional as F
             dev = b["ref_pos"].device
@@ -155,11 +159,9 @@ class PhysDock(nn.Module):
             b["ref_space_uid"] = torch.cat([b["ref_space_uid"], b["ref_space_uid"].max() + 1 +
                                             torch.arange(pa, device=dev, dtype=b["ref_space_uid"].dtype)])
             b["atom_id_to_token_id"] = torch.cat([b["atom_id_to_token_id"],
-                                                  torch.full((pa,), T, device=dev, dtype=b["atom_id_to_token_id"].dtype)])
-            chunk_pad = torch.zeros(pt, device=dev, dtype=b["token_id_to_chunk_sizes"].dtype)
-            if pt:
-                chunk_pad[0] = pa
-            b["token_id_to_chunk_sizes"] = torch.cat([b["token_id_to_chunk_sizes"], chunk_pad])
+                                                  torch.zeros(pa, device=dev, dtype=b["atom_id_to_token_id"].dtype)])
+            b["token_id_to_chunk_sizes"] = torch.cat([b["token_id_to_chunk_sizes"],
+                                                      torch.zeros(pt, device=dev, dtype=b["token_id_to_chunk_sizes"].dtype)])
             for k in ("target_feat", "key_res_feat", "pocket_res_feat", "is_ligand"):
                 pad(k, {0: pt})
             for k in ("token_bonds_feature", "rel_tok_feat", "templ_feat", "z_mask"):
@@ -289,6 +291,9 @@ class PhysDock(nn.Module):
         for k in ("a_mask", "atom_id_to_token_id", "_tok_start", "ref_pos"):
             batch[k] = staged(k, batch[k])
         lig_flag = batch["is_ligand"][batch["atom_id_to_token_id"]]          # index gather on metadata, once per call
+        if A_real < A:
+            lig_flag = lig_flag.clone()
+            lig_flag[A_real:] = 0                                            # padded atoms carry a placeholder token index
         lig_w = ws.get("lig_w", A)
         lig_w.copy_(batch["a_mask"] * lig_flag)
         any_align = any(p["align"] for p in plan)
