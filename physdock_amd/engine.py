@@ -570,11 +570,13 @@ class Engine:
         return {"atom_bias": fa, "token_bias": ft, "tab_atom": tab_a, "tab_token": tab_t, "bnd_atom": bnd["atom"],
                 "bnd_token": bnd["token"], "ps_atom": ps_a, "ps_token": ps_t, "B": B}
 
-    def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample, nk, bnd=None, bias_prescale=0.0):
+    def dit_block(self, prefix, x, B, N, C, bias, tab, tab_off, tab_ld, per_sample, nk, bnd=None, bias_prescale=0.0, rows_alloc=0):
         """DiTBlock (transformers.py:155-159; attentions.py:241-265; transitions.py:27-30).
-        tab: AdaLN table row(s) [shift | 1+scale | gate] x (attention, transition) for this block."""
+        tab: AdaLN table row(s) [shift | 1+scale | gate] x (attention, transition) for this block.
+        rows_alloc: rows x is allocated with (>= B N, see af3_dit): every row-wise launch of the block then covers that many rows -
+        whole 64-row tiles - and the rows past B N hold garbage nobody reads (the attention addresses rows by (sample, position))."""
         P, eps = self.P, self.eps
-        rows = B * N
+        rows = rows_alloc or B * N
         H = C // 32
         grp = dict(pro_rows_per_group=N, pro_gstride=tab_ld) if per_sample else {}
         mgrp = dict(mul_rows_per_group=N if per_sample else rows, mul_gstride=tab_ld if per_sample else 0)
@@ -632,7 +634,8 @@ class Engine:
             self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=self.stats_buf(rows), stats_inline=(LN, eps),
                       pro_b=off(tab, tab_off), pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
-        o_split = unsplit_f16 and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C \
+        # (the attention kernel lays its split output out as [2][B N][C]: it is the projection's A2 only when no padding rows follow)
+        o_split = unsplit_f16 and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C and rows == B * N \
             and ops.presplit_supported(rows, C, C, f16=True, gate=True, per_group_rows=N if per_sample else 0, gstride=tab_ld if per_sample else 0)
         if o_split:
             o2 = self.lws("dit_o2", 2, rows, C, dtype=torch.float16)
@@ -670,7 +673,13 @@ class Engine:
         Ha, Hs = Ca // 32, Cs // 32
         L = ops._lib.init()
         sp = ops.stream()
-        ba = self.lws("dit_ba", B * A, Ca)
+        # Sample-major activations [B N, C] are allocated - and run through every row-wise launch - in whole 64-row tiles: a ragged
+        # system (T = 227 -> 228 tokens at 20 samples = 4 560 rows) otherwise leaves every projection a row remainder, and the remainder
+        # launches (<= 63 rows on the general kernel, 22 - 50 us each) cost more than the projections themselves.  Rows past B N are
+        # never initialised and never read by anything that mixes rows (attention / pooling address rows by (sample, position)).
+        RA = B * A if per_sample else -(-(B * A) // 64) * 64
+        RT = B * T if per_sample else -(-(B * T) // 64) * 64
+        ba = self.lws("dit_ba", RA, Ca)
         cin_b = ops.ptr(scal["c_in"]) if per_sample else None
         ops.check(L.pd_precond(ops.ptr(x_hat), 0.0 if per_sample else scal["c_in"], cin_b, ops.ptr(P["dit.linear_x.weight"]),
                                ops.ptr(P["dit.linear_x.bias"]), ops.ptr(a), ops.ptr(ba), B, A, Ca, sp), "precond")
@@ -685,21 +694,23 @@ class Engine:
         psa, pst = prep["ps_atom"], prep["ps_token"]
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_encoder.blocks.{b}", ba, B, A, Ca, off(prep["atom_bias"], b * fa_stride),
-                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + b) * 8), bias_prescale=psa)
-        u = self.lws("dit_u", B * A, Cs)
-        self.lin(ba, "dit.linear_downscale", B * A, out=u, act=ACT_SILU)
-        bs = self.lws("dit_bs", B * T, Cs)
+                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + b) * 8), bias_prescale=psa,
+                           rows_alloc=RA)
+        u = self.lws("dit_u", RA, Cs)
+        self.lin(ba, "dit.linear_downscale", RA, out=u, act=ACT_SILU)
+        bs = self.lws("dit_bs", RT, Cs)
         ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs), B, A, T, Cs, sp), "pool")
         for b in range(nb_t):
             self.dit_block(f"dit.token_dit.blocks.{b}", bs, B, T, Cs, off(prep["token_bias"], b * ft_stride),
-                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr, bnd=off(bnd_t, (row * nb_t + b) * 8), bias_prescale=pst)
-        us = self.lws("dit_us", B * T, Ca)
-        self.lin(bs, "dit.linear_upscale", B * T, out=us)
+                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr, bnd=off(bnd_t, (row * nb_t + b) * 8), bias_prescale=pst,
+                           rows_alloc=RT)
+        us = self.lws("dit_us", RT, Ca)
+        self.lin(bs, "dit.linear_upscale", RT, out=us)
         ops.check(L.pd_unpool_add(ops.ptr(ba), ops.ptr(us), ops.ptr(batch["atom_id_to_token_id"]), B, A, T, Ca, sp), "unpool")
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_decoder.blocks.{b}", ba, B, A, Ca,
                            off(prep["atom_bias"], (nb_a + b) * fa_stride), tab_a, row * lda_ + (nb_a + b) * 6 * Ca, lda_,
-                           per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + nb_a + b) * 8), bias_prescale=psa)
+                           per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + nb_a + b) * 8), bias_prescale=psa, rows_alloc=RA)
         cs_b = ops.ptr(scal["c_skip"]) if per_sample else None
         co_b = ops.ptr(scal["c_out"]) if per_sample else None
         ops.check(L.pd_denoise(ops.ptr(ba), ops.ptr(x_hat), ops.ptr(P["dit.norm_r.weight"]), ops.ptr(P["dit.norm_r.bias"]),
