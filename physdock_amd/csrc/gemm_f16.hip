@@ -750,6 +750,13 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
     }
 }
 
+// lab knobs of the column split: most blocks per row tile, fewest work items a block may be left with
+#ifndef PD_F16_WROWS_MAX_SPLIT
+#define PD_F16_WROWS_MAX_SPLIT 4
+#endif
+#ifndef PD_F16_WROWS_MIN_ITEMS
+#define PD_F16_WROWS_MIN_ITEMS 8
+#endif
 template <int PRO, int EPI, int TM, int TN, int GK = 4, int NWV = 16>
 int run_f16_wrows(int op, const pd_gemm_args* p, hipStream_t s) {
     auto k = gemm_f16_wrows_kernel<PRO, EPI, TM, TN, GK, NWV>;
@@ -759,9 +766,13 @@ int run_f16_wrows(int op, const pd_gemm_args* p, hipStream_t s) {
     const int ntiles = p->M / 64;
     // fewer row tiles than CUs: up to four blocks share a tile's columns (norm-prologue forms: re-staging the rows is cheap)
     const int nitems = (2 / TM) * ((p->N >> 5) / TN);
+    // (measured per call at 1 / 2 / 3 / 5 / 8 / 12 samples of 256 tokens: up to 4 blocks with >= 8 items each 89 / 107 / 127 / 136 / 138 /
+    //  143 ms; up to 16 blocks with >= 2 items 89 / 100 / 110 / 113 / 135 / 145 ms: the deep split below 32 row tiles only)
+    const bool few = ntiles < 32;
     int nsplit = (PRO != 3 && ntiles < 256) ? 256 / ntiles : 1;
-    nsplit = nsplit > 4 ? 4 : nsplit;
-    while (nsplit > 1 && nitems / nsplit < 8) --nsplit;
+    const int max_split = few ? 4 * PD_F16_WROWS_MAX_SPLIT : PD_F16_WROWS_MAX_SPLIT;
+    nsplit = nsplit > max_split ? max_split : nsplit;
+    while (nsplit > 1 && nitems / nsplit < (few ? PD_F16_WROWS_MIN_ITEMS / 4 : PD_F16_WROWS_MIN_ITEMS)) --nsplit;
     hipLaunchKernelGGL(k, dim3((unsigned)(nsplit > 1 ? ntiles * nsplit : (ntiles < 256 ? ntiles : 256))), dim3(64 * NWV), WROWS_LDS_BYTES, s, *p);
     return pd_check_launch();
 }
@@ -929,7 +940,7 @@ int dispatch_f16_wchunk(int op, int epi, const pd_gemm_args* p, hipStream_t s) {
 #define PD_F16_WROWS_A2 1              // lab: 0 = pre-split A stays on the tile kernel
 #endif
 #ifndef PD_F16_WROWS_MIN_TILES_SPLIT
-#define PD_F16_WROWS_MIN_TILES_SPLIT 32   // norm-prologue forms (blocks may share a row tile): from 8 samples of 256 tokens on
+#define PD_F16_WROWS_MIN_TILES_SPLIT 4    // norm-prologue forms (blocks may share a row tile): from one sample of 256 tokens on
 #endif
 #ifndef PD_F16_WROWS_MIN_TILES
 #define PD_F16_WROWS_MIN_TILES 128     // 64-row tiles, one block per CU: from half the chip on (32 samples of 256 tokens: 72 -> 66 us + the split pass; 48: 105 -> 74; 20: 49 -> 61, stays on the tile kernel)

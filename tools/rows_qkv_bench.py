@@ -20,7 +20,7 @@ def timeit(fn, n=30, warm=5):
 
 
 Cd, N_ = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (128, 2048)
-for B in (64, 48, 32, 20, 16, 8, 4):
+for B in (64, 48, 32, 20, 16, 8, 5, 4, 2, 1):
     rows = B * N_
     x = torch.randn(rows, Cd, device="cuda")
     tab = torch.randn(1, 3 * Cd, device="cuda") * 0.5
