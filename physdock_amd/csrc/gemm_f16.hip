@@ -939,6 +939,9 @@ int dispatch_f16_wchunk(int op, int epi, const pd_gemm_args* p, hipStream_t s) {
 #ifndef PD_F16_WROWS_A2
 #define PD_F16_WROWS_A2 1              // lab: 0 = pre-split A stays on the tile kernel
 #endif
+#ifndef PD_F16_WROWS_TINY
+#define PD_F16_WROWS_TINY 1             // lab: 0 = launches below the tile kernels' thresholds never reach the wide-rows kernels
+#endif
 #ifndef PD_F16_WROWS_MIN_TILES_SPLIT
 #define PD_F16_WROWS_MIN_TILES_SPLIT 4    // norm-prologue forms (blocks may share a row tile): from one sample of 256 tokens on
 #endif
@@ -1055,7 +1058,9 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
     // 128 x 128 tiles when they fill the chip, else 64 x 128 tiles if there are enough of THOSE; smaller launches are latency-bound
     // (k-split fp32 kernel).  The caller's tile (its 64 x 64 choice below 192 row/column blocks) only says the rows come in 64s.
     const long long t128 = p.M % 128 == 0 ? (long long)(p.M / 128) * (p.N / 128) : 0, t64 = (long long)(p.M / 64) * (p.N / 128);
-    if (t128 < PD_F16_MIN_TILES && t64 < PD_F16_MIN_TILES_SMALL) return PD_ERR_UNSUPPORTED;
+    // (the tile kernels' own threshold; the wide-rows kernels below share a row tile among several blocks and take fewer: PD_F16_TINY)
+    const bool tiny = t128 < PD_F16_MIN_TILES && t64 < PD_F16_MIN_TILES_SMALL;
+    if (tiny && !(PD_F16_WROWS_TINY && p.K == 512 && !p.A2 && !p.stats && p.stats_inline)) return PD_ERR_UNSUPPORTED;
     const bool small = t128 < PD_F16_MIN_TILES;
     if (p.rowscale_acc || (p.rowscale && !glut) || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
@@ -1112,6 +1117,7 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
         }
         return dispatch_f16_wrows(0, pro, epi, &p, (hipStream_t)stream);
     }
+    if (tiny) return PD_ERR_UNSUPPORTED;
     if ((!p.stats && p.stats_inline) || (rows_ok && PD_F16_ROWS_GIVEN_STATS)) {
         const bool big = rows_big;
         if (!rows_ok) return PD_ERR_UNSUPPORTED;
