@@ -69,6 +69,8 @@ def compile_cmd(src, out, mode=("-c",)):
     for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES", "PD_F16_MIN_TILES_SMALL", "PD_F16_ABL", "PD_F16_T256", "PD_F16_T256_BPC", "PD_F16_ROWS_MIN_TILES", "PD_F16_ROWS_MIN_TILES64", "PD_F16_ROWS_NO_XPF", "PD_F16_ROWS_GIVEN_STATS", "PD_F16_WROWS_MIN_TILES", "PD_F16_WROWS_MIN_TILES_SPLIT", "PD_F16_WROWS_MAX_SPLIT", "PD_F16_WROWS_TINY", "PD_F16_WROWS_MIN_ITEMS", "PD_F16_WROWS_A2", "PD_F16_WCHUNK", "PD_F16_WROWS_GLU12", "PD_F16_WROWS_12"):
         if os.environ.get(knob) and base == "gemm_f16.hip":
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
+    if os.environ.get("PD_ATTN_NOSPLIT_BLOCKS") and base == "attention.hip":     # lab: block count from which a launch is not key-split
+        cmd[1:1] = ["-DPD_ATTN_NOSPLIT_BLOCKS=" + os.environ["PD_ATTN_NOSPLIT_BLOCKS"]]
     if os.environ.get("PD_ATTN_MIN_WAVES") and base == "attention.hip":     # lab: query waves from which the split-operand kernels take a launch
         cmd[1:1] = ["-DPD_ATTN_MIN_WAVES=" + os.environ["PD_ATTN_MIN_WAVES"]]
     if os.environ.get("PD_ATTN_LAZY") and base == "attn_f16.hip":     # lab: lazy rescale of the attention accumulator (threshold in log2 units)
