@@ -316,6 +316,9 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O | (uintptr_t)a->bias) & 15)
         return PD_ERR_UNSUPPORTED;
     const int variant = pd_attention_variant(a);
+    // A bias whose producer folded the operand-scale product into it (bias_prescale != 1) is only meaningful to the pipelined kernel:
+    // any other kernel would consume it as an unscaled bias and return a wrong softmax silently - refuse instead.
+    if (a->bias && a->bias_prescale > 0.f && a->bias_prescale != 1.f && variant < 3000) return PD_ERR_ARG;
     if ((a->O2 || a->K2) && (variant < 2000 || variant % 1000 > 100)) return PD_ERR_UNSUPPORTED;   // only the unsplit fp16-parts kernel writes the split output / reads pre-split K, V
     if (variant >= 2000 && variant % 1000 > 100) {       // key-split launch on the fp16-parts kernel + the shared combine kernel
         if (((uintptr_t)a->ws & 15) != 0) return PD_ERR_UNSUPPORTED;

@@ -538,6 +538,9 @@ PD_EXPORT int pd_attention_bias_prescale_log2(float q_amax, float k_amax, float 
 extern "C" int pd_attention_pipe_ok(const pd_attn_args* a) {
     if (!a->f16x3 || a->fp32_mfma || a->bias_prescale < 0.f) return 0;      // < 0: the caller asks for attn_parts_kernel (A/B runs)
     if (a->bias && !(a->bias_prescale > 0.f)) return 0;
+    // the masked entries of a pre-scaled tile are -1e9 log2(e) 2^k (~ -2^(30.4 + k)): beyond k = 90 they would overflow to -inf and a
+    // fully masked query row would compute (-inf) - (-inf).  Tiny q / k bounds (near-zero projections) stay on attn_parts_kernel.
+    if (a->bias && a->bias_prescale > 0x1p90f) return 0;
     // the kernel addresses q, k, v and the bias through buffer descriptors with 32-bit offsets relative to the (batch, head) base
     const long long lim = 0xffffff00ll;
     const long long kss = a->K2 ? a->kv2_ss * 2 : a->k_ss * 4, vss = a->K2 ? a->kv2_ss * 2 : a->v_ss * 4;

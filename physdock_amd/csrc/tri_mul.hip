@@ -49,6 +49,10 @@ __global__ __launch_bounds__(64 * NWAVES) void tri_mul_kernel(const pd_tri_mul_a
                 const int r = lr + 8 * t, j = j0 + 4 * lq;
                 if (i0 + r < p.T && j < p.Treal) va = *reinterpret_cast<const f32x4*>(Ap + (long long)(i0 + r) * p.T + j);
                 if (I0 + r < p.T && j < p.Treal) vb = *reinterpret_cast<const f32x4*>(Bp + (long long)(I0 + r) * p.T + j);
+                if (j + 3 >= p.Treal) {          // last partial quad: padded j never enter the reduction (as K = Treal did in the fp32 GEMM)
+#pragma unroll
+                    for (int e = 1; e < 4; ++e) if (j + e >= p.Treal) { va[e] = 0.f; vb[e] = 0.f; }
+                }
             } else {                             // memory row = j, 4 consecutive output rows / columns
                 const int j = j0 + lr + 8 * t;
                 if (j < p.Treal && i0 + 4 * lq < p.T) va = *reinterpret_cast<const f32x4*>(Ap + (long long)j * p.T + i0 + 4 * lq);

@@ -96,28 +96,36 @@ class Engine:
 
     _PS_MEMO = {}
 
-    def attn_prescale(self, qk, nbatch, nq, nk, H, ws=None):
+    def attn_prescale(self, qk, nbatch, nq, nk, H, ws=None, strides=None):
         """power of two to fold into the out_scale of the bias producer of an attention launch, or 0.0: non-zero exactly when
         pd_attention would run this launch on the pipelined fp16-format kernel (variant 3000 +), which takes the bias tile - times the
         product of its q and k operand scales - as the initial value of the score accumulator.  qk: host (|q|, |k|) bounds or None."""
         if qk is None or not (ops.PIPE_ATTN and ops.F16_ATTN and ops.SPLIT_ATTN):
             return 0.0
-        key = (float(qk[0]), float(qk[1]), nbatch, nq, nk, H, ws is not None and ws.numel())
+        # strides: the (batch, sequence) strides in floats the REAL launch addresses q / k / v with - the pipelined kernel's
+        # 32-bit buffer offsets bound them (pd_attention_pipe_ok), so the probe must see them, and the real pre-scale too (its
+        # magnitude limit); the library refuses a pre-scaled bias on any other kernel (PD_ERR_ARG) should the two ever disagree
+        st = tuple(strides) if strides is not None else (max(nq, nk) * H * 32, H * 32)
+        key = (float(qk[0]), float(qk[1]), nbatch, nq, nk, H, ws is not None and ws.numel(), st,
+               ops.PIPE_ATTN, ops.F16_ATTN, ops.SPLIT_ATTN)
         r = Engine._PS_MEMO.get(key)
         if r is None:
             d = 1 << 20
-            v = ops.attention(d, d, d, d, nq=nq, nk=nk, nbatch=nbatch, nheads=H, q_strides=(nq * H * 32, H * 32), k_strides=(nk * H * 32, H * 32),
-                              v_strides=(nk * H * 32, H * 32), o_strides=(nq * H * 32, H * 32), bias=d, bias_nk=nq, ws=ws,
-                              f16_amax=(qk[0], qk[1], 1.0), bias_prescale=1.0, query_only=True)
-            r = ops.attn_bias_prescale(qk[0], qk[1]) if v >= 3000 else 0.0
+            r = ops.attn_bias_prescale(qk[0], qk[1])
+            v = ops.attention(d, d, d, d, nq=nq, nk=nk, nbatch=nbatch, nheads=H, q_strides=st, k_strides=st,
+                              v_strides=st, o_strides=(nq * H * 32, H * 32), bias=d, bias_nk=nq, ws=ws,
+                              f16_amax=(qk[0], qk[1], 1.0), bias_prescale=r, query_only=True)
+            if v < 3000:
+                r = 0.0
             Engine._PS_MEMO[key] = r
         return r
 
-    def trunk_prescale(self, prefix, norm_weight, nbatch, nq, nk, H):
+    def trunk_prescale(self, prefix, norm_weight, nbatch, nq, nk, H, strides=None):
         """attn_prescale of a trunk attention (static bounds from the projection weights)"""
         if self.trunk_attn_bounds(prefix, norm_weight) is None:
             return 0.0
-        return self.attn_prescale(self.P.attn_static_bounds_host(prefix, norm_weight)[:2], nbatch, nq, nk, H, self.attn_ws(nbatch, nq, nk, H))
+        return self.attn_prescale(self.P.attn_static_bounds_host(prefix, norm_weight)[:2], nbatch, nq, nk, H, self.attn_ws(nbatch, nq, nk, H),
+                                  strides=strides)
 
     @staticmethod
     def o_bound(bounds):
@@ -259,7 +267,8 @@ class Engine:
         # bias first: its streaming pass over z also produces the row statistics of the shared norm
         st = self.ws.get(f"stats@{self.lane}", M, 2)
         bias = self.ws.get("tri_bias", ops.bias_frag_numel(H, T, T), zero=True)
-        ps = self.trunk_prescale(prefix, nw, T, T, self.Tr, H)
+        # (strides of the widest projection layout, q|k|v|g: the fused-tail q|k|v form only shrinks them)
+        ps = self.trunk_prescale(prefix, nw, T, T, self.Tr, H, strides=(4 * C, T * 4 * C) if transpose else (T * 4 * C, 4 * C))
         self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, norm="norm", st_out=st, prescale=ps)
         bnd = self.trunk_attn_bounds(prefix, nw)
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
@@ -307,7 +316,7 @@ class Engine:
         abias = self.ws.get("atom_bias", ops.bias_frag_numel(Ca // 32, A, A), zero=True)
         for b in range(no_blocks):
             blk = f"{prefix}.blocks.{b}"
-            ps = self.trunk_prescale(blk + ".attention", P[blk + ".attention.norm_s.weight"], 1, A, self.Ar, Ca // 32)
+            ps = self.trunk_prescale(blk + ".attention", P[blk + ".attention.norm_s.weight"], 1, A, self.Ar, Ca // 32, strides=(A * 4 * Ca, 4 * Ca))
             self.pair_bias(blk + ".attention", ap, A, A, Cap, ap_mask, P[blk + ".attention.norm_z.weight"], abias, prescale=ps)
             self.attention_pair_bias(blk + ".attention", a, 1, A, Ca, abias, nk=self.Ar, bias_prescale=ps)
             self.transition(blk + ".transition", a, A, Ca)
@@ -319,7 +328,7 @@ class Engine:
         for b in range(no_blocks):
             blk = f"{prefix}.blocks.{b}"
             self.triangle_block(blk, z, T, Cz, z_mask, z_maskT)
-            ps = self.trunk_prescale(blk + ".attention", P[blk + ".attention.norm_s.weight"], 1, T, self.Tr, Cs // 32)
+            ps = self.trunk_prescale(blk + ".attention", P[blk + ".attention.norm_s.weight"], 1, T, self.Tr, Cs // 32, strides=(T * 4 * Cs, 4 * Cs))
             self.pair_bias(blk + ".attention", z, T, T, Cz, z_mask, P[blk + ".attention.norm_z.weight"], sbias, prescale=ps)
             self.attention_pair_bias(blk + ".attention", s, 1, T, Cs, sbias, nk=self.Tr, bias_prescale=ps)
             self.transition(blk + ".transition", s, T, Cs)
@@ -398,7 +407,7 @@ class Engine:
         for b in range(dc.no_blocks_evoformer):
             blk = f"{te}.evoformer.blocks.{b}"
             # MSA row attention with pair bias (attentions.py:76-97)
-            ps = self.trunk_prescale(blk + ".msa_row_attention", P[blk + ".msa_row_attention.norm_m.weight"], S, T, self.Tr, Hm)
+            ps = self.trunk_prescale(blk + ".msa_row_attention", P[blk + ".msa_row_attention.norm_m.weight"], S, T, self.Tr, Hm, strides=(T * 4 * Cm, 4 * Cm))
             self.pair_bias(blk + ".msa_row_attention", z, T, T, Cz, z_mask, P[blk + ".msa_row_attention.norm_z.weight"], mbias, prescale=ps)
             self.attention_pair_bias(blk + ".msa_row_attention", m, S, T, Cm, mbias, norm_name="norm_m", nk=self.Tr, bias_prescale=ps)
             self.msa_column_attention(blk + ".msa_col_attention", m, S, T, Cm)
@@ -530,8 +539,8 @@ class Engine:
         # pipelined attention kernel: attn_prescale)
         Ar, Tr = batch.get("_A_real", A), batch.get("_T_real", T)
         f16 = ops.SPLIT_GEMM and ops.F16_GEMM
-        ps_a = self.attn_prescale(P.dit_qk_bounds_host("atom"), B, A, Ar, Ca // 32, self.attn_ws(B, A, Ar, Ca // 32)) if (B and f16) else 0.0
-        ps_t = self.attn_prescale(P.dit_qk_bounds_host("token"), B, T, Tr, Cs // 32, self.attn_ws(B, T, Tr, Cs // 32)) if (B and f16) else 0.0
+        ps_a = self.attn_prescale(P.dit_qk_bounds_host("atom"), B, A, Ar, Ca // 32, self.attn_ws(B, A, Ar, Ca // 32), strides=(A * 3 * Ca, 3 * Ca)) if (B and f16) else 0.0
+        ps_t = self.attn_prescale(P.dit_qk_bounds_host("token"), B, T, Tr, Cs // 32, self.attn_ws(B, T, Tr, Cs // 32), strides=(T * 3 * Cs, 3 * Cs)) if (B and f16) else 0.0
         osc_a, osc_t = LOG2E * (ps_a or 1.0), LOG2E * (ps_t or 1.0)
         Wa, ba_, na = P.dit_bias("atom")                  # [2*nb_atom*H, Cap] with LN affine folded
         fa = ws.get("dit_atom_bias", ops.bias_frag_numel(na, A, A), zero=True)

@@ -182,6 +182,10 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
         key = (M, N, K, a.lda, int(glu), hn_w is not None, mul is not None, res is not None, pro_rows_per_group > 0, out_mode, act, pro_act,
                a.W2 is not None, a.W3 is not None, a.ksplit_ws is not None, bool(a_kmajor), batch)
         key = key + (INLINE_STATS, F16_ROWS, a.A2 is not None, a.a_amax is not None)
+        # everything else the library's choice depends on: epilogue operands, the alignment class of A and of the
+        # prologue vectors, the group stride, and the run-time switches a test or a lab run may flip
+        key = key + (bias is not None, Y2 is not None, int(hn_split or 0), int(pro_gstride or 0), (a.A or 0) & 15, (a.pro_w or 0) & 15,
+                     (a.pro_b or 0) & 15, F16_GEMM, SPLIT_GEMM, KV_PRESPLIT, KSPLIT_GEMM, F16_WIDE_ROWS)
         ok = _INLINE_STATS_OK.get(key)
         if ok is None:
             ok = False

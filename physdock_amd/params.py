@@ -239,3 +239,33 @@ def seeded_state_dict(shapes, seed: int = 0, dtype=torch.float32):
             x = 0.1 * x
         out[name] = x.to(dtype)
     return out
+
+
+_OUTLIER_ROWS = (".linear_q.weight", ".linear_k.weight", ".linear_v.weight", ".linear_o.weight", ".linear_g.weight",
+                 ".w1.weight", ".w2.weight", ".w3.weight", ".norm_s.linear.weight", ".ffn_norm.linear.weight")
+
+
+def outlier_state_dict(shapes, seed: int = 0, frac: float = 0.01, lo: float = 30.0, hi: float = 100.0, outlier_seed: int = 77):
+    """`seeded_state_dict` with trained-model-like OUTLIERS: `frac` of the entries of every norm gain (1-D ``*.weight``) and
+    `frac` of the rows of every attention / SwiGLU projection and AdaLN-Zero modulation matrix are multiplied by a factor drawn
+    from U(lo, hi).  Trained transformers carry a few such gains / channels; the two-part fp16 operand format of the DiT
+    kernels (csrc/common.h) sizes its scales from static magnitude bounds, so a parity fixture on near-init weights alone
+    would not notice a bound that is far too loose (precision loss) or violated (overflow).  Deterministic: one CPU generator,
+    names in sorted order; a tensor of n gains / rows gets round(frac n) outliers, at least one when n >= 64."""
+    out = seeded_state_dict(shapes, seed)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(outlier_seed)
+    for name in sorted(out):
+        w = out[name]
+        gains = w.ndim == 1 and name.endswith(".weight")
+        rows = w.ndim == 2 and name.endswith(_OUTLIER_ROWS)
+        if not (gains or rows):
+            continue
+        n = w.shape[0]
+        k = max(int(round(frac * n)), 1 if n >= 64 else 0)
+        if k == 0:
+            continue
+        idx = torch.randperm(n, generator=g)[:k]
+        f = lo + (hi - lo) * torch.rand(k, generator=g)
+        w[idx] = w[idx] * (f if gains else f[:, None])
+    return out
