@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 7
+#define PD_ABI_VERSION 8
 
 enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFRAG = 3 };
 
@@ -365,12 +365,16 @@ int pd_pairwise_rmsd(const float* x, const int* idx, const float* ref, float* D,
 int pd_euler(const float* x_hat, const float* x_den, const float* x_proj, const float* w, float t_hat, float eta, float dt,
              float* x_next, int B, int A, void* stream);
 int pd_timestep_embed(const float* tau, float* emb, int n, void* stream);
-/* pd_dit_bounds (ABI 5): rigorous magnitude bounds of a DiT block's activations from the AdaLN table alone, for the two-part fp16
- * operand format: tab [nrows][ld] holds per DiT block (shift | 1 + scale | gate) x (attention, transition), C channels each;
- * consts [nblocks][4] = (q bound, k bound, max_n ||Wv_n||_2, max_n ||W1_n||_2 max_n ||W3_n||_2) from the weights;
- * out [nrows][nblocks][8] = (|q|, |k|, |v| = |o|, |y|, |y'|, |h|, 0, 0) upper bounds (see csrc/sampler.hip for the derivation;
- * reference adaptive_layer_norm_zero.py:16-21, attentions.py:241-265, transitions.py:27-30).                                   */
-int pd_dit_bounds(const float* tab, int nrows, int ld, int nblocks, int C, const float* consts, float* out, void* stream);
+/* pd_dit_bounds (ABI 5; tightened in ABI 8): rigorous magnitude bounds of a DiT block's activations for the two-part fp16 operand
+ * format, from the AdaLN table and the weights - no activation is looked at: tab [nrows][ld] holds per DiT block
+ * (shift | 1 + scale | gate) x (attention, transition), C channels each; consts [nblocks][4] = (q bound, k bound, -, -);
+ * wstack [nblocks][C + 2 hidden][C] = the block's (linear_v | w1 | w3) rows as its projections use them; vh [nrows][nblocks][2]
+ * scratch.  out [nrows][nblocks][8] = (|q|, |k|, |v| = |o|, |y|, |y'|, |h|, 0, 0) upper bounds.  ABI 8: |v| and |h| are per-output-row
+ * Cauchy-Schwarz bounds with the step's own modulation inside the norm (sqrt(C) ||W_n o (1 + scale)||_2 + |W_n . shift|), maximised
+ * over n - a large AdaLN gain or weight row no longer loosens the bound of every channel (csrc/sampler.hip for the derivation;
+ * reference adaptive_layer_norm_zero.py:16-21, attentions.py:241-265, transitions.py:27-30).                                     */
+int pd_dit_bounds(const float* tab, int nrows, int ld, int nblocks, int C, int hidden, const float* consts, const float* wstack,
+                  float* vh, float* out, void* stream);
 /* chirality accept / reject of B poses without leaving the device (replaces the per-pose RDKit rebuild + R/S comparison of
  * redocking.py:264-281,303-317): centres[nc][4] = (centre atom, three neighbour atoms), indices into the A atoms of a pose;
  * sign of the signed volume (n1-c).((n2-c)x(n3-c)) vs ref_sign[nc] (+1 / -1); accept[b] = 1 iff every centre matches.

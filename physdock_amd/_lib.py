@@ -183,7 +183,7 @@ def _declare(L):
     sig("pd_euler", p, p, p, p, f, f, f, p, i, i, p)
     sig("pd_pairwise_rmsd", p, p, p, p, p, i, i, i, p)
     sig("pd_timestep_embed", p, p, i, p)
-    sig("pd_dit_bounds", p, i, i, i, i, p, p, p)
+    sig("pd_dit_bounds", p, i, i, i, i, i, p, p, p, p, p)
     sig("pd_norm_split2", p, i, i, i, i, f, p, p, i, i, p, p, p)
     sig("pd_transition_f16", C.POINTER(TransitionArgs), p)
     sig("pd_tri_tail", C.POINTER(TriTailArgs), p)

@@ -585,48 +585,123 @@ PD_EXPORT int pd_ligand_scatter(float* dst, const float* src, const float* lig, 
     return pd_check_launch();
 }
 
-// ---- magnitude bounds for the two-part fp16 operand format of the DiT kernels, from the AdaLN table alone ----------------
+// ---- magnitude bounds for the two-part fp16 operand format of the DiT kernels, from the AdaLN table and the weights ------
 // A DiT block's activations are products of bounded things: x^ = LayerNorm(x) without affine has |x^_k| <= sqrt(C - 1) and
-// ||x^||_2 <= sqrt(C) for ANY input; AdaLN-Zero then gives y = (1 + scale) x^ + shift with (shift, 1 + scale) rows of the
-// per-call table (adaptive_layer_norm_zero.py:16-21).  Hence, rigorously and without looking at a single activation:
-//   |y_k|  <= wmax sqrt(C) + bmax,          ||y||_2 <= wmax sqrt(C) + ||shift||_2,
-//   |v_n|  <= ||Wv_n||_2 ||y||_2            (Cauchy-Schwarz; the DiT's q|k|v projection has no bias),   |o| <= max |v|,
+// ||x^||_2 <= sqrt(C) for ANY input; AdaLN-Zero then gives y = w x^ + shift with (shift, w = 1 + scale) rows of the per-call
+// table (adaptive_layer_norm_zero.py:16-21).  Hence, rigorously and without looking at a single activation:
+//   |y_k|  <= wmax sqrt(C) + bmax,
+//   |W_n . y| <= ||W_n o w||_2 ||x^||_2 + |W_n . shift| <= sqrt(C) ||W_n o w||_2 + |W_n . shift| =: R(W_n)      (Cauchy-Schwarz
+//             per OUTPUT ROW with the step's own modulation inside the norm - round 5; rounds 3-4 used max_n ||W_n|| * (wmax sqrt(C)
+//             + ||shift||), which is the same statement with every factor replaced by its maximum: a single large AdaLN gain or
+//             weight row then loosened the bound of every channel by that factor and the ordinary channels lost their low bits),
+//   |v_n|  <= R(Wv_n)        (the DiT's q|k|v projection has no bias),   |o| <= max_n |v_n|  (a convex combination of v rows),
 //   |q_k|, |k_k| <= sqrt(32) max|head-norm gain|   (per-head RMS norm),
-//   |h_n| = |silu(a_n) b_n| <= |a_n| |b_n| <= ||W1_n||_2 ||W3_n||_2 ||y'||_2^2      (transition SwiGLU, y' = second AdaLN).
-// out[(row * nblocks + b) * 8 + ..] = [q, k, v (= o), y, y', h, 0, 0]; consts[b * 4 + ..] = [q bound, k bound,
-// max_n ||Wv_n||, max_n ||W1_n|| * max_n ||W3_n||] come from the weights once (packing.py).  One block per (DiT block, row).
+//   |h_n| = |silu(a_n) b_n| <= |a_n| |b_n| <= R'(W1_n) R'(W3_n)      (transition SwiGLU; R' with the second AdaLN of the block).
+// out[(row * nblocks + b) * 8 + ..] = [q, k, v (= o), y, y', h, 0, 0]; consts[b * 4 + ..] = [q bound, k bound, -, -].
+// Stage 1 (dit_bounds_rows_kernel) fills vh[(row * nblocks + b) * 2 + ..] = [max_n R(Wv_n), max_n R'(W1_n) R'(W3_n)] by atomic
+// maxima; stage 2 (dit_bounds_kernel) adds the table-only bounds.  Both once per sample_diffusion call, outside the step loop.
+//
+// Stage 1: one workgroup per (DiT block, 64 weight rows); LANES are table rows (steps / samples, 64 per pass), so the sums over k
+// run in registers without a single cross-lane reduction: the k-chunk of the table is staged [vector][k][row] in LDS (lanes read
+// consecutive words), the weights of a row are wave-uniform loads.
+constexpr int BR_KC = 32, BR_ROWS = 16;       // k per LDS chunk; weight rows per wave
+__global__ __launch_bounds__(256) void dit_bounds_rows_kernel(const float* __restrict__ tab, int nrows, int ld, int nblocks, int C, int hidden,
+                                                               const float* __restrict__ wstack, float* __restrict__ vh) {
+    __shared__ float lt[4][BR_KC][64];
+    const int b = blockIdx.x, n0 = blockIdx.y * 64, r0 = blockIdx.z * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* tb = tab + (long long)b * 6 * C;
+    const float* Wb = wstack + (long long)b * (C + 2 * hidden) * C;
+    const int nw0 = n0 + wave * BR_ROWS;                              // this wave's weight rows nw0 .. nw0 + 15
+    float pv2[BR_ROWS], pvs[BR_ROWS], pa2[BR_ROWS], pas[BR_ROWS], pb2[BR_ROWS], pbs[BR_ROWS];
+#pragma unroll
+    for (int i = 0; i < BR_ROWS; ++i) pv2[i] = pvs[i] = pa2[i] = pas[i] = pb2[i] = pbs[i] = 0.f;
+    for (int k0 = 0; k0 < C; k0 += BR_KC) {
+        __syncthreads();
+        // stage (shift1, w1, shift2, w2)[k0 .. k0 + 31] of 64 table rows: 4 x 64 x 32 floats, 32 consecutive k per (vector, row)
+        for (int i = tid; i < 4 * 64 * BR_KC; i += 256) {
+            const int kk = i % BR_KC, r = (i / BR_KC) % 64, v = i / (BR_KC * 64);
+            const int col = (v == 0 ? 0 : v == 1 ? C : v == 2 ? 3 * C : 4 * C) + k0 + kk;
+            lt[v][kk][r] = (r0 + r < nrows && k0 + kk < C) ? tb[(long long)(r0 + r) * ld + col] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < BR_KC; ++kk) {
+            const float s1 = lt[0][kk][lane], w1 = lt[1][kk][lane], s2 = lt[2][kk][lane], w2 = lt[3][kk][lane];
+            const int k = k0 + kk;
+#pragma unroll
+            for (int i = 0; i < BR_ROWS; ++i) {
+                const int n = nw0 + i;                                 // wave-uniform
+                if (n < C) {
+                    const float w = Wb[(long long)n * C + k];
+                    const float t = w * w1;
+                    pv2[i] += t * t; pvs[i] += w * s1;
+                }
+                if (n < hidden) {
+                    const float wa = Wb[(long long)(C + n) * C + k], wb = Wb[(long long)(C + hidden + n) * C + k];
+                    const float ta = wa * w2, tb2 = wb * w2;
+                    pa2[i] += ta * ta; pas[i] += wa * s2;
+                    pb2[i] += tb2 * tb2; pbs[i] += wb * s2;
+                }
+            }
+        }
+    }
+    const float rc = sqrtf((float)C);
+    float vmax = 0.f, hmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < BR_ROWS; ++i) {
+        const int n = nw0 + i;
+        if (n < C) vmax = fmaxf(vmax, rc * sqrtf(pv2[i]) + fabsf(pvs[i]));
+        if (n < hidden) hmax = fmaxf(hmax, (rc * sqrtf(pa2[i]) + fabsf(pas[i])) * (rc * sqrtf(pb2[i]) + fabsf(pbs[i])));
+    }
+    if (r0 + lane < nrows) {          // non-negative floats order like their bit patterns
+        unsigned* o = reinterpret_cast<unsigned*>(vh + ((long long)(r0 + lane) * nblocks + b) * 2);
+        atomicMax(o, __float_as_uint(vmax));
+        atomicMax(o + 1, __float_as_uint(hmax));
+    }
+}
+
 __global__ __launch_bounds__(256) void dit_bounds_kernel(const float* __restrict__ tab, int ld, int nblocks, int C,
-                                                          const float* __restrict__ consts, float* __restrict__ out) {
+                                                          const float* __restrict__ consts, const float* __restrict__ vh,
+                                                          float* __restrict__ out) {
     const int b = blockIdx.x, row = blockIdx.y;
     const float* base = tab + (long long)row * ld + (long long)b * 6 * C;
-    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // bmax1, wmax1, bsq1, bmax2, wmax2, bsq2
+    float v[4] = {0.f, 0.f, 0.f, 0.f};          // bmax1, wmax1, bmax2, wmax2
     for (int k = threadIdx.x; k < C; k += 256) {
         const float s1 = base[k], w1 = base[C + k], s2 = base[3 * C + k], w2 = base[4 * C + k];
-        v[0] = fmaxf(v[0], fabsf(s1)); v[1] = fmaxf(v[1], fabsf(w1)); v[2] += s1 * s1;
-        v[3] = fmaxf(v[3], fabsf(s2)); v[4] = fmaxf(v[4], fabsf(w2)); v[5] += s2 * s2;
+        v[0] = fmaxf(v[0], fabsf(s1)); v[1] = fmaxf(v[1], fabsf(w1));
+        v[2] = fmaxf(v[2], fabsf(s2)); v[3] = fmaxf(v[3], fabsf(w2));
     }
-    __shared__ float red[4][6];
+    __shared__ float red[4][4];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = (i % 3 == 2) ? wave_sum(v[i]) : wave_max(v[i]);
+    for (int i = 0; i < 4; ++i) v[i] = wave_max(v[i]);
     if ((threadIdx.x & 63) == 0)
-        for (int i = 0; i < 6; ++i) red[threadIdx.x >> 6][i] = v[i];
+        for (int i = 0; i < 4; ++i) red[threadIdx.x >> 6][i] = v[i];
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 0; i < 6; ++i)
-            for (int w = 1; w < 4; ++w) v[i] = (i % 3 == 2) ? v[i] + red[w][i] : fmaxf(v[i], red[w][i]);
-        const float rc = sqrtf((float)C) * 1.0001f;       // (a hair above the exact bound: the table itself is rounded fp32)
-        const float y1 = v[1] * rc + v[0], y1l2 = v[1] * rc + sqrtf(v[2]) * 1.0001f;
-        const float y2 = v[4] * rc + v[3], y2l2 = v[4] * rc + sqrtf(v[5]) * 1.0001f;
+        for (int i = 0; i < 4; ++i)
+            for (int w = 1; w < 4; ++w) v[i] = fmaxf(v[i], red[w][i]);
+        // (1.001: the table and the sums above are rounded fp32; the operand scale leaves a factor two of headroom below 65504 anyway)
+        const float rc = sqrtf((float)C) * 1.001f;
         const float* c = consts + 4 * b;
+        const float* m = vh + ((long long)row * nblocks + b) * 2;
         float* o = out + ((long long)row * nblocks + b) * 8;
-        o[0] = c[0]; o[1] = c[1]; o[2] = c[2] * y1l2 * 1.0001f; o[3] = y1; o[4] = y2; o[5] = c[3] * y2l2 * y2l2 * 1.0001f;
+        o[0] = c[0]; o[1] = c[1]; o[2] = m[0] * 1.001f; o[3] = v[1] * rc + v[0]; o[4] = v[3] * rc + v[2]; o[5] = m[1] * 1.002f;
         o[6] = 0.f; o[7] = 0.f;
     }
 }
 
-PD_EXPORT int pd_dit_bounds(const float* tab, int nrows, int ld, int nblocks, int C, const float* consts, float* out, void* stream) {
-    if (!tab || !consts || !out || nrows <= 0 || nblocks <= 0 || C <= 0 || ld < nblocks * 6 * C) return PD_ERR_ARG;
-    hipLaunchKernelGGL(dit_bounds_kernel, dim3(nblocks, nrows), dim3(256), 0, (hipStream_t)stream, tab, ld, nblocks, C, consts, out);
+// wstack: [nblocks][C + 2 hidden][C] fp32 = the block's (linear_v | w1 | w3) rows as the projections use them; vh: [nrows][nblocks][2] scratch
+PD_EXPORT int pd_dit_bounds(const float* tab, int nrows, int ld, int nblocks, int C, int hidden, const float* consts, const float* wstack,
+                            float* vh, float* out, void* stream) {
+    if (!tab || !consts || !wstack || !vh || !out || nrows <= 0 || nblocks <= 0 || C <= 0 || hidden <= 0 || ld < nblocks * 6 * C) return PD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(vh, 0, sizeof(float) * 2 * (size_t)nrows * nblocks, s) != hipSuccess) return PD_ERR_LAUNCH;
+    const int nmax = C > hidden ? C : hidden;
+    hipLaunchKernelGGL(dit_bounds_rows_kernel, dim3(nblocks, (nmax + 63) / 64, (nrows + 63) / 64), dim3(256), 0, s, tab, nrows, ld, nblocks, C,
+                       hidden, wstack, vh);
+    hipLaunchKernelGGL(dit_bounds_kernel, dim3(nblocks, nrows), dim3(256), 0, s, tab, ld, nblocks, C, consts, vh, out);
     return pd_check_launch();
 }
 

@@ -54,6 +54,12 @@ class Engine:
         self.device = device
         self.ws = Workspace(device)
         self.lane = 0              # sample lane (concurrent stream) whose private DiT scratch is in use
+        #: DiT families ("atom" / "token") whose launches were taken off the two-part fp16 format by check_dit_bounds (their bounds
+        #: turned out too loose for these weights): they run on bf16 x 6, which needs no bound.  Lives with the engine = the weights.
+        self.f16_off = set()
+        self.probe = None          # check_dit_bounds: records (operand, observed magnitudes, bound) at three sites of dit_block
+        self.bound_report = {}     # family -> operand -> dict(amax_ratio, typical_ratio): the last check_dit_bounds result
+        self._bounds_checked = set()
         dc = config.model.diffusion_conditioning
         self.inf, self.eps = float(dc.inf), float(dc.eps)
 
@@ -539,8 +545,8 @@ class Engine:
         # pipelined attention kernel: attn_prescale)
         Ar, Tr = batch.get("_A_real", A), batch.get("_T_real", T)
         f16 = ops.SPLIT_GEMM and ops.F16_GEMM
-        ps_a = self.attn_prescale(P.dit_qk_bounds_host("atom"), B, A, Ar, Ca // 32, self.attn_ws(B, A, Ar, Ca // 32), strides=(A * 3 * Ca, 3 * Ca)) if (B and f16) else 0.0
-        ps_t = self.attn_prescale(P.dit_qk_bounds_host("token"), B, T, Tr, Cs // 32, self.attn_ws(B, T, Tr, Cs // 32), strides=(T * 3 * Cs, 3 * Cs)) if (B and f16) else 0.0
+        ps_a = self.attn_prescale(P.dit_qk_bounds_host("atom"), B, A, Ar, Ca // 32, self.attn_ws(B, A, Ar, Ca // 32), strides=(A * 3 * Ca, 3 * Ca)) if (B and f16 and "atom" not in self.f16_off) else 0.0
+        ps_t = self.attn_prescale(P.dit_qk_bounds_host("token"), B, T, Tr, Cs // 32, self.attn_ws(B, T, Tr, Cs // 32), strides=(T * 3 * Cs, 3 * Cs)) if (B and f16 and "token" not in self.f16_off) else 0.0
         osc_a, osc_t = LOG2E * (ps_a or 1.0), LOG2E * (ps_t or 1.0)
         Wa, ba_, na = P.dit_bias("atom")                  # [2*nb_atom*H, Cap] with LN affine folded
         fa = ws.get("dit_atom_bias", ops.bias_frag_numel(na, A, A), zero=True)
@@ -572,7 +578,10 @@ class Engine:
             consts = P.dit_bound_consts(kind)
             nb = consts.shape[0]
             out = ws.get("dit_bounds_" + kind, n, nb, 8)
-            ops.check(L.pd_dit_bounds(ops.ptr(tab), n, tab.shape[1], nb, C, ops.ptr(consts), ops.ptr(out), ops.stream()), "dit_bounds")
+            wstack, hidden = P.dit_bound_weights(kind)
+            vh = ws.get("dit_bounds_vh_" + kind, n, nb, 2)
+            ops.check(L.pd_dit_bounds(ops.ptr(tab), n, tab.shape[1], nb, C, hidden, ops.ptr(consts), ops.ptr(wstack), ops.ptr(vh),
+                                      ops.ptr(out), ops.stream()), "dit_bounds")
             if per_sample:                  # rows = samples of ONE launch (training-time forward): the launch needs the largest
                 out.copy_(out.amax(0, keepdim=True).expand_as(out))
             bnd[kind] = out
@@ -642,6 +651,8 @@ class Engine:
         else:
             self.gemm(x, P.qkv(prefix + ".attention"), qkv, rows, 3 * C, C, stats=self.stats_buf(rows), stats_inline=(LN, eps),
                       pro_b=off(tab, tab_off), pro_w=off(tab, tab_off + C), a_amax=b_y, **hn, **grp)
+        if self.probe is not None and kv2 is None and f16:
+            self.probe(prefix, "v", qkv[:B * N, 2 * C:], bnd + 8)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         # (the attention kernel lays its split output out as [2][B N][C]: it is the projection's A2 only when no padding rows follow)
         o_split = unsplit_f16 and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C and rows == B * N \
@@ -653,6 +664,8 @@ class Engine:
         else:
             o = self.lws("dit_o", rows, C)
             ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), o, **akw)
+            if self.probe is not None and f16:
+                self.probe(prefix, "o", o[:B * N], bnd + 8)
             self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, a_amax=b_o, **mgrp)
         t2 = tab_off + 3 * C
         W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
@@ -669,7 +682,81 @@ class Engine:
         else:
             self.gemm(x, W13, h, rows, 2 * hidden, C, stats=self.stats_buf(rows), stats_inline=(LN, eps), pro_b=off(tab, t2),
                       pro_w=off(tab, t2 + C), glu=1, a_amax=b_y2, **grp)
+        if self.probe is not None and f16:
+            self.probe(prefix, "h", h[:B * N], bnd + 20)
         self.gemm(h, W2, x, rows, C, hidden, ldw=ldw, mul=off(tab, t2 + 2 * C), res=x, a_amax=b_h, **mgrp)
+
+    def check_dit_bounds(self, batch, a, s, prep, plan, B, sigma_data=16.0):
+        """First-call guard of the two-part fp16 operand format (round 5): run the denoiser on THIS system,
+        THESE weights and the call's own AdaLN tables at three noise levels (first, middle, last step; inputs = ground-truth
+        coordinates + t^ N(0, 1), the operating point of a trained denoiser) with every bounded operand materialised in fp32, and
+        compare what the launches would see with the bounds pd_dit_bounds derived:
+          * observed max > bound: the bound is VIOLATED (an overflow waiting to happen) -> FloatingPointError, always;
+          * bound / (typical magnitude) > 2^17, or bound / observed max > 2^12: the bound holds but is so loose that ordinary
+            elements fall below the low part's precision floor (csrc/common.h: 2^-40 of the bound) -> the family ("atom" /
+            "token") is taken off the fp16 format for this engine (bf16 x 6 needs no bound), with a warning.
+        "Typical magnitude" = root mean square over the rows' median |x| would be costlier; the rms of the operand is used.
+        Returns the set of families switched off by THIS check (the caller then re-prepares the call).  Not part of any
+        captured graph; costs three eager denoiser passes once per (weights, shape)."""
+        import warnings
+        saved = (ops.ATTN_SPLIT_OUT, ops.FUSED_TRANSITION, ops.KV_PRESPLIT, ops.GEMM_HOOK, ops.ATTN_HOOK)
+        ops.ATTN_SPLIT_OUT = ops.FUSED_TRANSITION = ops.KV_PRESPLIT = False          # v, o and h as fp32 tensors
+        ops.GEMM_HOOK = ops.ATTN_HOOK = None                                          # (test / profiling hooks see the product launches only)
+        rec = []
+
+        def probe(prefix, name, t, bound_addr):
+            tf = t.float()
+            rec.append((prefix, name, tf.abs().amax(), tf.pow(2).mean().sqrt(), bound_addr))
+        A = a.shape[0]
+        gen = torch.Generator(device=self.device).manual_seed(1234)
+        xg = batch["x_gt"] - (batch["x_gt"] * batch["a_mask"][:, None]).sum(0, keepdim=True) / batch["a_mask"].sum().clamp_min(1)
+        steps = sorted({0, len(plan) // 2, len(plan) - 1})
+        x_hat = self.ws.get("probe_xhat", B, A, 3)
+        x_den = self.ws.get("probe_xden", B, A, 3)
+        bnd_of = {}
+        self.probe = probe
+        try:
+            for i in steps:
+                x_hat.copy_(xg[None] + plan[i]["t_hat"] * torch.randn(B, A, 3, device=self.device, generator=gen))
+                n0 = len(rec)
+                self.af3_dit(batch, x_hat, x_den, a, s, prep, B, plan[i], row=i)
+                for j in range(n0, len(rec)):
+                    bnd_of[j] = i
+        finally:
+            self.probe = None
+            ops.ATTN_SPLIT_OUT, ops.FUSED_TRANSITION, ops.KV_PRESPLIT, ops.GEMM_HOOK, ops.ATTN_HOOK = saved
+        if not rec:
+            return set()
+        amax = torch.stack([r[2] for r in rec]).cpu()
+        rms = torch.stack([r[3] for r in rec]).cpu()
+        # the bounds live in the per-call tables: read them back through their addresses' offsets
+        tabs = {"atom": prep["bnd_atom"], "token": prep["bnd_token"]}
+        report, off_now = {}, set()
+        for j, (prefix, name, _, _, addr) in enumerate(rec):
+            fam = "token" if ".token_dit." in prefix else "atom"
+            tb = tabs[fam]
+            idx = (addr - tb.data_ptr()) // 4
+            bound = float(tb.reshape(-1)[idx])
+            m, r = float(amax[j]), float(rms[j])
+            if not (m <= bound * 1.001):
+                raise FloatingPointError(f"fp16-format operand bound VIOLATED at {prefix} ({name}, step {bnd_of[j]}): observed max {m:.4g} > "
+                                         f"bound {bound:.4g} - the engine's bounds do not describe these weights (rebuild the engine; "
+                                         f"ops.F16_GEMM = False to confirm)")
+            e = report.setdefault(fam, {}).setdefault(name, {"amax_ratio": 0.0, "typical_ratio": 0.0, "where": None})
+            ra, rt = bound / max(m, 1e-30), bound / max(r, 1e-30)
+            if rt > e["typical_ratio"]:
+                e["typical_ratio"], e["where"] = rt, f"{prefix} step {bnd_of[j]}"
+            e["amax_ratio"] = max(e["amax_ratio"], ra)
+        for fam, ops_ in report.items():
+            for name, e in ops_.items():
+                if e["typical_ratio"] > 2.0 ** 17 or e["amax_ratio"] > 2.0 ** 12:
+                    off_now.add(fam)
+                    warnings.warn(f"physdock_amd: the static bound of the {fam}-level DiT operand '{name}' is 2^{math.log2(e['typical_ratio']):.1f} "
+                                  f"above its typical magnitude (2^{math.log2(e['amax_ratio']):.1f} above its maximum) at {e['where']}: the {fam} "
+                                  f"blocks run on the bf16 x 6 kernels for these weights (no bound needed, ~1.3x slower)")
+        self.bound_report = report
+        self.f16_off |= off_now
+        return off_now
 
     def af3_dit(self, batch, x_hat, x_den, a, s, prep, B, scal, row=0, per_sample=False):
         """AF3DiT.forward (transformers.py:235-262) for one noise level.
@@ -697,7 +784,8 @@ class Engine:
         fa_stride = ops.bias_frag_numel(Ha, A, A)
         ft_stride = ops.bias_frag_numel(Hs, T, T)
         nb_a, nb_t = dt.no_blocks_atom, dt.no_blocks_dit
-        bnd_a, bnd_t = prep["bnd_atom"], prep["bnd_token"]
+        bnd_a = None if "atom" in self.f16_off else prep["bnd_atom"]
+        bnd_t = None if "token" in self.f16_off else prep["bnd_token"]
         if (prep["ps_atom"] or prep["ps_token"]) and prep["B"] != B:
             raise RuntimeError("prepare_dit pre-scaled the hoisted biases for a different sample count")
         psa, pst = prep["ps_atom"], prep["ps_token"]

@@ -87,10 +87,53 @@ def split2_f16(W):
 class PackedWeights:
     """Device-resident fp32 views of a reference-named state dict + cached packed forms."""
 
-    def __init__(self, params, config):
+    def __init__(self, params, config, equalise=True):
         self.p = {k: v.detach().float().contiguous() for k, v in params.items()}
         self.cfg = config
         self.cache = {}
+        self.equalised = self._equalise() if equalise else {}
+
+    @staticmethod
+    def _pow2_ratio(norms):
+        """per-channel power of two r that brings norms / r within a factor sqrt(2) of the median norm - for channels at least a
+        factor ~3 (2^1.5) away from it; the ordinary spread of a weight matrix's rows is left alone (r = 1, also for zero rows)"""
+        nz = norms[norms > 0]
+        if nz.numel() == 0:
+            return torch.ones_like(norms)
+        e = torch.round(torch.log2(norms.clamp_min(1e-30) / nz.median())).clamp(-40, 40)
+        e = torch.where(e.abs() >= 2, e, torch.zeros_like(e))
+        return torch.where(norms > 0, torch.exp2(e), torch.ones_like(norms))
+
+    def _equalise(self):
+        """Channel equalisation of producer / consumer weight pairs by POWERS OF TWO (exact in fp32, the network function is
+        unchanged): value channels  linear_v row k / r_k, linear_o column k x r_k  (attention is linear in v), and SwiGLU channels
+        w3 row n / r_n, w2 column n x r_n  (h_n = silu(w1_n y) (w3_n y) is linear in w3_n), with r = the power of two nearest to
+        (row norm / median row norm), resp. (||w1_n|| ||w3_n|| / median).  A trained checkpoint with a few large value / hidden
+        channels then presents operands v, o, h whose channels have comparable magnitude, so ONE power-of-two operand scale per
+        launch (the two-part fp16 format, csrc/common.h) costs no precision on the ordinary channels.  Weights whose rows are
+        already balanced - the seeded parity weights - get r = 1 everywhere and are left bit-identical.
+        Returns {weight name: r} for the rows that were touched (diagnostics)."""
+        done = {}
+        for name in sorted(self.p):
+            if name.endswith(".linear_v.weight"):
+                pre = name[:-len(".linear_v.weight")]
+                o = pre + ".linear_o.weight"
+                if o not in self.p or self.p[o].shape[1] != self.p[name].shape[0]:
+                    continue
+                r = self._pow2_ratio(self.p[name].double().norm(dim=1).float())
+            elif name.endswith(".w3.weight"):
+                pre = name[:-len(".w3.weight")]
+                o, w1 = pre + ".w2.weight", pre + ".w1.weight"
+                if o not in self.p or w1 not in self.p or self.p[o].shape[1] != self.p[name].shape[0]:
+                    continue
+                r = self._pow2_ratio((self.p[w1].double().norm(dim=1) * self.p[name].double().norm(dim=1)).float())
+            else:
+                continue
+            if bool((r != 1).any()):
+                self.p[name] = (self.p[name] / r[:, None]).contiguous()
+                self.p[o] = (self.p[o] * r[None, :]).contiguous()
+                done[name] = r
+        return done
 
     def __getitem__(self, name):
         return self.p[name]
@@ -264,20 +307,25 @@ class PackedWeights:
         return self._c(("ditqk", kind), mk)
 
     def dit_bound_consts(self, kind):
-        """[blocks][4] = (q bound, k bound, max_n ||Wv_n||_2, max_n ||W1_n||_2 * max_n ||W3_n||_2): the weight-dependent factors of
-        the activation bounds pd_dit_bounds derives for the two-part fp16 operand format (csrc/sampler.hip)"""
+        """[blocks][4] = (q bound, k bound, 0, 0): the weight-only entries of the activation bounds pd_dit_bounds derives for the
+        two-part fp16 operand format (csrc/sampler.hip); the v / h bounds come from dit_bound_weights and the step's AdaLN row"""
         def mk():
-            rows = []
             qb, kb = self.dit_qk_bounds_host(kind)
-            for blk in self._dit_blocks(kind):
-                wv = self.p[blk + ".attention.linear_v.weight"]
-                w1 = self.p[blk + ".transition.feed_forward.w1.weight"]
-                w3 = self.p[blk + ".transition.feed_forward.w3.weight"]
-                up = 1.0001                                                     # the norms themselves are rounded fp32
-                rows.append([qb, kb, float(wv.double().norm(dim=1).max()) * up,
-                             float(w1.double().norm(dim=1).max()) * float(w3.double().norm(dim=1).max()) * up])
+            rows = [[qb, kb, 0.0, 0.0] for _ in self._dit_blocks(kind)]
             return torch.tensor(rows, dtype=torch.float32, device=self.p[self._dit_blocks(kind)[0] + ".attention.linear_v.weight"].device)
         return self._c(("ditbound", kind), mk)
+
+    def dit_bound_weights(self, kind):
+        """([blocks][C + 2 hidden][C] fp32, hidden): per DiT block the rows of linear_v, w1 and w3 as the projections use them (after
+        the channel equalisation) - pd_dit_bounds bounds |v_n| and |h_n| per output row against the step's AdaLN modulation"""
+        def mk():
+            blocks = []
+            for blk in self._dit_blocks(kind):
+                blocks.append(torch.cat([self.p[blk + ".attention.linear_v.weight"], self.p[blk + ".transition.feed_forward.w1.weight"],
+                                         self.p[blk + ".transition.feed_forward.w3.weight"]], 0))
+            hidden = self.p[self._dit_blocks(kind)[0] + ".transition.feed_forward.w1.weight"].shape[0]
+            return (torch.stack(blocks).contiguous(), hidden)
+        return self._c(("ditboundw", kind), mk)
 
     def adaln(self, kind):
         """All AdaLN-Zero projections of one DiT family stacked: per block

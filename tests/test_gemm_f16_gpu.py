@@ -192,22 +192,38 @@ def test_norm_split2_is_the_scaled_two_part_split():
     assert float((out[0].float() - hi.float()).abs().max()) <= float(hi.float().abs().max()) * 2 ** -10    # same rounding up to fp32 noise
 
 
-def test_dit_bounds_hold_and_are_not_wild(medium_block_inputs=None):
-    """pd_dit_bounds: the bounds really bound (LayerNorm + AdaLN algebra) and are within ~2^7 of the observed maxima"""
+@pytest.mark.parametrize("outliers", [False, True])
+def test_dit_bounds_hold_and_are_not_wild(outliers):
+    """pd_dit_bounds: the bounds really bound (LayerNorm + AdaLN algebra) and are within ~2^7 (h: 2^11) of the observed maxima - also
+    when a few AdaLN gains / shifts are x 64 with the consuming weight columns / 64 and a few value / SwiGLU rows are x 64
+    (trained-model-like outlier channels): the per-row Cauchy-Schwarz form keeps the modulation INSIDE the norm, so a large gain
+    that the weights divide out again does not loosen anything (rounds 3-4: the bound of h grew by 64^3 on this input)"""
     from physdock_amd import ops
-    nrows, nb, Cd = 5, 3, 128
-    tab = (0.4 * torch.randn(nrows, nb * 6 * Cd, generator=g(1))).cuda()
+    nrows, nb, Cd, hidden = 5, 3, 128, 256
+    tab = (0.4 * torch.randn(nrows, nb * 6 * Cd, generator=g(1)))
     for b in range(nb):
         tab[:, b * 6 * Cd + Cd:b * 6 * Cd + 2 * Cd] += 1.0
         tab[:, b * 6 * Cd + 4 * Cd:b * 6 * Cd + 5 * Cd] += 1.0
     Wv = torch.randn(nb, Cd, Cd, generator=g(2)) / math.sqrt(Cd)
-    W1 = torch.randn(nb, 256, Cd, generator=g(3)) / math.sqrt(Cd); W3 = torch.randn(nb, 256, Cd, generator=g(4)) / math.sqrt(Cd)
-    consts = torch.tensor([[7.0, 6.0, float(Wv[b].norm(dim=1).max()), float(W1[b].norm(dim=1).max() * W3[b].norm(dim=1).max())]
-                           for b in range(nb)]).cuda()
+    W1 = torch.randn(nb, hidden, Cd, generator=g(3)) / math.sqrt(Cd); W3 = torch.randn(nb, hidden, Cd, generator=g(4)) / math.sqrt(Cd)
+    if outliers:
+        for b in range(nb):
+            base = b * 6 * Cd
+            for k in (3, 77):           # y channels x 64 (shift and 1 + scale), divided out of the consumers' columns
+                tab[:, base + k] *= 64; tab[:, base + Cd + k] *= 64; Wv[b][:, k] /= 64
+                tab[:, base + 3 * Cd + k] *= 64; tab[:, base + 4 * Cd + k] *= 64; W1[b][:, k] /= 64; W3[b][:, k] /= 64
+            Wv[b][5] *= 64              # a value channel and a hidden channel x 64
+            W3[b][9] *= 64
+    tab = tab.cuda()
+    consts = torch.tensor([[7.0, 6.0, 0.0, 0.0] for b in range(nb)]).cuda()
+    wstack = torch.cat([Wv, W1, W3], 1).contiguous().cuda()
     out = torch.empty(nrows, nb, 8, device="cuda")
-    ops.check(ops._lib.init().pd_dit_bounds(ops.ptr(tab), nrows, tab.shape[1], nb, Cd, ops.ptr(consts), ops.ptr(out), ops.stream()), "b")
+    vh = torch.empty(nrows, nb, 2, device="cuda")
+    ops.check(ops._lib.init().pd_dit_bounds(ops.ptr(tab), nrows, tab.shape[1], nb, Cd, hidden, ops.ptr(consts), ops.ptr(wstack), ops.ptr(vh),
+                                            ops.ptr(out), ops.stream()), "b")
     out = out.cpu()
     x = torch.randn(4096, Cd, generator=g(5)) * torch.exp(torch.randn(4096, 1, generator=g(6)))     # arbitrary activations
+    x[:64, 3] += 50.0                                                                                # ... some with a dominant channel
     xh = torch.nn.functional.layer_norm(x, (Cd,))
     t = tab.cpu()
     for r in range(nrows):
@@ -222,7 +238,7 @@ def test_dit_bounds_hold_and_are_not_wild(medium_block_inputs=None):
             for val, bound, name in ((y1, got[3], "y"), (y2, got[4], "y'"), (v, got[2], "v"), (h, got[5], "h")):
                 m = float(val.abs().max())
                 assert m <= float(bound), (name, m, float(bound))
-                assert float(bound) <= m * (2 ** 7 if name != "h" else 2 ** 12), (name, m, float(bound))
+                assert float(bound) <= m * (2 ** 7 if name != "h" else 2 ** 11), (name, m, float(bound), outliers)
 
 
 def test_bounds_on_the_medium_model():

@@ -226,9 +226,12 @@ def main_g9(RefPhysDock, RefConfig, ref_model_module):
         # 6 gamma_min and the relaxation below - from the reference (seed-stored; ~20 minutes of 8 host cores)
         ("cfg1_b64_40", cfg1_batch(0), 64, 40, True),
         # cfg2 (T = 512 / A = 4096) at a chip-filling sample count: the fp16-format kernels at nq = nk = 4096 and M = 65536 rows
-        ("cfg2_b16", cfg2_batch(0), 16, 6, False),
-        # trained-model-like OUTLIER weights (params.outlier_state_dict: 1 % of norm gains, projection rows and AdaLN rows
-        # x 30-100): the static magnitude bounds of the two-part fp16 format must hold and must not cost the precision
+        # (10 steps, as for cfg2 above: after 6 steps of the p = 1000 schedule |x| is still ~700 A - one fp32 ulp 6e-5 A - and the
+        #  distance between ANY two fp32 implementations is ulp-dominated: 1.06e-3 A measured against a 6-step fixture)
+        ("cfg2_b16", cfg2_batch(0), 16, 10, False),
+        # trained-model-like OUTLIER CHANNELS (params.outlier_state_dict: 1 % of the value / SwiGLU / query-key channels, norm
+        # gains and AdaLN rows x 32-64, divided out of their consumers - the function is preserved, the operands of the
+        # projections are not): the static magnitude bounds of the two-part fp16 format must hold and must not cost the precision
         ("cfg1_outlier", cfg1_batch(0), 8, 10, False),
     )
     seed_stored = ("cfg1_b32", "cfg1_b64_40", "cfg2_b16", "cfg1_outlier")
