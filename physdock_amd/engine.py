@@ -786,12 +786,15 @@ class Engine:
         nb_a, nb_t = dt.no_blocks_atom, dt.no_blocks_dit
         bnd_a = None if "atom" in self.f16_off else prep["bnd_atom"]
         bnd_t = None if "token" in self.f16_off else prep["bnd_token"]
+
+        def boff(t, n):                       # address of a bound row, or None for a family that runs without bounds (bf16 x 6)
+            return None if t is None else off(t, n)
         if (prep["ps_atom"] or prep["ps_token"]) and prep["B"] != B:
             raise RuntimeError("prepare_dit pre-scaled the hoisted biases for a different sample count")
         psa, pst = prep["ps_atom"], prep["ps_token"]
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_encoder.blocks.{b}", ba, B, A, Ca, off(prep["atom_bias"], b * fa_stride),
-                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + b) * 8), bias_prescale=psa,
+                           tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar, bnd=boff(bnd_a, (row * 2 * nb_a + b) * 8), bias_prescale=psa,
                            rows_alloc=RA)
         u = self.lws("dit_u", RA, Cs)
         self.lin(ba, "dit.linear_downscale", RA, out=u, act=ACT_SILU)
@@ -799,7 +802,7 @@ class Engine:
         ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs), B, A, T, Cs, sp), "pool")
         for b in range(nb_t):
             self.dit_block(f"dit.token_dit.blocks.{b}", bs, B, T, Cs, off(prep["token_bias"], b * ft_stride),
-                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr, bnd=off(bnd_t, (row * nb_t + b) * 8), bias_prescale=pst,
+                           tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr, bnd=boff(bnd_t, (row * nb_t + b) * 8), bias_prescale=pst,
                            rows_alloc=RT)
         us = self.lws("dit_us", RT, Ca)
         self.lin(bs, "dit.linear_upscale", RT, out=us)
@@ -807,7 +810,7 @@ class Engine:
         for b in range(nb_a):
             self.dit_block(f"dit.atom_dit_decoder.blocks.{b}", ba, B, A, Ca,
                            off(prep["atom_bias"], (nb_a + b) * fa_stride), tab_a, row * lda_ + (nb_a + b) * 6 * Ca, lda_,
-                           per_sample, Ar, bnd=off(bnd_a, (row * 2 * nb_a + nb_a + b) * 8), bias_prescale=psa, rows_alloc=RA)
+                           per_sample, Ar, bnd=boff(bnd_a, (row * 2 * nb_a + nb_a + b) * 8), bias_prescale=psa, rows_alloc=RA)
         cs_b = ops.ptr(scal["c_skip"]) if per_sample else None
         co_b = ops.ptr(scal["c_out"]) if per_sample else None
         ops.check(L.pd_denoise(ops.ptr(ba), ops.ptr(x_hat), ops.ptr(P["dit.norm_r.weight"]), ops.ptr(P["dit.norm_r.bias"]),

@@ -18,12 +18,38 @@ b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()
 with torch.no_grad():
     c32 = orc.diffusion_conditioning(P, batch)
     c64 = orc.diffusion_conditioning(P64, b64)
-model = PhysDock(cfg); model.load_state_dict(P); model = model.cuda().eval()
-eng = model.engine(torch.device("cuda", 0))
-hip = eng.conditioning(model._prepare_batch({k: v.cuda() for k, v in batch.items()}))
-print("conditioning trunk, cfg1, medium, seeded weights: max |x - x_f64| / max |x_f64|")
-for n, h, a, r in zip("a ap s z".split(), hip, c32, c64):
-    e_hip = float((h.cpu().double().reshape(r.shape) - r).abs().max() / r.abs().max())
-    e_cpu = float((a.double() - r).abs().max() / r.abs().max())
-    e_pair = float((h.cpu().reshape(a.shape) - a).abs().max() / a.abs().max())
-    print(f"  {n:3s} HIP fp32 vs f64: {e_hip:.2e}   CPU fp32 (oracle) vs f64: {e_cpu:.2e}   HIP vs CPU fp32: {e_pair:.2e}")
+from physdock_amd import ops
+
+
+def rel(u, v):
+    return float((u.double() - v.double()).abs().max() / v.double().abs().max())
+
+
+def rms(u, v):
+    return float(((u.double() - v.double()).pow(2).mean() / v.double().pow(2).mean()).sqrt())
+
+
+print("conditioning trunk, cfg1, medium, seeded weights: max |x - x_f64| / max |x_f64|  (rms error / rms value)")
+for n, a, r in zip("a ap s z".split(), c32, c64):
+    print(f"  {n:3s} CPU fp32 (oracle) vs f64: {rel(a, r):.2e} ({rms(a, r):.2e})")
+dbatch = {k: v.cuda() for k, v in batch.items()}
+hips = {}
+for mode, flags in (("f16x3", {}), ("bf16x6", dict(F16_GEMM=False, F16_ATTN=False)),
+                    ("fp32", dict(SPLIT_GEMM=False, SPLIT_ATTN=False, F16_GEMM=False, F16_ATTN=False))):
+    saved = {k: getattr(ops, k) for k in flags}
+    for k, v in flags.items():
+        setattr(ops, k, v)
+    try:
+        model = PhysDock(cfg); model.load_state_dict(P); model = model.cuda().eval()
+        eng = model.engine(torch.device("cuda", 0))
+        hip = [t.cpu().clone() for t in eng.conditioning(model._prepare_batch(dbatch))]
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)
+    hips[mode] = hip
+    for n, h, a, r in zip("a ap s z".split(), hip, c32, c64):
+        h = h.reshape(r.shape)
+        print(f"  {mode:7s} {n:3s} HIP vs f64: {rel(h, r):.2e} ({rms(h, r):.2e})   HIP vs CPU fp32: {rel(h, a):.2e} ({rms(h, a):.2e})")
+    del model
+for n, i in zip("a ap s z".split(), range(4)):
+    print(f"  {n:3s} HIP f16x3 vs HIP fp32: {rel(hips['f16x3'][i], hips['fp32'][i]):.2e} ({rms(hips['f16x3'][i], hips['fp32'][i]):.2e})")
