@@ -402,10 +402,15 @@ def main():
         logger.__exit__()
         with open(args.launch_log, "w") as f:
             json.dump(logger.log, f)
+    per_rank_s = [elapsed]
     if dist:
+        # every rank's own clock around the timed region, on rank 0's line: a straggler (a GPU that throttles, a slow xGMI gather) is
+        # visible in the first real multi-GPU run instead of hiding inside the maximum
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        td.all_gather(allt, t)
+        per_rank_s = [float(v) for v in allt]
+        elapsed = max(per_rank_s)
     assert torch.isfinite(x).all()
     if dist and rank == 0:      # the gathered blocks of the last call: every rank's poses arrived and the ranks' streams differ
         assert all(bool(torch.isfinite(t).all()) for t in gathered), "non-finite poses in a gathered rank block"
@@ -418,6 +423,7 @@ def main():
     out = {
         "metric": "poses/sec (whole node) at crop_size=256, atom_crop_size=2048",
         "value": value, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "per_rank_s": [round(v, 4) for v in per_rank_s],
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (fp16x2-split operands x3 MFMA / bf16x3-split x6 MFMA, fp32 accumulate)", "data": "synthetic",
         "arithmetic": "fp32 results; chip-filling contractions run on split operands with fp32 accumulation: where a rigorous "

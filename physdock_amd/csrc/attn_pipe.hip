@@ -506,9 +506,18 @@ bool raise_lds() {
                                LDS_BYTES) == hipSuccess;
 }
 
+// Short key ranges (<= PD_PIPE_NW4_MAXNK keys: token / triangle / MSA attention at 256 - 512 tokens) run on FOUR-wave blocks of 128
+// queries: a block lives for only four to eight key tiles, most of it prologue and tail, and twice as many independent blocks per CU
+// (four resident instead of two) fill each other's gaps; the K / V tiles are staged by both query blocks of a (sample, head).
+#ifndef PD_PIPE_NW4_MAXNK
+#define PD_PIPE_NW4_MAXNK 0
+#endif
 template <bool PRE, bool HASBIAS>
 void launch(const pd_attn_args* a, hipStream_t stream) {
-    if (a->nq > 128) {
+    if (a->nq > 128 && a->nk <= PD_PIPE_NW4_MAXNK) {
+        dim3 grid(a->nbatch, (a->nq + 127) / 128, a->nheads);
+        hipLaunchKernelGGL((attn_pipe_kernel<4, PRE, HASBIAS>), grid, dim3(256), LDS_BYTES, stream, *a);
+    } else if (a->nq > 128) {
         dim3 grid(a->nbatch, (a->nq + 255) / 256, a->nheads);
         hipLaunchKernelGGL((attn_pipe_kernel<8, PRE, HASBIAS>), grid, dim3(512), LDS_BYTES, stream, *a);
     } else {

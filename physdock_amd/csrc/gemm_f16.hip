@@ -750,6 +750,230 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
     }
 }
 
+
+// ---- wide rows, 64 x 64 wave units with a K-SPLIT TAIL (round 5): the head-norm / plain / gate-residual projections on the unit shape
+// that took the SwiGLU projection from 0.33 to 0.44 of the pipe (an A fragment pair feeds two column blocks, a W fragment pair two row
+// blocks: 12 MFMAs per 16-k step, per four ds_read_b128 and four 16-byte W requests - the 64 x 32 items issue the same requests per SIX).
+// N = 1536 is 24 such units for sixteen waves - one and a half rounds, which is why round 4 left q | k | v on 64 x 32 items.  Here every
+// wave takes full units while whole rounds of sixteen last and the remaining EIGHT units are shared by wave pairs (w, w + 8): each wave
+// contracts one K half (256) of the pair's unit, the partial tiles meet in LDS - in the A tile's space, which is dead once every wave has
+// left its main loop - and each wave of a pair finishes one 32-column half of the unit (sum of two numbers: order-free, bit-reproducible).
+// Every wave issues the same MFMA count (N = 1536: 576, N = 512: 192).  Units: N / 64 = 16 f + {0, 8}.
+template <int PRO, int EPI>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gemm_f16_wrows_ks_kernel(const pd_gemm_args p) {
+    constexpr int BM = 64, KC = 512, PART = BM * WLP, NKS = KC / 16, NWV = 16, RPP = 4 * NWV;
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float a_s = pd_pow2_scale(*p.a_amax);
+    const float inv_a_s = 1.0f / a_s;
+    const int ntiles = p.M / BM, ncb = p.N >> 5, nunits = ncb >> 1;
+    const int nfull = (nunits >> 4) << 4;                            // units taken whole, sixteen per round
+    const bool tail = nunits > nfull;                                // eight more, one per wave pair
+    const int wpart = ncb * NKS * 1024;
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W2), 0, 2 * wpart, 0x00020000);
+    const int loff = lane * 16;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * BM;
+        if constexpr (PRO == 3) {
+            const int q = tid & 15;
+#pragma unroll 1
+            for (int r = tid >> 4; r < BM; r += RPP) {
+                const _Float16* a2 = reinterpret_cast<const _Float16*>(p.A2) + (long long)(row0 + r) * KC;
+                f16x8 c[NPARTS][4];
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c[part][i] = *reinterpret_cast<const f16x8*>(a2 + (long long)part * p.M * KC + 8 * (q + 16 * i));
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + part * PART + r * WLP + 8 * (q + 16 * i)) = c[part][i];
+            }
+        } else {   // sixteen threads (one DPP row) per row: statistics, LayerNorm / RMSNorm, modulation, operand scale, split - once
+            const int q = tid & 15;
+#pragma unroll 1
+            for (int r = tid >> 4; r < BM; r += RPP) {
+                const int m = row0 + r;
+                const float* xr = p.A + (long long)m * p.lda;
+                const int goff = PRO == 2 ? (m / p.pro_rows_per_group) * p.pro_gstride : 0;
+                f32x4 v[8];
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * (q + 16 * i));
+                    s1 += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+                }
+                auto row16 = [](float x) {
+                    x += pd_dpp<0xB1>(x); x += pd_dpp<0x4E>(x); x += pd_dpp<0x141>(x); x += pd_dpp<0x140>(x);
+                    return x;
+                };
+                s1 = row16(s1);
+                float mean = p.stats_inline == 2 ? s1 * (1.0f / KC) : 0.f;
+                float sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+                sq = row16(sq);
+                const float rstd = rsqrtf(sq * (1.0f / KC) + p.stats_eps) * a_s;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = 4 * (q + 16 * i);
+                    const f32x4 gw = *reinterpret_cast<const f32x4*>(p.pro_w + goff + c), gb = *reinterpret_cast<const f32x4*>(p.pro_b + goff + c);
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (v[i][e] - mean) * rstd * gw[e] + gb[e] * a_s;
+                    const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]);
+                    *reinterpret_cast<u32x2*>(lds + r * WLP + c) = u32x2{p0.h, p1.h};
+                    *reinterpret_cast<u32x2*>(lds + PART + r * WLP + c) = u32x2{p0.l, p1.l};
+                }
+            }
+        }
+        lds_barrier();
+        const _Float16* abase = lds + l31 * WLP + 8 * hh;
+        f16x8 wf[2][2][NPARTS];                                          // [ring buffer][column block of the unit][part]
+        auto wload = [&](int cu, int buf, int ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int so = ((cu * 2 + j) * NKS + ks) * 1024;
+                wf[buf][j][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so, 0));
+                wf[buf][j][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, loff, so + wpart, 0));
+            }
+        };
+        f32x16 acc[2][2];
+        auto zero = [&]() {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        };
+        auto kstep = [&](int buf, int ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 32 * i * WLP + 16 * ks);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART + 32 * i * WLP + 16 * ks);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 t = acc[i][j];
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[buf][j][1], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[buf][j][0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[buf][j][0], t, 0, 0, 0);
+                    acc[i][j] = t;
+                }
+            }
+        };
+        // k-steps ks0 .. ks0 + n (n even) of unit cu against the resident rows; buffer 0 holds step ks0 on entry; the last step's request
+        // is the FIRST step of the wave's next segment (ncu, nks0), if any - the ring runs on across units
+        auto contract = [&](int cu, int ks0, int n, bool more, int ncu, int nks0) {
+#pragma unroll 1
+            for (int ks = ks0; ks < ks0 + n; ks += 2) {
+                wload(cu, 1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(0, ks);
+                if (ks + 2 < ks0 + n) wload(cu, 0, ks + 2);
+                else if (more) wload(ncu, 0, nks0);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(1, ks + 1);
+            }
+        };
+        auto consts = [&](int col0, int nj, float (&c0)[2], float (&c1)[2], float (&cs)[2]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n0 = col0 + 32 * j + l31;
+                const bool on = j < nj;
+                c0[j] = (on && p.bias) ? p.bias[n0] : 0.f;
+                c1[j] = 1.f;
+                if constexpr (EPI == EPI_HN) c1[j] = on ? p.hn_w[(n0 / p.hn_split) * 32 + l31] : 1.f;
+                if constexpr (EPI == EPI_GATERES)
+                    c1[j] = (on && p.mul) ? p.mul[(long long)(row0 / p.mul_rows_per_group) * p.mul_gstride + n0] : 1.f;
+                cs[j] = on ? p.w_inv[n0] * inv_a_s : 0.f;
+            }
+        };
+        const int pr = wave & 7, kh = wave >> 3;                          // tail: pair and K half
+        const int tcu = nfull + pr;
+        int cu = wave;
+        if (cu < nfull) wload(cu, 0, 0);
+        else if (tail) wload(tcu, 0, kh * (NKS / 2));
+        for (; cu < nfull; cu += NWV) {
+            zero();
+            const bool more_full = cu + NWV < nfull;
+            contract(cu, 0, NKS, more_full || tail, more_full ? cu + NWV : tcu, more_full ? 0 : kh * (NKS / 2));
+            float c0[2], c1[2], cs[2];
+            consts(cu * 64, 2, c0, c1, cs);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= cs[j];
+            epilogue<EPI, 2, 2>(p, acc, c0, c1, row0, cu * 64, 0, 0, l31, hh);
+        }
+        if (tail) {
+            zero();
+            contract(tcu, kh * (NKS / 2), NKS / 2, false, 0, 0);
+        }
+        lds_barrier();                               // every wave has left its main loop: the A tile's space is free
+        if (tail) {
+            // the partial tile of the column block the PARTNER finishes goes to this wave's 8 KB slot: [row block][register quad][lane]
+            // (kh as a compile-time constant: a run-time index into the accumulator array would move it to scratch memory)
+            auto exchange = [&](auto khc) {
+                constexpr int KH = decltype(khc)::value;
+                float* xch = reinterpret_cast<float*>(lds) + wave * 2048;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x16& t = acc[i][1 - KH];
+                        *reinterpret_cast<f32x4*>(xch + ((i * 4 + g) * 64 + lane) * 4) = f32x4{t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+                    }
+                lds_barrier();
+                const float* xin = reinterpret_cast<const float*>(lds) + (wave ^ 8) * 2048;
+                float c0[2], c1[2], cs[2];
+                consts(tcu * 64 + 32 * KH, 1, c0, c1, cs);
+                f32x16 fin[2][1];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(xin + ((i * 4 + g) * 64 + lane) * 4);
+                        const f32x16& t = acc[i][KH];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) fin[i][0][4 * g + e] = (t[4 * g + e] + o[e]) * cs[0];
+                    }
+                const float d0[1] = {c0[0]}, d1[1] = {c1[0]};
+                epilogue<EPI, 2, 1>(p, fin, d0, d1, row0, tcu * 64 + 32 * KH, 0, 0, l31, hh);
+            };
+            if (kh == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
+            lds_barrier();                           // the slots are read: the next tile's rows may overwrite them
+        }
+    }
+}
+
+template <int PRO, int EPI>
+int run_f16_wrows_ks(int op, const pd_gemm_args* p, hipStream_t s) {
+    auto k = gemm_f16_wrows_ks_kernel<PRO, EPI>;
+    if (op == 1)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, WROWS_LDS_BYTES) == hipSuccess
+                   ? PD_OK : PD_ERR_LAUNCH;
+    const int ntiles = p->M / 64;
+    hipLaunchKernelGGL(k, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(1024), WROWS_LDS_BYTES, s, *p);
+    return pd_check_launch();
+}
+
+// the K-split-tail kernel takes a launch when the row tiles fill the chip by themselves and N is 16 f + {0, 8} units of 64 columns
+#ifndef PD_F16_WROWS_KS
+#define PD_F16_WROWS_KS 0      // measured slower (round 5: q | k | v 104 -> 127 us, linear_o 35 -> 49 us, 157.9 -> 147.5 poses/s): lab knob
+#endif
+inline bool wrows_ks_shape(const pd_gemm_args* p) {
+    const int units = p->N / 64;
+    return PD_F16_WROWS_KS && p->N % 64 == 0 && (units % 16 == 0 || units % 16 == 8) && p->M / 64 >= 256;
+}
+
 // lab knobs of the column split: most blocks per row tile, fewest work items a block may be left with
 #ifndef PD_F16_WROWS_MAX_SPLIT
 #define PD_F16_WROWS_MAX_SPLIT 4
@@ -789,6 +1013,19 @@ int dispatch_f16_wrows(int op, int pro, int epi, const pd_gemm_args* p, hipStrea
         if (pro == 1 && epi == EPI_PLAIN) r = run_f16_wrows<1, EPI_PLAIN, 2, 2, 2, 12>(op, p, s);
         if (pro == 2 && epi == EPI_PLAIN) r = run_f16_wrows<2, EPI_PLAIN, 2, 2, 2, 12>(op, p, s);
         if (op != 1 || r != PD_OK) return r;
+    }
+#endif
+#if PD_F16_WROWS_KS
+    if (op == 1 || wrows_ks_shape(p)) {       // 64 x 64 units with a K-split tail (chip-filling launches; set-up covers every form)
+        int r = PD_ERR_UNSUPPORTED;
+        if (pro == 1 && epi == EPI_HN) r = run_f16_wrows_ks<1, EPI_HN>(op, p, s);
+        if (pro == 2 && epi == EPI_HN) r = run_f16_wrows_ks<2, EPI_HN>(op, p, s);
+        if (pro == 1 && epi == EPI_PLAIN) r = run_f16_wrows_ks<1, EPI_PLAIN>(op, p, s);
+        if (pro == 2 && epi == EPI_PLAIN) r = run_f16_wrows_ks<2, EPI_PLAIN>(op, p, s);
+        if (pro == 3 && epi == EPI_GATERES) r = run_f16_wrows_ks<3, EPI_GATERES>(op, p, s);
+        if (pro == 3 && epi == EPI_PLAIN) r = run_f16_wrows_ks<3, EPI_PLAIN>(op, p, s);
+        if (op != 1 && r != PD_ERR_UNSUPPORTED) return r;
+        if (op == 1 && r != PD_OK && r != PD_ERR_UNSUPPORTED) return r;
     }
 #endif
     if (pro == 1 && epi == EPI_HN) return run_f16_wrows<1, EPI_HN, 2, 1>(op, p, s);
