@@ -254,6 +254,9 @@ typedef struct pd_attn_args {
        takes the bias tile as the INITIAL VALUE of the score accumulator - no bias add.  0 with a bias: the launch stays on
        attn_parts_kernel (csrc/attn_f16.hip), which adds an unscaled bias; < 0: keep the launch on attn_parts_kernel (A/B runs).   */
     float bias_prescale;
+    /* ABI 8: rows of one part plane of O2 when the launch covers only a slice of the samples that share the O2 buffer (the low parts
+       sit o2_rows * nheads * 32 elements behind the high parts); 0: nbatch * nq.  pd_attention sets it for its own sub-launches.    */
+    long long o2_rows;
 } pd_attn_args;
 /* Launches that cannot fill the chip (nbatch * nheads * ceil(nq/128) < 512 blocks) with a long key range are split into
  * up to 8 key chunks when ws holds nsplit * nbatch * nq * nheads * 34 floats; a second kernel merges the chunks. */
@@ -262,6 +265,13 @@ int pd_attention(const pd_attn_args* args, void* stream);
  * a key-split launch; 1000 + waves for attn_split_kernel<waves>, 2000 + waves for attn_parts_kernel<waves, 2>, 2000 + 4 +
  * 100 * nsplit for a key-split launch on attn_parts_kernel<4, 2, false, true> (profiling) */
 int pd_attention_variant(const pd_attn_args* args);
+/* ABI 8 (lab builds with -DPD_ATTN_TAIL=1 only; the shipped library returns 0: measured no gain): a chip-filling launch of the
+ * pipelined kernel (variant 3000 +) whose last round of 256-query blocks would be less than half
+ * full - 20 samples x 4 heads x 2048 atoms are 640 blocks for 512 slots: the second round runs on a quarter of the chip - hands the
+ * samples of that round to the key-split form of attn_parts_kernel instead (their key range cut in `*nsplit` chunks, merged by the
+ * combine kernel), so that the tail costs a fraction of a round.  Needs ws (nsplit * tail samples * nq * nheads * 34 floats).  Returns
+ * the number of tail samples pd_attention would treat that way (0: none) and the chunk count.                                    */
+int pd_attention_tail(const pd_attn_args* args, int* nsplit);
 /* log2 of the power of two a bias producer folds into out_scale for f16x3 launches with bias_prescale (ABI 7): the q and k operand
  * scales of the fp16 format for these bounds (scale = 1/sqrt(32)); host arithmetic identical to the kernel's.  3000 + waves =
  * attn_pipe_kernel<waves, ., .> in pd_attention_variant's numbering.                                                        */

@@ -75,6 +75,7 @@ class AttnArgs(C.Structure):
         ("f16x3", C.c_int), ("f16_q_amax", C.c_float), ("f16_k_amax", C.c_float), ("f16_v_amax", C.c_float), ("f16_amax", _fp), ("O2", _fp),
         ("K2", _fp), ("V2", _fp), ("kv2_bs", C.c_longlong), ("kv2_ss", C.c_longlong),      # ABI 6
         ("bias_prescale", C.c_float),                                                       # ABI 7
+        ("o2_rows", C.c_longlong),                                                          # ABI 8
     ]
 
 
@@ -149,6 +150,7 @@ def _declare(L):
     sig("pd_pair_bias", p, p, p, p, p, f, f, p, i, i, i, i, i, i, f, p)
     sig("pd_attention", C.POINTER(AttnArgs), p)
     sig("pd_attention_variant", C.POINTER(AttnArgs))
+    sig("pd_attention_tail", C.POINTER(AttnArgs), C.POINTER(C.c_int))
     sig("pd_attention_bias_prescale_log2", f, f, f)
     sig("pd_graph_begin", p)
     sig("pd_graph_end", p, C.POINTER(C.c_void_p))

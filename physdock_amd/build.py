@@ -71,6 +71,8 @@ def compile_cmd(src, out, mode=("-c",)):
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_ATTN_NOSPLIT_BLOCKS") and base == "attention.hip":     # lab: block count from which a launch is not key-split
         cmd[1:1] = ["-DPD_ATTN_NOSPLIT_BLOCKS=" + os.environ["PD_ATTN_NOSPLIT_BLOCKS"]]
+    if os.environ.get("PD_ATTN_TAIL") and base == "attention.hip":     # lab: 0 = no key-split tail round
+        cmd[1:1] = ["-DPD_ATTN_TAIL=" + os.environ["PD_ATTN_TAIL"]]
     if os.environ.get("PD_ATTN_MIN_WAVES") and base == "attention.hip":     # lab: query waves from which the split-operand kernels take a launch
         cmd[1:1] = ["-DPD_ATTN_MIN_WAVES=" + os.environ["PD_ATTN_MIN_WAVES"]]
     if os.environ.get("PD_ATTN_LAZY") and base == "attn_f16.hip":     # lab: lazy rescale of the attention accumulator (threshold in log2 units)

@@ -251,7 +251,19 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const pd_attn_args p)
         L += ml[1] * w;
         acc += *reinterpret_cast<const f32x4*>(p.ws + (((long long)s * p.nbatch + b) * p.nq + q) * C + h * 32 + d4 * 4) * w;
     }
-    *reinterpret_cast<f32x4*>(p.O + (long long)b * p.o_bs + (long long)q * p.o_ss + h * 32 + d4 * 4) = acc * (1.0f / L);
+    const f32x4 o = acc * (1.0f / L);
+    if (p.O2) {
+        // the split output of the fp16-format kernels (pd_gemm_args.A2): o times the power of two of the v bound, two fp16 parts
+        const float sv = pd_pow2_scale(p.f16_amax ? p.f16_amax[2] : p.f16_v_amax);
+        const long long rows = p.o2_rows > 0 ? p.o2_rows : (long long)p.nbatch * p.nq;
+        unsigned short* op = reinterpret_cast<unsigned short*>(p.O2) + ((long long)b * p.nq + q) * C + h * 32 + d4 * 4;
+        const pd_parts2 p0 = pd_split2h(o[0] * sv, o[1] * sv), p1 = pd_split2h(o[2] * sv, o[3] * sv);
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2_*>(op) = u32x2_{p0.h, p1.h};
+        *reinterpret_cast<u32x2_*>(op + rows * C) = u32x2_{p0.l, p1.l};
+        return;
+    }
+    *reinterpret_cast<f32x4*>(p.O + (long long)b * p.o_bs + (long long)q * p.o_ss + h * 32 + d4 * 4) = o;
 }
 
 }  // namespace
@@ -307,6 +319,36 @@ PD_EXPORT int pd_attention_variant(const pd_attn_args* a) {
     return (wide && a->nq >= 512 && (long long)a->nbatch * a->nheads * ((a->nq + 255) / 256) >= 1024) ? 8 : 4;
 }
 
+// Tail round of a pipelined launch (see the header): samples of a last round of 256-query blocks that would fill at most half of the
+// 512 block slots (two blocks per CU).  Their attention runs key-split on attn_parts_kernel<4, 2, ., true> + attn_combine_kernel.
+#ifndef PD_ATTN_TAIL
+#define PD_ATTN_TAIL 0      // measured: no gain (round 5, NOTES.md: a quarter-full last round costs ~0.15 of a round, not one) - lab knob
+#endif
+static int attn_tail(const pd_attn_args* a, int* nsplit) {
+    if (!PD_ATTN_TAIL || !a->ws || a->nq <= 128) return 0;
+    const int bps = a->nheads * ((a->nq + 255) / 256);            // blocks per sample
+    if (bps > 256 || 512 % bps) return 0;
+    const int per = 512 / bps;                                    // samples per full round
+    const int bt = a->nbatch % per;
+    if (a->nbatch < per || bt == 0 || bt * bps > 256) return 0;
+    const int nit = (a->nk + KT - 1) / KT;
+    int s = 512 / (bt * bps);
+    s = s < 4 ? s : 4;
+    s = s < nit / 4 ? s : nit / 4;
+    while (s > 1 && a->ws_bytes < 4ll * s * bt * a->nq * a->nheads * 34) --s;
+    if (s < 2) return 0;
+    *nsplit = s;
+    return bt;
+}
+
+PD_EXPORT int pd_attention_tail(const pd_attn_args* a, int* nsplit) {
+    int ns = 0;
+    if (!a || pd_attention_variant(a) < 3000) return 0;
+    const int bt = attn_tail(a, &ns);
+    if (nsplit) *nsplit = bt ? ns : 0;
+    return bt;
+}
+
 PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
     if (!a || !a->Q || ((!a->K || !a->V) && !(a->K2 && a->V2)) || (!a->O && !a->O2) || (!a->K2) != (!a->V2)) return PD_ERR_ARG;
     if (a->nq <= 0 || a->nk <= 0 || a->nbatch <= 0 || a->nheads <= 0) return PD_ERR_ARG;
@@ -330,7 +372,36 @@ PD_EXPORT int pd_attention(const pd_attn_args* a, void* stream) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s);
         return pd_check_launch();
     }
-    if (variant >= 3000) return pd_attention_pipe_try(a, stream, 0);
+    if (variant >= 3000) {
+        int ns = 0;
+        const int bt = attn_tail(a, &ns);
+        if (bt == 0) return pd_attention_pipe_try(a, stream, 0);
+        if (((uintptr_t)a->ws & 15) != 0) return PD_ERR_UNSUPPORTED;
+        // full rounds on the pipelined kernel, the samples of the last one key-split: same buffers, disjoint sample ranges
+        const int n1 = a->nbatch - bt;
+        const long long C = (long long)a->nheads * 32, rows = (long long)a->nbatch * a->nq;
+        pd_attn_args m = *a;
+        m.nbatch = n1;
+        m.o2_rows = a->O2 ? rows : 0;
+        int r = pd_attention_pipe_try(&m, stream, 0);
+        if (r != PD_OK) return r;
+        pd_attn_args t = *a;
+        t.nbatch = bt; t.nsplit = ns; t.o2_rows = a->O2 ? rows : 0;
+        t.Q = a->Q + n1 * a->q_bs;
+        if (a->K) t.K = a->K + n1 * a->k_bs;
+        if (a->V) t.V = a->V + n1 * a->v_bs;
+        if (a->O) t.O = a->O + n1 * a->o_bs;
+        if (a->O2) t.O2 = reinterpret_cast<unsigned short*>(a->O2) + n1 * a->nq * C;
+        if (a->K2) {
+            t.K2 = reinterpret_cast<const unsigned short*>(a->K2) + n1 * a->kv2_bs;
+            t.V2 = reinterpret_cast<const unsigned short*>(a->V2) + n1 * a->kv2_bs;
+        }
+        r = pd_attention_f16_split(&t, stream, 0);
+        if (r != PD_OK) return r;
+        const long long total = (long long)bt * a->nq * a->nheads * 8;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t);
+        return pd_check_launch();
+    }
     if (variant >= 1000) return pd_attention_split_try(a, stream, 0);
     if (variant > 100) {
         if (((uintptr_t)a->ws & 15) != 0) return PD_ERR_UNSUPPORTED;

@@ -231,6 +231,14 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         }
         if constexpr (NP == 2) {                           // undo the operand scales (exact), then the bias
             if (bias_wave) {
+                if constexpr (SPLIT) {
+                    // the key-split form also serves the tail round of a pipelined launch (pd_attention_tail), whose bias tiles were
+                    // produced times the product of the q and k operand scales: times c_s that is the plain bias again, exactly
+                    if (p.bias_prescale > 0.f) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) bf[g] *= c_s;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = __builtin_fmaf(s[r], c_s, bf[r >> 2][r & 3]);
             } else {
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
             // output already split for the projection that follows (pd_gemm_args.A2): o times the V scale (|o| <= max|v|, the
             // same bound and hence the same power of two the GEMM derives from f16_amax[2]) is exactly O' / l'
             const float inv = 1.0f / l;
-            const long long rows = (long long)p.nbatch * p.nq, C = (long long)p.nheads * 32;
+            const long long rows = p.o2_rows > 0 ? p.o2_rows : (long long)p.nbatch * p.nq, C = (long long)p.nheads * 32;
             unsigned short* op = reinterpret_cast<unsigned short*>(p.O2) + ((long long)b * p.nq + query) * C + h * 32 + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -388,13 +396,17 @@ void launch(const pd_attn_args* a, hipStream_t stream) {
 // to a->ws; the caller runs attn_combine_kernel afterwards.  init_only: 1 raise the dynamic-LDS limit.
 extern "C" int pd_attention_f16_split(const pd_attn_args* a, void* stream, int init_only) {
     auto k = attn_parts_kernel<4, 2, false, true>;
+    auto kpre = attn_parts_kernel<4, 2, true, true>;          // K / V pre-split by the projection (the tail round of a DiT launch)
     if (init_only == 1)
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<2>()) == hipSuccess
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<2>()) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(kpre), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<2>()) == hipSuccess
                    ? PD_OK : PD_ERR_LAUNCH;
     if (!a->f16_amax && !(a->f16_q_amax > 0.f && a->f16_k_amax > 0.f && a->f16_v_amax > 0.f)) return PD_ERR_ARG;
-    if (a->O2 || a->K2 || a->nsplit < 2 || !a->ws) return PD_ERR_UNSUPPORTED;
+    if (a->nsplit < 2 || !a->ws) return PD_ERR_UNSUPPORTED;       // (O / O2 are the combine kernel's business: the chunks go to ws)
+    if (a->K2 && (!a->V2 || (((uintptr_t)a->K2 | (uintptr_t)a->V2) & 15) || a->kv2_ss % 8 || a->kv2_bs % 8)) return PD_ERR_ARG;
     dim3 grid(a->nbatch, ((a->nq + 127) / 128) * a->nsplit, a->nheads);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes<2>(), (hipStream_t)stream, *a);
+    if (a->K2) hipLaunchKernelGGL(kpre, grid, dim3(256), lds_bytes<2>(), (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes<2>(), (hipStream_t)stream, *a);
     return pd_check_launch();
 }
 

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         if (p.O2) {
             // output already split for the projection that follows (pd_gemm_args.A2): o times the V scale (|o| <= max|v|)
             const float inv = 1.0f / l;
-            const long long rows = (long long)p.nbatch * p.nq, C = (long long)p.nheads * 32;
+            const long long rows = p.o2_rows > 0 ? p.o2_rows : (long long)p.nbatch * p.nq, C = (long long)p.nheads * 32;
             unsigned short* op = reinterpret_cast<unsigned short*>(p.O2) + ((long long)b * p.nq + query) * C + h * 32 + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

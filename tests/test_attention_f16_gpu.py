@@ -342,3 +342,4 @@ def test_pipelined_kernel_ignores_the_padding_of_the_bias_buffer(B, H, nq, nk):
     assert torch.isfinite(outs[0]).all()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
