@@ -796,10 +796,20 @@ class Engine:
             self.dit_block(f"dit.atom_dit_encoder.blocks.{b}", ba, B, A, Ca, off(prep["atom_bias"], b * fa_stride),
                            tab_a, row * lda_ + b * 6 * Ca, lda_, per_sample, Ar, bnd=boff(bnd_a, (row * 2 * nb_a + b) * 8), bias_prescale=psa,
                            rows_alloc=RA)
-        u = self.lws("dit_u", RA, Cs)
-        self.lin(ba, "dit.linear_downscale", RA, out=u, act=ACT_SILU)
         bs = self.lws("dit_bs", RT, Cs)
-        ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs), B, A, T, Cs, sp), "pool")
+        Wd, bd, _, Kd, ldwd = P.linear("dit.linear_downscale")
+        tpb = batch.get("_pool_tpb", 0)
+        rc = -3
+        if ops.FUSED_POOL and ops.SPLIT_GEMM and tpb > 0 and Kd == Ca and ldwd == Ca:
+            # linear_downscale + SiLU + token mean + s in one launch: u [B A, 512] (268 MB at the benchmark shape) is never written
+            rc = L.pd_downscale_pool(ops.ptr(ba), P.w3(Wd, Kd).data_ptr(), ops.ptr(bd), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs),
+                                     B, A, T, Ca, Cs, tpb, sp)
+        if rc == -3:            # PD_ERR_UNSUPPORTED (other widths, a token of more than 64 atoms): projection, then the segment mean
+            u = self.lws("dit_u", RA, Cs)
+            self.lin(ba, "dit.linear_downscale", RA, out=u, act=ACT_SILU)
+            ops.check(L.pd_segment_pool(ops.ptr(u), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs), B, A, T, Cs, sp), "pool")
+        else:
+            ops.check(rc, "downscale_pool")
         for b in range(nb_t):
             self.dit_block(f"dit.token_dit.blocks.{b}", bs, B, T, Cs, off(prep["token_bias"], b * ft_stride),
                            tab_t, row * ldt_ + b * 6 * Cs, ldt_, per_sample, Tr, bnd=boff(bnd_t, (row * nb_t + b) * 8), bias_prescale=pst,

@@ -177,6 +177,9 @@ class PhysDock(nn.Module):
         ts = torch.zeros(chunk.shape[0] + 1, dtype=torch.int32, device=chunk.device)
         ts[1:] = torch.cumsum(chunk, 0).to(torch.int32)
         b["_tok_start"] = ts
+        # tokens per block of the fused downscale + pool kernel (csrc/pool.hip): as many consecutive tokens as are sure to hold <= 64 atoms
+        mc = int(chunk.max()) if chunk.numel() else 0
+        b["_pool_tpb"] = min(32, 64 // mc) if 0 < mc <= 64 else 0
         for k in ("ref_feat", "ref_pos", "a_mask", "ap_mask", "target_feat", "key_res_feat", "pocket_res_feat",
                   "token_bonds_feature", "rel_tok_feat", "msa_feat", "templ_feat", "z_mask", "x_gt", "is_ligand", "t_mask"):
             v = b[k]

@@ -256,6 +256,9 @@ SPLIT_ATTN = True
 
 #: two-part fp16 operands (three partial products) for attention launches whose caller supplies magnitude bounds (f16_amax=)
 F16_ATTN = True
+#: linear_downscale + SiLU + token pooling of the denoiser as one kernel (csrc/pool.hip); False: pd_gemm + pd_segment_pool
+FUSED_POOL = True
+
 #: chip-filling fp16-format launches on the software-pipelined kernel (csrc/attn_pipe.hip) when the bias was produced pre-scaled
 #: (bias_prescale=); False: attn_parts_kernel (csrc/attn_f16.hip) with an unscaled bias - callers must then not pre-scale
 PIPE_ATTN = True
