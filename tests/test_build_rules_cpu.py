@@ -23,6 +23,9 @@ MFMA_EXPECTED = {
     "attention.hip": ("v_mfma_f32_32x32x2_f32",),
     "gemm_stream.hip": ("v_mfma_f32_32x32x2_f32",),
     "gemm.hip": ("v_mfma_f32_32x32x2_f32",),
+    "pool.hip": ("v_mfma_f32_32x32x16_bf16",),
+    "gemm_f16.hip": ("v_mfma_f32_32x32x16_f16",),
+    "attn_pipe.hip": ("v_mfma_f32_32x32x16_f16",),
 }
 PACKED = re.compile(r"\bv_pk_(add|mul|fma)_f32\b")
 
