@@ -457,7 +457,7 @@ def main():
             summ = lt.summary()
         dom = summ[0]
         traffic, traffic_src = None, None
-        for tag in ("r04", "r03", "r02"):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same call (tools/collect_profiles.sh)
+        for tag in ("r05", "r04", "r03", "r02"):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same call (tools/collect_profiles.sh)
             pmc = os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")
             if os.path.exists(pmc) and args.cfg == "cfg1" and B == 64:
                 allrows = json.load(open(pmc))

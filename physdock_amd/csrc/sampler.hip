@@ -601,14 +601,15 @@ PD_EXPORT int pd_ligand_scatter(float* dst, const float* src, const float* lig, 
 // Stage 1 (dit_bounds_rows_kernel) fills vh[(row * nblocks + b) * 2 + ..] = [max_n R(Wv_n), max_n R'(W1_n) R'(W3_n)] by atomic
 // maxima; stage 2 (dit_bounds_kernel) adds the table-only bounds.  Both once per sample_diffusion call, outside the step loop.
 //
-// Stage 1: one workgroup per (DiT block, 64 weight rows); LANES are table rows (steps / samples, 64 per pass), so the sums over k
+// Stage 1: one workgroup per (DiT block, 32 weight rows); LANES are table rows (steps / samples, 64 per pass), so the sums over k
 // run in registers without a single cross-lane reduction: the k-chunk of the table is staged [vector][k][row] in LDS (lanes read
 // consecutive words), the weights of a row are wave-uniform loads.
-constexpr int BR_KC = 32, BR_ROWS = 16;       // k per LDS chunk; weight rows per wave
+constexpr int BR_KC = 32, BR_ROWS = 8;        // k per LDS chunk; weight rows per wave (a workgroup of four waves: 32 rows)
 __global__ __launch_bounds__(256) void dit_bounds_rows_kernel(const float* __restrict__ tab, int nrows, int ld, int nblocks, int C, int hidden,
                                                                const float* __restrict__ wstack, float* __restrict__ vh) {
-    __shared__ float lt[4][BR_KC][64];
-    const int b = blockIdx.x, n0 = blockIdx.y * 64, r0 = blockIdx.z * 64;
+    __shared__ float lt[4][BR_KC][64];                                // table chunk: [vector][k][table row]
+    __shared__ __attribute__((aligned(16))) float lw[4][3][BR_ROWS][BR_KC];      // weight chunk: [wave][Wv | W1 | W3][row][k]
+    const int b = blockIdx.x, n0 = blockIdx.y * (4 * BR_ROWS), r0 = blockIdx.z * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* tb = tab + (long long)b * 6 * C;
@@ -625,24 +626,33 @@ __global__ __launch_bounds__(256) void dit_bounds_rows_kernel(const float* __res
             const int col = (v == 0 ? 0 : v == 1 ? C : v == 2 ? 3 * C : 4 * C) + k0 + kk;
             lt[v][kk][r] = (r0 + r < nrows && k0 + kk < C) ? tb[(long long)(r0 + r) * ld + col] : 0.f;
         }
+        // ... and this wave's 3 x 16 weight rows of the chunk: coalesced 128-byte row segments; rows that do not exist read as zero
+        // (a zero row adds nothing to any sum), so the inner loop carries no conditionals
+        for (int i = lane; i < 3 * BR_ROWS * BR_KC; i += 64) {
+            const int kk = i % BR_KC, rw = (i / BR_KC) % BR_ROWS, m = i / (BR_KC * BR_ROWS);
+            const int n = nw0 + rw;
+            const bool ok = k0 + kk < C && (m == 0 ? n < C : n < hidden);
+            const long long row = m == 0 ? n : (m == 1 ? C + n : C + hidden + n);
+            lw[wave][m][rw][kk] = ok ? Wb[row * C + k0 + kk] : 0.f;
+        }
         __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < BR_KC; ++kk) {
-            const float s1 = lt[0][kk][lane], w1 = lt[1][kk][lane], s2 = lt[2][kk][lane], w2 = lt[3][kk][lane];
-            const int k = k0 + kk;
+#pragma unroll 2
+        for (int kk = 0; kk < BR_KC; kk += 4) {
+            float s1[4], w1[4], s2[4], w2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] = lt[0][kk + e][lane]; w1[e] = lt[1][kk + e][lane]; s2[e] = lt[2][kk + e][lane]; w2[e] = lt[3][kk + e][lane]; }
 #pragma unroll
             for (int i = 0; i < BR_ROWS; ++i) {
-                const int n = nw0 + i;                                 // wave-uniform
-                if (n < C) {
-                    const float w = Wb[(long long)n * C + k];
-                    const float t = w * w1;
-                    pv2[i] += t * t; pvs[i] += w * s1;
-                }
-                if (n < hidden) {
-                    const float wa = Wb[(long long)(C + n) * C + k], wb = Wb[(long long)(C + hidden + n) * C + k];
-                    const float ta = wa * w2, tb2 = wb * w2;
-                    pa2[i] += ta * ta; pas[i] += wa * s2;
-                    pb2[i] += tb2 * tb2; pbs[i] += wb * s2;
+                // broadcast reads: every lane the same 16 bytes
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&lw[wave][0][i][kk]);
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(&lw[wave][1][i][kk]);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(&lw[wave][2][i][kk]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = wv[e] * w1[e], ta = wa[e] * w2[e], tb2 = wb[e] * w2[e];
+                    pv2[i] = __builtin_fmaf(t, t, pv2[i]);   pvs[i] = __builtin_fmaf(wv[e], s1[e], pvs[i]);
+                    pa2[i] = __builtin_fmaf(ta, ta, pa2[i]);  pas[i] = __builtin_fmaf(wa[e], s2[e], pas[i]);
+                    pb2[i] = __builtin_fmaf(tb2, tb2, pb2[i]); pbs[i] = __builtin_fmaf(wb[e], s2[e], pbs[i]);
                 }
             }
         }
@@ -699,7 +709,7 @@ PD_EXPORT int pd_dit_bounds(const float* tab, int nrows, int ld, int nblocks, in
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(vh, 0, sizeof(float) * 2 * (size_t)nrows * nblocks, s) != hipSuccess) return PD_ERR_LAUNCH;
     const int nmax = C > hidden ? C : hidden;
-    hipLaunchKernelGGL(dit_bounds_rows_kernel, dim3(nblocks, (nmax + 63) / 64, (nrows + 63) / 64), dim3(256), 0, s, tab, nrows, ld, nblocks, C,
+    hipLaunchKernelGGL(dit_bounds_rows_kernel, dim3(nblocks, (nmax + 4 * BR_ROWS - 1) / (4 * BR_ROWS), (nrows + 63) / 64), dim3(256), 0, s, tab, nrows, ld, nblocks, C,
                        hidden, wstack, vh);
     hipLaunchKernelGGL(dit_bounds_kernel, dim3(nblocks, nrows), dim3(256), 0, s, tab, ld, nblocks, C, consts, vh, out);
     return pd_check_launch();
