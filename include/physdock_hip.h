@@ -302,10 +302,11 @@ int pd_segment_pool(const float* u, const int* tok_start, const float* add, floa
 int pd_unpool_add(float* ba, const float* us, const long long* a2t, int B, int A, int T, int C, void* stream);
 /* pd_downscale_pool (ABI 8): linear_downscale + SiLU + token mean pooling + s of the denoiser in one launch (reference
  * layers/transformers.py:205-212; csrc/pool.hip): out[b,t,:] = sum_{atoms l of t} silu(W ba[b,l,:] + bias) / (n_t + 1e-3) + add[t,:].
- * ba [B][A][128]; W3 = the three bf16 parts of W [N][128], fragment-major (packing.split3_bf16); tok_start [T + 1]; tpb tokens per
- * block (1..32) with the caller's guarantee that tpb consecutive tokens hold at most 64 atoms.  PD_ERR_UNSUPPORTED: other shapes.  */
-int pd_downscale_pool(const float* ba, const void* W3, const float* bias, const int* tok_start, const float* add, float* out,
-                      int B, int A, int T, int Cin, int N, int tpb, void* stream);
+ * ba [B][A][128]; W2 / w_inv = the two fp16 parts of W [N][128] (fragment-major) and its inverse row scales (packing.split2_f16) -
+ * the A operand's power-of-two scale is the block's own: the maximum of the tile it stages; tok_start [T + 1]; tpb tokens per block
+ * (1..32) with the caller's guarantee that tpb consecutive tokens hold at most 64 atoms.  PD_ERR_UNSUPPORTED: other shapes.        */
+int pd_downscale_pool(const float* ba, const void* W2, const float* w_inv, const float* bias, const int* tok_start, const float* add,
+                      float* out, int B, int A, int T, int Cin, int N, int tpb, void* stream);
 int pd_gather_rows_add(float* y, const float* x, const long long* idx, int R, int C, void* stream);
 int pd_axpby(float* out, const float* a, float sa, const float* b, const float* sb_ptr, float sb, long long n, void* stream);
 /* pd_template_feat  : templ_feat [T,T,no_bins+1] = [distogram bins of the pseudo-beta distance | mask] * mask, mask = z_mask *

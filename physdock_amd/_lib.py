@@ -163,7 +163,7 @@ def _declare(L):
     sig("pd_pair_init_z", p, p, p, p, p, p, p, p, p, p, p, i, i, p)
     sig("pd_segment_pool", p, p, p, p, i, i, i, i, p)
     sig("pd_unpool_add", p, p, p, i, i, i, i, p)
-    sig("pd_downscale_pool", p, p, p, p, p, p, i, i, i, i, i, i, p)
+    sig("pd_downscale_pool", p, p, p, p, p, p, p, i, i, i, i, i, i, p)
     sig("pd_gather_rows_add", p, p, p, i, i, p)
     sig("pd_axpby", p, p, f, p, p, f, ll, p)
     sig("pd_template_mask", p, p, p, p, i, i, p)

@@ -2,9 +2,11 @@
 //     bs[b, t, :] = ( sum_{atoms l of token t} silu(W ba[b, l, :] + bias) ) / (n_t + 1e-3) + s[t, :]
 // Round 5.  The two-launch form writes u = silu(W ba + b) - [B A, 512] fp32, 268 MB at the benchmark shape - and
 // reads it back for the segment mean: 135 + 46 us per step, store-bound.  Here a block owns the atoms of `tpb` consecutive tokens of
-// one sample (at most 64 rows: the host picks tpb = 64 / max atoms per token), keeps them - split once into three bf16 parts, the
-// residual stream has no static magnitude bound, so this is the bound-free bf16 x 6 format of gemm_split.hip - in LDS, and every wave
-// walks 32-column blocks of W: 96 MFMAs of projection, bias + SiLU on the accumulator fragments, and then the POOLING ITSELF AS A
+// one sample (at most 64 rows: the host picks tpb = 64 / max atoms per token) and keeps them in LDS in the two-part fp16 format of
+// gemm_f16.hip.  The residual stream has no static magnitude bound - but the block stages its WHOLE operand tile, so it measures the
+// tile's own maximum while loading and derives the power-of-two operand scale from that: the tightest scale there is, exact, data-
+// dependent but order-free (a maximum), hence bit-reproducible.  Every wave then walks 32-column blocks of W (two fp16 parts with
+// per-row scales, packing.split2_f16): 48 MFMAs of projection, bias + SiLU on the accumulator fragments, and then the POOLING ITSELF AS A
 // MATRIX PRODUCT on the same pipe: pooled[t, j] = sum_rows P[t, row] u[row, j] with P the 0 / 1 membership matrix of the block's
 // tokens (exact in bf16) and u split into three bf16 parts (exact), 12 MFMAs, accumulated in fp32 in the matrix pipe's fixed order -
 // bit-reproducible, no atomics, no cross-lane shuffles.  The k index of that product is a free choice; it is chosen so that a lane's
@@ -16,6 +18,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -23,11 +26,13 @@ constexpr int CIN = 128, ROWS = 64, PITCH = 136;          // bf16 elements per L
 constexpr int PART = ROWS * PITCH;
 constexpr int NKS = CIN / 16;
 
-__global__ __launch_bounds__(256, 3) void downscale_pool_kernel(const float* __restrict__ ba, const __bf16* __restrict__ W3,
-                                                                const float* __restrict__ bias, const int* __restrict__ tok_start,
+__global__ __launch_bounds__(256, 4) void downscale_pool_kernel(const float* __restrict__ ba, const _Float16* __restrict__ W2,
+                                                                const float* __restrict__ w_inv, const float* __restrict__ bias,
+                                                                const int* __restrict__ tok_start,
                                                                 const float* __restrict__ add, float* __restrict__ out,
                                                                 int A, int T, int N, int tpb) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[3 * PART];
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * PART];
+    __shared__ float wmax[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -37,21 +42,32 @@ __global__ __launch_bounds__(256, 3) void downscale_pool_kernel(const float* __r
     int n = tok_start[t0 + ntok] - a0;
     n = n > ROWS ? ROWS : n;                               // (the launcher guarantees n <= 64)
 
-    // ---- stage the block's atom rows: fp32 -> three bf16 parts, once
+    // ---- stage the block's atom rows: the tile's own maximum -> power-of-two scale -> two fp16 parts, once
+    float a_s;
     {
         const int row = tid >> 2, c0 = (tid & 3) * 32;
         const float* src = ba + ((long long)b * A + a0 + row) * CIN + c0;
+        f32x4 v[8];
+        float m = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < n) v = *reinterpret_cast<const f32x4*>(src + 4 * i);
-            const pd_parts p0 = pd_split2(v[0], v[1]), p1 = pd_split2(v[2], v[3]);
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < n) v[i] = *reinterpret_cast<const f32x4*>(src + 4 * i);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[i][0]), fabsf(v[i][1]))), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
+        }
+        m = wave_max(m);
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+        a_s = pd_pow2_scale(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const pd_parts2 p0 = pd_split2h(v[i][0] * a_s, v[i][1] * a_s), p1 = pd_split2h(v[i][2] * a_s, v[i][3] * a_s);
             unsigned short* d = lds + row * PITCH + c0 + 4 * i;
             *reinterpret_cast<u32x2*>(d) = u32x2{p0.h, p1.h};
-            *reinterpret_cast<u32x2*>(d + PART) = u32x2{p0.m, p1.m};
-            *reinterpret_cast<u32x2*>(d + 2 * PART) = u32x2{p0.l, p1.l};
+            *reinterpret_cast<u32x2*>(d + PART) = u32x2{p0.l, p1.l};
         }
     }
+    const float inv_a_s = 1.0f / a_s;
     // ---- membership fragments of the pooling product (A operand: lane = token slot l31, k-slot kappa = 8 hh + s of k-step q <-> atom
     //      row 16 q + 8 (s >> 2) + 4 hh + (s & 3)) and the tokens' 1 / (n_t + 1e-3) in accumulator-register order
     int ra = 0, rb = 0;
@@ -83,13 +99,13 @@ __global__ __launch_bounds__(256, 3) void downscale_pool_kernel(const float* __r
 
     const int ncb = N >> 5;
     const unsigned short* abase = lds + l31 * PITCH + 8 * hh;
-    const long long wpart = (long long)ncb * NKS * 512;                   // bf16 elements per part of the fragment-major weights
+    const long long wpart = (long long)ncb * NKS * 512;                   // fp16 elements per part of the fragment-major weights
     for (int cb = wave; cb < ncb; cb += 4) {
-        const __bf16* wb = W3 + ((long long)cb * NKS * 64 + lane) * 8;
-        bf16x8 wf[2][3];
+        const _Float16* wb = W2 + ((long long)cb * NKS * 64 + lane) * 8;
+        f16x8 wf[2][2];
         auto wload = [&](int buf, int ks) {
 #pragma unroll
-            for (int pt = 0; pt < 3; ++pt) wf[buf][pt] = *reinterpret_cast<const bf16x8*>(wb + pt * wpart + (long long)ks * 512);
+            for (int pt = 0; pt < 2; ++pt) wf[buf][pt] = *reinterpret_cast<const f16x8*>(wb + pt * wpart + (long long)ks * 512);
         };
         f32x16 acc[2];
 #pragma unroll
@@ -103,21 +119,18 @@ __global__ __launch_bounds__(256, 3) void downscale_pool_kernel(const float* __r
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                bf16x8 af[3];
-#pragma unroll
-                for (int pt = 0; pt < 3; ++pt) af[pt] = *reinterpret_cast<const bf16x8*>(abase + pt * PART + 32 * i * PITCH + 16 * ks);
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 32 * i * PITCH + 16 * ks);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART + 32 * i * PITCH + 16 * ks);
                 f32x16 c = acc[i];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wf[ks & 1][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], wf[ks & 1][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], wf[ks & 1][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wf[ks & 1][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], wf[ks & 1][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wf[ks & 1][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks & 1][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[ks & 1][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks & 1][0], c, 0, 0, 0);
                 acc[i] = c;
             }
         }
         const int col = cb * 32 + l31;
         const float bv = bias ? bias[col] : 0.f;
+        const float cs = w_inv[col] * inv_a_s;                                // undo the weight row's and the tile's operand scales (exact)
         // u = silu(acc + bias) (rows beyond n are silu(bias): no token's membership row selects them), then pooled = P . u on the pipe
         f32x16 pz;
 #pragma unroll
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(256, 3) void downscale_pool_kernel(const float* __r
             u32x4 fh, fm, fl;
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
-                const pd_parts t = pd_split2(pd_silu(acc[i][e8 + 2 * s2] + bv), pd_silu(acc[i][e8 + 2 * s2 + 1] + bv));
+                const pd_parts t = pd_split2(pd_silu(__builtin_fmaf(acc[i][e8 + 2 * s2], cs, bv)), pd_silu(__builtin_fmaf(acc[i][e8 + 2 * s2 + 1], cs, bv)));
                 fh[s2] = t.h; fm[s2] = t.m; fl[s2] = t.l;
             }
             pz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[q], __builtin_bit_cast(bf16x8, fl), pz, 0, 0, 0);
@@ -147,17 +160,17 @@ __global__ __launch_bounds__(256, 3) void downscale_pool_kernel(const float* __r
 
 }  // namespace
 
-// ba [B][A][128] fp32 (row pitch 128), W3 = packing.split3_bf16 of the [N][128] weight, bias [N] or NULL, tok_start [T + 1] (atoms of a
-// token contiguous, tokens ascending), add [T][N] or NULL, out [B][T][N].  tpb tokens per block, 1 .. 32, and the caller guarantees that
-// tpb consecutive tokens never hold more than 64 atoms (tpb = 64 / max atoms per token).  PD_ERR_UNSUPPORTED for other shapes: run
-// pd_gemm (act = SiLU) + pd_segment_pool.
-PD_EXPORT int pd_downscale_pool(const float* ba, const void* W3, const float* bias, const int* tok_start, const float* add, float* out,
-                                int B, int A, int T, int Cin, int N, int tpb, void* stream) {
-    if (!ba || !W3 || !tok_start || !out || B <= 0 || A <= 0 || T <= 0) return PD_ERR_ARG;
+// ba [B][A][128] fp32 (row pitch 128), W2 / w_inv = packing.split2_f16 of the [N][128] weight (two fp16 parts, fragment-major, and the
+// inverse row scales), bias [N] or NULL, tok_start [T + 1] (atoms of a token contiguous, tokens ascending), add [T][N] or NULL, out
+// [B][T][N].  tpb tokens per block, 1 .. 32, and the caller guarantees that tpb consecutive tokens never hold more than 64 atoms (tpb =
+// 64 / max atoms per token).  PD_ERR_UNSUPPORTED for other shapes: run pd_gemm (act = SiLU) + pd_segment_pool.
+PD_EXPORT int pd_downscale_pool(const float* ba, const void* W2, const float* w_inv, const float* bias, const int* tok_start, const float* add,
+                                float* out, int B, int A, int T, int Cin, int N, int tpb, void* stream) {
+    if (!ba || !W2 || !w_inv || !tok_start || !out || B <= 0 || A <= 0 || T <= 0) return PD_ERR_ARG;
     if (Cin != CIN || N <= 0 || N % 32 != 0 || tpb < 1 || tpb > 32) return PD_ERR_UNSUPPORTED;
-    if ((((uintptr_t)ba | (uintptr_t)W3) & 15) != 0) return PD_ERR_UNSUPPORTED;
+    if ((((uintptr_t)ba | (uintptr_t)W2) & 15) != 0) return PD_ERR_UNSUPPORTED;
     dim3 grid((unsigned)((T + tpb - 1) / tpb), (unsigned)B);
-    hipLaunchKernelGGL(downscale_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, ba, reinterpret_cast<const __bf16*>(W3), bias, tok_start,
-                       add, out, A, T, N, tpb);
+    hipLaunchKernelGGL(downscale_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, ba, reinterpret_cast<const _Float16*>(W2), w_inv, bias,
+                       tok_start, add, out, A, T, N, tpb);
     return pd_check_launch();
 }

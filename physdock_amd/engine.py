@@ -800,9 +800,10 @@ class Engine:
         Wd, bd, _, Kd, ldwd = P.linear("dit.linear_downscale")
         tpb = batch.get("_pool_tpb", 0)
         rc = -3
-        if ops.FUSED_POOL and ops.SPLIT_GEMM and tpb > 0 and Kd == Ca and ldwd == Ca:
+        if ops.FUSED_POOL and ops.SPLIT_GEMM and ops.F16_GEMM and tpb > 0 and Kd == Ca and ldwd == Ca:
             # linear_downscale + SiLU + token mean + s in one launch: u [B A, 512] (268 MB at the benchmark shape) is never written
-            rc = L.pd_downscale_pool(ops.ptr(ba), P.w3(Wd, Kd).data_ptr(), ops.ptr(bd), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs),
+            w2p, w2i = P.w2(Wd, Kd)
+            rc = L.pd_downscale_pool(ops.ptr(ba), w2p.data_ptr(), ops.ptr(w2i), ops.ptr(bd), ops.ptr(batch["_tok_start"]), ops.ptr(s), ops.ptr(bs),
                                      B, A, T, Ca, Cs, tpb, sp)
         if rc == -3:            # PD_ERR_UNSUPPORTED (other widths, a token of more than 64 atoms): projection, then the segment mean
             u = self.lws("dit_u", RA, Cs)

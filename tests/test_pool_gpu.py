@@ -16,7 +16,7 @@ def g(seed):
 @pytest.mark.parametrize("B,chunks_kind,N", [(64, "cfg1", 512), (3, "ragged", 512), (5, "ragged0", 256), (2, "big", 512)])
 def test_fused_downscale_pool_vs_float64_and_two_launches(B, chunks_kind, N):
     from physdock_amd import ops
-    from physdock_amd.packing import split3_bf16
+    from physdock_amd.packing import split2_f16, split3_bf16
     gen = g(7)
     if chunks_kind == "cfg1":
         chunks = torch.tensor([9] * 224 + [1] * 32)
@@ -43,10 +43,11 @@ def test_fused_downscale_pool_vs_float64_and_two_launches(B, chunks_kind, N):
     L = ops._lib.init()
     bad, Wd, bd, tsd, sd = ba.cuda(), W.cuda(), bias.cuda(), ts.cuda(), s.cuda()
     w3 = split3_bf16(Wd)
+    w2p, w2i = split2_f16(Wd)
     outs = []
     for _ in range(2):
         out = torch.full((B, T, N), float("nan"), device="cuda")
-        ops.check(L.pd_downscale_pool(ops.ptr(bad), w3.data_ptr(), ops.ptr(bd), ops.ptr(tsd), ops.ptr(sd), ops.ptr(out), B, A, T, Cin, N, tpb,
+        ops.check(L.pd_downscale_pool(ops.ptr(bad), w2p.data_ptr(), ops.ptr(w2i), ops.ptr(bd), ops.ptr(tsd), ops.ptr(sd), ops.ptr(out), B, A, T, Cin, N, tpb,
                                       ops.stream()), "pool")
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
@@ -74,5 +75,5 @@ def test_unsupported_shapes_are_refused_not_mangled():
     from physdock_amd import ops
     L = ops._lib.init()
     d = torch.zeros(64, device="cuda")
-    assert L.pd_downscale_pool(ops.ptr(d), ops.ptr(d), None, ops.ptr(d), None, ops.ptr(d), 1, 64, 4, 64, 512, 4, ops.stream()) == -3      # Cin != 128
-    assert L.pd_downscale_pool(ops.ptr(d), ops.ptr(d), None, ops.ptr(d), None, ops.ptr(d), 1, 64, 4, 128, 512, 0, ops.stream()) == -3     # a token > 64 atoms
+    assert L.pd_downscale_pool(ops.ptr(d), ops.ptr(d), ops.ptr(d), None, ops.ptr(d), None, ops.ptr(d), 1, 64, 4, 64, 512, 4, ops.stream()) == -3      # Cin != 128
+    assert L.pd_downscale_pool(ops.ptr(d), ops.ptr(d), ops.ptr(d), None, ops.ptr(d), None, ops.ptr(d), 1, 64, 4, 128, 512, 0, ops.stream()) == -3     # a token > 64 atoms
