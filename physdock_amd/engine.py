@@ -641,7 +641,7 @@ class Engine:
         # the kernel pd_attention picks depends on the launch shape only: asked once per block (kv2 and o_split both need it)
         unsplit_f16 = bool(f16 and ops.F16_ATTN and ops.SPLIT_ATTN and ops.unsplit_f16_attention(
             ops.attention(off(qkv, 0), off(qkv, C), off(qkv, 2 * C), None, query_only=True, **akw)))
-        if unsplit_f16 and ops.KV_PRESPLIT \
+        if unsplit_f16 and ops.KV_PRESPLIT and self.probe is None \
                 and ops.kv2_supported(rows, C, a2=qkv_presplit and a2 is not None, per_group_rows=N if per_sample else 0):
             kv2 = self.lws("dit_kv2", rows, 4 * C, dtype=torch.float16)      # per row: k then v, groups of (4 high, 4 low) parts
             hn.update(Y2=kv2, y2_amax=bnd + 4, y2_col0=C)
@@ -655,7 +655,7 @@ class Engine:
             self.probe(prefix, "v", qkv[:B * N, 2 * C:], bnd + 8)
         Wo, bo, _, _, ldw = P.linear(prefix + ".attention.linear_o")
         # (the attention kernel lays its split output out as [2][B N][C]: it is the projection's A2 only when no padding rows follow)
-        o_split = unsplit_f16 and ops.ATTN_SPLIT_OUT and C % 32 == 0 and ldw == C and rows == B * N \
+        o_split = unsplit_f16 and ops.ATTN_SPLIT_OUT and self.probe is None and C % 32 == 0 and ldw == C and rows == B * N \
             and ops.presplit_supported(rows, C, C, f16=True, gate=True, per_group_rows=N if per_sample else 0, gstride=tab_ld if per_sample else 0)
         if o_split:
             o2 = self.lws("dit_o2", 2, rows, C, dtype=torch.float16)
@@ -669,7 +669,7 @@ class Engine:
             self.gemm(o, Wo, x, rows, C, C, ldw=ldw, bias=bo, mul=off(tab, tab_off + 2 * C), res=x, a_amax=b_o, **mgrp)
         t2 = tab_off + 3 * C
         W2, _, _, _, ldw = P.linear(prefix + ".transition.feed_forward.w2")
-        if f16 and ops.FUSED_TRANSITION and not presplit and W13.shape[1] == C and ldw == hidden \
+        if f16 and ops.FUSED_TRANSITION and self.probe is None and not presplit and W13.shape[1] == C and ldw == hidden \
                 and ops.transition_f16(x, rows, C, hidden, shift=off(tab, t2), scale1p=off(tab, t2 + C), gate=off(tab, t2 + 2 * C),
                                        W13=P.w2(W13, C), W2=P.w2(W2, hidden), y_amax=b_y2, h_amax=b_h, eps=eps,
                                        rows_per_group=N if per_sample else 0, gstride=tab_ld if per_sample else 0):
@@ -699,8 +699,9 @@ class Engine:
         Returns the set of families switched off by THIS check (the caller then re-prepares the call).  Not part of any
         captured graph; costs three eager denoiser passes once per (weights, shape)."""
         import warnings
-        saved = (ops.ATTN_SPLIT_OUT, ops.FUSED_TRANSITION, ops.KV_PRESPLIT, ops.GEMM_HOOK, ops.ATTN_HOOK)
-        ops.ATTN_SPLIT_OUT = ops.FUSED_TRANSITION = ops.KV_PRESPLIT = False          # v, o and h as fp32 tensors
+        # (while self.probe is set, dit_block materialises v, o and h as fp32 tensors: no pre-split k | v, no split attention output, no
+        #  fused atom transition - a per-ENGINE switch: replicas of a StreamPool run their checks while other replicas sample)
+        saved = (ops.GEMM_HOOK, ops.ATTN_HOOK)
         ops.GEMM_HOOK = ops.ATTN_HOOK = None                                          # (test / profiling hooks see the product launches only)
         rec = []
 
@@ -724,7 +725,7 @@ class Engine:
                     bnd_of[j] = i
         finally:
             self.probe = None
-            ops.ATTN_SPLIT_OUT, ops.FUSED_TRANSITION, ops.KV_PRESPLIT, ops.GEMM_HOOK, ops.ATTN_HOOK = saved
+            ops.GEMM_HOOK, ops.ATTN_HOOK = saved
         if not rec:
             return set()
         amax = torch.stack([r[2] for r in rec]).cpu()
