@@ -630,6 +630,21 @@ void gemm_f16_wrows_kernel(const pd_gemm_args p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + part * PART + r * WLP + 8 * (q + 16 * i)) = c[part][i];
             }
+        } else if constexpr (PRO == 0) {
+            // plain fp32 rows (no norm: the attention output in front of linear_o at a handful of samples): scale, split, stage
+            const int q = tid & 15;
+#pragma unroll 1
+            for (int r = tid >> 4; r < BM; r += RPP) {
+                const float* xr = p.A + (long long)(row0 + r) * p.lda;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = 4 * (q + 16 * i);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+                    const pd_parts2 p0 = pd_split2h(v[0] * a_s, v[1] * a_s), p1 = pd_split2h(v[2] * a_s, v[3] * a_s);
+                    *reinterpret_cast<u32x2*>(lds + r * WLP + c) = u32x2{p0.h, p1.h};
+                    *reinterpret_cast<u32x2*>(lds + PART + r * WLP + c) = u32x2{p0.l, p1.l};
+                }
+            }
         } else {   // ---- prologue: sixteen threads (one DPP row) per row, 16-byte chunks interleaved; 4 NWV rows per pass
             const int q = tid & 15;
 #pragma unroll 1
@@ -1034,6 +1049,8 @@ int dispatch_f16_wrows(int op, int pro, int epi, const pd_gemm_args* p, hipStrea
     if (pro == 2 && epi == EPI_PLAIN) return run_f16_wrows<2, EPI_PLAIN, 2, 1>(op, p, s);
     if (pro == 3 && epi == EPI_GATERES) return run_f16_wrows<3, EPI_GATERES, 2, 1>(op, p, s);
     if (pro == 3 && epi == EPI_PLAIN) return run_f16_wrows<3, EPI_PLAIN, 2, 1>(op, p, s);
+    if (pro == 0 && epi == EPI_GATERES) return run_f16_wrows<0, EPI_GATERES, 2, 1>(op, p, s);
+    if (pro == 0 && epi == EPI_PLAIN) return run_f16_wrows<0, EPI_PLAIN, 2, 1>(op, p, s);
 #ifdef PD_F16_WROWS_GLU12      // lab: 32 x 64 wave tiles, four-deep fragment ring (163 vs 128 us at 64 samples)
     if (pro == 1 && epi == EPI_GLU) return run_f16_wrows<1, EPI_GLU, 1, 2>(op, p, s);
     if (pro == 2 && epi == EPI_GLU) return run_f16_wrows<2, EPI_GLU, 1, 2>(op, p, s);
@@ -1176,6 +1193,12 @@ int dispatch_f16_wchunk(int op, int epi, const pd_gemm_args* p, hipStream_t s) {
 #ifndef PD_F16_WROWS_A2
 #define PD_F16_WROWS_A2 1              // lab: 0 = pre-split A stays on the tile kernel
 #endif
+#ifndef PD_F16_WROWS_PLAIN
+#define PD_F16_WROWS_PLAIN 1            // lab: 0 = plain fp32 rows (K = 512, few samples) stay on the fp32 streaming kernel
+#endif
+#ifndef PD_F16_WROWS_PLAIN_MAX_TILES
+#define PD_F16_WROWS_PLAIN_MAX_TILES 31  // up to 7 samples of 256 tokens
+#endif
 #ifndef PD_F16_WROWS_TINY
 #define PD_F16_WROWS_TINY 1             // lab: 0 = launches below the tile kernels' thresholds never reach the wide-rows kernels
 #endif
@@ -1297,7 +1320,11 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
     const long long t128 = p.M % 128 == 0 ? (long long)(p.M / 128) * (p.N / 128) : 0, t64 = (long long)(p.M / 64) * (p.N / 128);
     // (the tile kernels' own threshold; the wide-rows kernels below share a row tile among several blocks and take fewer: PD_F16_TINY)
     const bool tiny = t128 < PD_F16_MIN_TILES && t64 < PD_F16_MIN_TILES_SMALL;
-    if (tiny && !(PD_F16_WROWS_TINY && p.K == 512 && !p.A2 && !p.stats && p.stats_inline)) return PD_ERR_UNSUPPORTED;
+    // plain fp32 rows with K = 512 at a handful of samples (linear_o behind an attention that writes fp32: one launch whose blocks share
+    // the row tiles, instead of the K-split pair of the fp32 streaming kernel: 7 + 7 us)
+    const bool plain512 = PD_F16_WROWS_PLAIN && p.K == 512 && !p.A2 && pro == 0 && !p.stats && !p.stats_inline && p.pro_act == PD_ACT_NONE &&
+                          p.M / 64 >= PD_F16_WROWS_MIN_TILES_SPLIT && p.M / 64 <= PD_F16_WROWS_PLAIN_MAX_TILES;
+    if (tiny && !(PD_F16_WROWS_TINY && p.K == 512 && !p.A2 && !p.stats && (p.stats_inline || plain512))) return PD_ERR_UNSUPPORTED;
     const bool small = t128 < PD_F16_MIN_TILES;
     if (p.rowscale_acc || (p.rowscale && !glut) || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
     int epi;
@@ -1347,7 +1374,10 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
         }
         return dispatch_f16_wchunk(0, epi, &p, (hipStream_t)stream);
     }
-    if (wrows_ok || wrows_a2) {
+    const bool wrows_plain = plain512 && p.act == PD_ACT_NONE && p.M % 64 == 0 && p.lda % 4 == 0 && ((uintptr_t)p.A & 15) == 0 &&
+                             (epi == EPI_PLAIN || (epi == EPI_GATERES && (!p.mul || p.mul_rows_per_group % 64 == 0))) &&
+                             (long long)(p.N / 32) * 32 * 1024 * 2 < 0x7fffffffll;
+    if (wrows_ok || wrows_a2 || wrows_plain) {
         if (init_only == 2) {
             const int r = dispatch_f16_wrows(1, pro, epi, nullptr, nullptr);
             return r == PD_OK ? epi + 0x500 : r;          // tile code 5: the wide-rows kernel

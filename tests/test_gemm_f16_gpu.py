@@ -537,6 +537,43 @@ def test_wide_rows_kernel_with_presplit_rows_gate_and_residual(per_sample, B):
     assert err <= 5e-5
 
 
+@pytest.mark.parametrize("per_sample,B", [(False, 1), (True, 3), (False, 7)])
+def test_wide_rows_kernel_on_plain_fp32_rows_at_a_handful_of_samples(per_sample, B):
+    """gemm_f16_wrows_kernel<0, GATERES, 2, 1> (round 5): the token linear_o at 1 - 7 samples, where the attention writes fp32 and the
+    projection used to run as a K-split PAIR of fp32 streaming launches - one launch, rows scaled and split while they are staged -
+    against float64."""
+    import ctypes as C_
+    from physdock_amd import ops
+    from physdock_amd.packing import split2_f16
+    N_, Cd = 256, 512
+    rows = B * N_
+    o = (torch.randn(rows, Cd, generator=g(41)) * 2).cuda()
+    res = torch.randn(rows, Cd, generator=g(42)).cuda()
+    Wo = (torch.randn(Cd, Cd, generator=g(43)) / math.sqrt(Cd)).cuda()
+    bo = torch.randn(Cd, generator=g(44)).cuda()
+    ngrp = B if per_sample else 1
+    gate = torch.randn(ngrp, 3 * Cd, generator=g(45)).cuda()
+    amax = torch.tensor([float(o.abs().max()) * 1.5], device="cuda")
+    mgrp = dict(mul_rows_per_group=N_ if per_sample else rows, mul_gstride=3 * Cd if per_sample else 0)
+    seen = []
+    L = ops._lib.init()
+    ops.GEMM_HOOK = lambda a, launch: (seen.append(L.pd_gemm_variant(C_.byref(a))), launch())
+    try:
+        y = res.clone()
+        ops.gemm(o, Wo, y, rows, Cd, Cd, bias=bo, mul=gate.data_ptr() + 8 * Cd, res=y, W2=split2_f16(Wo), a_amax=amax,
+                 ksplit_ws=torch.empty(9 << 18, device="cuda"), **mgrp)
+        torch.cuda.synchronize()
+    finally:
+        ops.GEMM_HOOK = None
+    assert len(seen) == 1 and seen[0] >= 2000000 and tile_code(seen[0]) == 5, seen
+    gd = gate[:, 2 * Cd:].double()
+    acc = o.double() @ Wo.double().t() + bo.double()
+    ref = res.double() + (acc.reshape(B, N_, Cd) * gd[:, None]).reshape(rows, Cd) if per_sample else res.double() + acc * gd
+    err = float((y.double() - ref).abs().max())
+    print(f"wide-rows linear_o on fp32 rows per_sample={per_sample} B={B}: max error vs float64 {err:.2e}")
+    assert err <= 5e-5
+
+
 @pytest.mark.parametrize("per_sample,B,K", [(False, 64, 1408), (True, 64, 1408), (False, 40, 1408), (False, 64, 576)])
 def test_chunked_wide_rows_kernel_of_the_token_down_projection(per_sample, B, K):
     """gemm_f16_wchunk_kernel<GATERES>: N = 512, K > 512 (the token w2 of a DiT block): one accumulator tile per wave, the fp32 rows
