@@ -147,8 +147,8 @@ int pd_norm_split2(const float* x, int ldx, int M, int C, int mode, float eps, c
 /* ---- pd_transition_f16 (ABI 5): the atom-level DiT transition in one launch --------------------------------------------------
  * x[m,:] += gate[g] * W2 . ( silu(W1 y) * (W3 y) ),  y = scale1p[g] * LayerNorm(x[m,:]) + shift[g],  g = m / rows_per_group
  * (transitions.py:27-30 with adaptive_layer_norm_zero.py:16-21 and feed_forward.py:30-31): row statistics, SwiGLU projection
- * and down-projection of 128 whole rows per block, the hidden activations stay in LDS.  C = 128 and hidden = 384 only, M % 128
- * == 0 and M / 128 >= 256 (PD_ERR_UNSUPPORTED otherwise: run pd_rowstats + two pd_gemm).  W13 / W2 are the two-part fp16
+ * and down-projection of 64 whole rows per block, the hidden activations stay in LDS.  C = 128 and hidden = 384 only, M % 64
+ * == 0 and M >= 2048 (PD_ERR_UNSUPPORTED otherwise: run pd_rowstats + two pd_gemm).  W13 / W2 are the two-part fp16
  * fragment-major forms of the packed [a(32) | b(32)] SwiGLU weights [2 hidden][C] and of W2 [C][hidden] with their inverse row
  * scales (packing.split2_f16); y_amax / h_amax are device scalars bounding |y| and |silu(a) b| (pd_dit_bounds).
  * args == NULL: one-time set-up (dynamic LDS limit), called by pd_init.                                                        */

@@ -242,6 +242,9 @@ void transition_f16_kernel(const pd_transition_args p) {
 
 // x [M][128] updated in place; see include/physdock_hip.h pd_transition_args.  PD_ERR_UNSUPPORTED for other shapes (the caller
 // then runs the three-launch form).  init: M <= 0 with args == nullptr raises the dynamic-LDS limit.
+#ifndef PD_TRANSITION_MIN128
+#define PD_TRANSITION_MIN128 16       // (round 5: 256 -> 16; same-box ms per call at 2 / 4 / 8 / 12 samples 94.4 / 104.9 / 140.0 / 144.1 -> 92.5 / 102.4 / 136.4 / 138.8)
+#endif
 PD_EXPORT int pd_transition_f16(const pd_transition_args* a, void* stream) {
     constexpr int BM = PD_TRANSITION_BM;
     typedef TT<BM> T;
@@ -253,7 +256,7 @@ PD_EXPORT int pd_transition_f16(const pd_transition_args* a, void* stream) {
     if (!a->x || !a->shift || !a->scale1p || !a->gate || !a->W13 || !a->w13_inv || !a->W2 || !a->w2_inv || !a->y_amax || !a->h_amax)
         return PD_ERR_ARG;
     if (a->C != C_ || a->hidden != 3 * CH || a->M <= 0 || a->M % BM != 0) return PD_ERR_UNSUPPORTED;
-    if (a->M / 128 < 256) return PD_ERR_UNSUPPORTED;                    // fewer 128-row tiles than CUs: the three-launch form fills the chip better
+    if (a->M / 128 < PD_TRANSITION_MIN128) return PD_ERR_UNSUPPORTED;   // (below 2 048 rows the launches are latency-bound either way)
     if (a->rows_per_group > 0 && a->gstride % 4 != 0) return PD_ERR_UNSUPPORTED;
     if (((uintptr_t)a->x | (uintptr_t)a->shift | (uintptr_t)a->scale1p | (uintptr_t)a->W13 | (uintptr_t)a->W2) & 15) return PD_ERR_UNSUPPORTED;
     const int ntiles = a->M / BM, grid = 256 * T::BLOCKS_PER_CU;
