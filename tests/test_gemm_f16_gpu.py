@@ -50,7 +50,8 @@ def test_f16_accuracy_is_at_least_fp32_mfma(K, wide, slack, M):
     finally:
         ops.GEMM_HOOK = None
     assert seen[-1] >= 2000000, seen                     # gemm_f16_kernel took it
-    assert tile_code(seen[-1]) == (1 if M == 1280 else 0), seen
+    # (M = 1280 rows of K = 512 plain fp32: the wide-rows kernel's plain form, round 5 - tile code 5; other K: the 64 x 128 tile)
+    assert tile_code(seen[-1]) == ((5 if K == 512 else 1) if M == 1280 else 0), seen
     e32 = (Y32.double() - ref).abs() / mag
     e3 = (Y3.double() - ref).abs() / mag
     print(f"K={K} wide={wide} bound x{slack:g}: fp32 MFMA max {float(e32.max()):.2e} rms {float(e32.pow(2).mean().sqrt()):.2e} | "
@@ -364,7 +365,7 @@ def test_fused_atom_transition_vs_three_launches_and_float64(per_sample):
     torch.testing.assert_close(x1, x3, atol=3e-5, rtol=2e-5)
     assert e1 <= 1.2 * e3 + 1e-9
     # shapes the kernel does not cover are declined, not mangled
-    assert ops.transition_f16(x1, 128 * 100, Cd, hidden, shift=tabd, scale1p=tabd, gate=tabd, W13=split2_f16(W13), W2=split2_f16(W2d),
+    assert ops.transition_f16(x1, 128 * 8, Cd, hidden, shift=tabd, scale1p=tabd, gate=tabd, W13=split2_f16(W13), W2=split2_f16(W2d),
                               y_amax=ymax, h_amax=hmax, eps=1e-5) is False
 
 
