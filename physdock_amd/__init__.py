@@ -13,4 +13,4 @@ from .import_weights import import_state_dict, import_unicore_ckpt  # noqa: F401
 from .model import PhysDock, weighted_rigid_align  # noqa: F401
 from .confidence import ConfidenceModule  # noqa: F401  (reference layers/confidence_module.py)
 from .params import param_shapes, seeded_state_dict  # noqa: F401
-from .driver import redock  # noqa: F401  (multi-round caller of the sampler, reference redocking.py:156-342)
+from .driver import redock, redock_many  # noqa: F401  (multi-round caller of the sampler, reference redocking.py:156-342)

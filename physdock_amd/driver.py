@@ -191,3 +191,25 @@ def redock(model, batch: Dict[str, torch.Tensor], *, ref_mol=None, ref_mol_poses
         out["pdb_blocks"] = PdbTemplate(infer_meta_data).blocks(aligned)
         out["receptor_pdb_blocks"] = PdbTemplate(infer_meta_data, receptor_only=True).blocks(aligned)
     return out
+
+
+def redock_many(model, systems, *, streams: Optional[int] = None, **common) -> List[dict]:
+    """The loop over systems of the reference's drivers (`redocking.py:128-154`: one `redocking(...)` call per input system;
+    `screening.py:100-116`: one receptor x many ligands) on ONE GPU.  `systems`: an iterable of feature dicts, or of
+    `(batch, per_system_kwargs)` pairs (`ref_mol`, `ref_mol_poses`, `chirality`, `infer_meta_data` ... differ per system); `common`:
+    keyword arguments of `redock` shared by all.  Results in input order.
+
+    Rounds of few samples cannot fill an MI355X (20 samples per round, the drivers' setting: 70 % of the per-pose rate of a 64-sample
+    call), and the systems are independent, so by default two of them are in flight on two HIP streams whenever a round has fewer
+    than 32 samples (`parallel.StreamPool`: one model replica, stream and host thread each; poses are bit-identical to the
+    one-at-a-time run, `tests/test_concurrent_streams_gpu.py`, `tests/test_configs_3_5_gpu.py`).  `streams=1` runs them one by one;
+    rounds of 32 or more samples already fill the chip and run one by one unless `streams` says otherwise.  Across GPUs the same list
+    is dealt out by `parallel.map_systems`."""
+    items = [(s, {}) if isinstance(s, dict) else (s[0], dict(s[1])) for s in systems]
+    n = streams if streams is not None else (2 if int(common.get("num_samples_per_round", 5)) < 32 else 1)
+    on_gpu = bool(items) and items[0][0]["x_gt"].is_cuda and hasattr(model, "config")
+    if n <= 1 or len(items) <= 1 or not on_gpu:
+        return [redock(model, b, **dict(common, **kw)) for b, kw in items]
+    from .parallel import StreamPool
+    pool = StreamPool(model, n=n)
+    return pool.map(lambda m, it: redock(m, it[0], **dict(common, **it[1])), items)

@@ -96,6 +96,18 @@ def test_stream_of_systems_serial_pool_and_sharded_agree(medium, systems, name):
     for a, b in zip(pooled, serial):
         _same(a, b)
     del pool
+    # (b') the same through the driver's own loop over systems: driver.redock_many puts two systems in flight by default when a round has
+    #      fewer than 32 samples (config #5), runs them one by one at 64 (config #3)
+    from physdock_amd import driver
+    per_system = []
+    for i, s in jobs:
+        kw = dict(seed=100 + i, infer_meta_data=s["infer_meta_data"])
+        if settings.get("physics_correction"):
+            kw["ref_mol_poses"] = s["ref_mol_poses"]
+        per_system.append((s["dbatch"], kw))
+    many = driver.redock_many(medium, per_system, **settings)
+    for res, b in zip(many, serial):
+        assert torch.equal(res["poses"].cpu(), b["poses"]) and list(res["ranking"]["order"]) == b["order"] and list(res["pdb_blocks"]) == b["pdb"]
     # (c) by-system sharding through the process group (RCCL, world size 1: every system is this rank's)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29551 + list(CONFIGS).index(name)}", rank=0, world_size=1)

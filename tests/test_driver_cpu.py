@@ -106,3 +106,15 @@ def test_ranking_representatives_match_the_reference_procedure_fixture():
     ids = [first] + [i for i in ids if i != first] if first in ids else [first] + ids[:4]
     assert ids == g["order"].tolist()
     assert np.allclose([g["rmsds"][i] for i in ids], g["top_rmsds"].numpy())
+
+
+def test_redock_many_keeps_order_and_per_system_arguments(setup):
+    """driver.redock_many = the drivers' loop over systems (redocking.py:128-154): results in input order, per-system keyword arguments
+    reach their own system only; without a GPU (or with streams=1) the systems run one by one"""
+    model, batch, poses, picked = setup
+    b2 = dict(batch)
+    b2["msa_feat"] = batch["msa_feat"] + 7.0
+    out = driver.redock_many(model, [batch, (b2, dict(num_samples_per_round=3, max_samples=3))], num_samples_per_round=2, max_samples=2, ranking=False)
+    assert len(out) == 2 and out[0]["poses"].shape[0] == 2 and out[1]["poses"].shape[0] == 3
+    assert [c["num_sample"] for c in model.calls] == [2, 3] and [c["msa_tag"] for c in model.calls] == [0.0, 7.0]
+    assert driver.redock_many(model, [], streams=2) == []
