@@ -34,6 +34,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef PD_F16_MIN_TILES_SMALL
 #define PD_F16_MIN_TILES_SMALL 160
 #endif
+#ifndef PD_F16_MIN_TILES_SMALL_LONGK
+#define PD_F16_MIN_TILES_SMALL_LONGK 96
+#endif
 // lab ablations of the direct-W main loop (timing only, wrong results): 1 every block stages the A rows of tile 0 (L2-hot operand),
 // 2 every wave loads the W fragments of column block 0 / k-step 0, 4 no block barrier inside the slice loop, 8 no A requests in the loop,
 // 16 the A fragments are read from LDS once per tile instead of once per k-step (no LDS reads in the loop), 32 no LDS staging stores,
@@ -1197,7 +1200,7 @@ int dispatch_f16_wchunk(int op, int epi, const pd_gemm_args* p, hipStream_t s) {
 #define PD_F16_WROWS_PLAIN 1            // lab: 0 = plain fp32 rows (K = 512, few samples) stay on the fp32 streaming kernel
 #endif
 #ifndef PD_F16_WROWS_PLAIN_MAX_TILES
-#define PD_F16_WROWS_PLAIN_MAX_TILES 31  // up to 7 samples of 256 tokens
+#define PD_F16_WROWS_PLAIN_MAX_TILES 39  // up to 9 samples of 256 tokens (from 40 tiles on the 64 x 128 tile kernel takes the launch)
 #endif
 #ifndef PD_F16_WROWS_TINY
 #define PD_F16_WROWS_TINY 1             // lab: 0 = launches below the tile kernels' thresholds never reach the wide-rows kernels
@@ -1319,7 +1322,9 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
     // (k-split fp32 kernel).  The caller's tile (its 64 x 64 choice below 192 row/column blocks) only says the rows come in 64s.
     const long long t128 = p.M % 128 == 0 ? (long long)(p.M / 128) * (p.N / 128) : 0, t64 = (long long)(p.M / 64) * (p.N / 128);
     // (the tile kernels' own threshold; the wide-rows kernels below share a row tile among several blocks and take fewer: PD_F16_TINY)
-    const bool tiny = t128 < PD_F16_MIN_TILES && t64 < PD_F16_MIN_TILES_SMALL;
+    // (long K - the token w2, K = 1408 - is worth the 64 x 128 tile from 96 tiles on: 31 us at 10 samples of 256 tokens against 39 us for the
+    //  K-split fp32 pair at 6 - 7 samples and 49 us for the bf16 x 6 64 x 64 tile that took 8 - 9; tools/w2_paths.py, round 5)
+    const bool tiny = t128 < PD_F16_MIN_TILES && t64 < (p.K >= 1024 ? PD_F16_MIN_TILES_SMALL_LONGK : PD_F16_MIN_TILES_SMALL);
     // plain fp32 rows with K = 512 at a handful of samples (linear_o behind an attention that writes fp32: one launch whose blocks share
     // the row tiles, instead of the K-split pair of the fp32 streaming kernel: 7 + 7 us)
     const bool plain512 = PD_F16_WROWS_PLAIN && p.K == 512 && !p.A2 && pro == 0 && !p.stats && !p.stats_inline && p.pro_act == PD_ACT_NONE &&
