@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const pd_attn_args p)
 // number of key chunks pd_attention would use (1 = no split): only when the launch leaves most of the chip idle, the
 // key range is long enough and the caller supplied a workspace of nsplit * nbatch * nq * (32 + 2) * nheads floats
 #ifndef PD_ATTN_MIN_WAVES
-#define PD_ATTN_MIN_WAVES 1024
+#define PD_ATTN_MIN_WAVES 128      // (round 5: 1024 -> 128; per call at 1 / 2 / 4 / 7 samples 87.8 / 94.2 / 103.9 / 122.5 -> 85.0 / 91.6 / 101.2 / 119.6 ms: a 256-key launch of 32 blocks is latency-bound on either pipe and the fp16-format kernels have the shorter chain)
 #endif
 #ifndef PD_ATTN_NOSPLIT_BLOCKS
 #define PD_ATTN_NOSPLIT_BLOCKS 320     // 128-query blocks from which a launch is not key-split (5 samples x 4 heads x 2048 atoms: 109.6 -> 106.2 ms per call, 7 samples 127 -> 122; at 256 blocks the split still wins)
