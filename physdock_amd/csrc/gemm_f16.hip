@@ -1328,7 +1328,7 @@ extern "C" int pd_gemm_f16_try(const pd_gemm_args* args, int pro, int tile, void
     // plain fp32 rows with K = 512 at a handful of samples (linear_o behind an attention that writes fp32: one launch whose blocks share
     // the row tiles, instead of the K-split pair of the fp32 streaming kernel: 7 + 7 us)
     const bool plain512 = PD_F16_WROWS_PLAIN && p.K == 512 && !p.A2 && pro == 0 && !p.stats && !p.stats_inline && p.pro_act == PD_ACT_NONE &&
-                          p.M / 64 >= PD_F16_WROWS_MIN_TILES_SPLIT && p.M / 64 <= PD_F16_WROWS_PLAIN_MAX_TILES;
+                          p.M / 64 >= PD_F16_WROWS_MIN_TILES_SPLIT && p.M / 64 <= PD_F16_WROWS_PLAIN_MAX_TILES && t128 < PD_F16_MIN_TILES;
     if (tiny && !(PD_F16_WROWS_TINY && p.K == 512 && !p.A2 && !p.stats && (p.stats_inline || plain512))) return PD_ERR_UNSUPPORTED;
     const bool small = t128 < PD_F16_MIN_TILES;
     if (p.rowscale_acc || (p.rowscale && !glut) || p.maskadd || p.out_scale != 1.f) return PD_ERR_UNSUPPORTED;
