@@ -37,6 +37,13 @@ constexpr int NSTAGE = 3;
 
 #define PD_SB() __builtin_amdgcn_sched_barrier(0)
 
+#ifdef PD_LAB      // lab build only (tools/attn_pipe_trace.py): s_memtime stamps along a block's life; 16 slots per wave
+__device__ unsigned long long* g_pipe_trace = nullptr;
+#define PD_PSTAMP(slot) do { if (ptr_) ptr_[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PD_PSTAMP(slot) do { } while (0)
+#endif
+
 // lab ablations (timing only, wrong results): 1 no block barrier in the main loop, 2 exp2 -> identity, 4 no MFMAs in the phases,
 // 8 no softmax VALU in the phases, 16 static s_setprio 1 for the second half of the block's waves, 32 no bias fetch in the
 // phases, 64 no K / V staging in the main loop
@@ -112,6 +119,14 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     // lanes with a real query: the lanes of the padding rows of a ragged last wave hold whatever the bias buffer's padding holds and
     // must not take part in the wave-wide decision to move the running maximum (the result would depend on that padding)
     const unsigned long long qlanes = __builtin_amdgcn_ballot_w64(query < p.nq);
+#ifdef PD_LAB
+    unsigned long long* ptr_ = nullptr;
+    {
+        const int lid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (g_pipe_trace && lane == 0 && lid < 1024) ptr_ = g_pipe_trace + ((long long)lid * NW + wave) * 16;
+    }
+#endif
+    PD_PSTAMP(0);                                          // kernel entry
 
     // power-of-two operand scales from the magnitude bounds (as attn_f16.hip); S' = S / c_s is what the matrix pipe accumulates
     float qs = p.scale * PD_LOG2E;
@@ -409,6 +424,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
             qraw[s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_q, qoff, 64 * s + 16, 0));
         }
     }
+    PD_PSTAMP(1);                                          // every prologue request issued
     PD_SB();
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -422,9 +438,12 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         qf[s][0] = __builtin_bit_cast(frag, fh);
         qf[s][1] = __builtin_bit_cast(frag, fl);
     }
+    PD_PSTAMP(2);                                          // Q arrived and split
     sstore(0);
+    PD_PSTAMP(3);                                          // K / V tile 0 arrived and staged
     gload(1);
     lds_barrier();
+    PD_PSTAMP(4);                                          // first barrier passed
     int s_cur = 0, s_nxt = STAGE, s_nn = 2 * STAGE;
     float mloc = 0.f;
     frag kf0[2];
@@ -434,6 +453,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         mloc = rowmax(sA);
     }
 
+    PD_PSTAMP(5);                                          // first score tile + row maximum
     if constexpr (ABL & 16) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
     if (wave_active) {
         for (int it = 0; it < nit - 1; ++it) {
@@ -446,6 +466,9 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
             // sub-tile 2 it + 1 (cur = sB): next scores = first half of tile it + 1
             phase(sB, sA, mloc, kf0, s_nxt, s_cur + 32, s_nxt + 32 * KP, 2 * it + 3);
             const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t;
+#ifdef PD_LAB
+            if (it < 6) PD_PSTAMP(6 + it);                 // end of main-loop iteration it
+#endif
         }
     } else {                                               // a wave without queries (ragged last block) only stages
         for (int it = 0; it < nit - 1; ++it) {
@@ -473,6 +496,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         if (two) finish(sB, kt0 + 1, s_cur + 32);
     }
 
+    PD_PSTAMP(12);                                         // last tile finished
     if (query < p.nq) {
         const float l = pd_xhalf_sum(l_run);
         if (p.O2) {
@@ -496,6 +520,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
             }
         }
     }
+    PD_PSTAMP(13);                                         // output stores issued
 }
 
 constexpr int LDS_BYTES = NSTAGE * STAGE * 2;
@@ -542,6 +567,13 @@ PD_EXPORT int pd_attention_bias_prescale_log2(float q_amax, float k_amax, float 
     volatile float qa = q_amax * qs;
     return exp2_of_scale(qa) + exp2_of_scale(k_amax);
 }
+
+#ifdef PD_LAB
+extern "C" __attribute__((visibility("default"))) int pd_lab_set_pipe_trace(void* buf) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_trace), &q, sizeof(q)) == hipSuccess ? PD_OK : PD_ERR_LAUNCH;
+}
+#endif
 
 // can this launch take the pipelined kernel?  (fp16-format unsplit launches whose bias - if any - was produced pre-scaled)
 extern "C" int pd_attention_pipe_ok(const pd_attn_args* a) {
