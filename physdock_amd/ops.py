@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import threading
 
 import torch
@@ -402,7 +403,19 @@ def attn_split_ws_numel(nbatch, nq, nk, nheads):
     blocks = nbatch * nheads * ((nq + 127) // 128)
     nit = (nk + 63) // 64
     if blocks >= 512 or nit < 8:
-        return 0
+        if os.environ.get("PD_ATTN_TAIL") != "1":
+            return 0
+        # lab builds with -DPD_ATTN_TAIL=1 (tools/ab_tail.sh): scratch for the key-split TAIL round of a chip-filling pipelined launch -
+        # the arithmetic of csrc/attention.hip attn_tail (measured: no gain, NOTES round 5; the shipped library never asks for it)
+        bps = nheads * ((nq + 255) // 256)
+        if nq <= 128 or bps > 256 or 512 % bps:
+            return 0
+        per = 512 // bps
+        bt = nbatch % per
+        if nbatch < per or bt == 0 or bt * bps > 256:
+            return 0
+        s = min(4, 512 // (bt * bps), nit // 4)
+        return s * bt * nq * nheads * 34 if s >= 2 else 0
     s = min(8, 1024 // blocks, nit // 4)
     return s * nbatch * nq * nheads * 34 if s >= 2 else 0
 
