@@ -177,3 +177,24 @@ def test_in_place_weight_updates_are_seen_by_the_version_sum():
         p.add_(1.0)
     assert m._param_versions() == v0 + 2
     # (writes through `p.data` bypass autograd's version counters by design: after those, call model._invalidate())
+
+
+def test_prepare_batch_picks_the_tokens_per_block_of_the_fused_pool():
+    """PhysDock._prepare_batch (host-side boundary bookkeeping): `_pool_tpb` = as many consecutive tokens as are sure to hold <= 64
+    atoms (csrc/pool.hip stages at most 64 atom rows per block), 0 = a token of more than 64 atoms -> the two-launch form; the
+    padding of ragged systems keeps padded atoms out of every token segment"""
+    import torch
+    from physdock_amd import PhysDock
+    from physdock_amd.synthetic import make_batch, small_batch
+    b = PhysDock._prepare_batch(small_batch(0))
+    chunk = b["token_id_to_chunk_sizes"]
+    assert b["_pool_tpb"] == min(32, 64 // int(chunk.max())) and int(b["_tok_start"][-1]) == b["_A_real"]
+    rag = PhysDock._prepare_batch(make_batch(221, 8, 35, 64, 2))          # T = 256, A = 1803 -> padded to a multiple of 64
+    assert rag["ref_pos"].shape[0] % 64 == 0 and rag["_A_real"] == 1803 and int(rag["_tok_start"][-1]) == 1803
+    assert rag["_pool_tpb"] == 64 // int(rag["token_id_to_chunk_sizes"].max())
+    big = dict(small_batch(0))
+    big["token_id_to_chunk_sizes"] = big["token_id_to_chunk_sizes"].clone()
+    n = int(big["token_id_to_chunk_sizes"].sum())
+    big["token_id_to_chunk_sizes"][:] = 0
+    big["token_id_to_chunk_sizes"][0] = n                                   # one token owning every atom
+    assert PhysDock._prepare_batch(big)["_pool_tpb"] == (0 if n > 64 else min(32, 64 // n))
