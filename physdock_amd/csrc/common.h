@@ -20,6 +20,13 @@ static inline int pd_check_launch() {
 
 __device__ __forceinline__ float pd_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float pd_silu(float x) { return x / (1.0f + __expf(-x)); }
+// The same on the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division, which hipcc expands into ten VALU instructions
+// (v_div_scale x 2, v_rcp, four fma, v_div_fmas, v_div_fixup).  Used where it was measured to pay (round 5, tools/ab_silu.sh): the SwiGLU
+// epilogue of the GEMM kernels (token up-projection 130.2 -> 126.9 us), the fused pool, the atom-pair FFN (921 -> 785 us).  NOT used in
+// transition_f16.hip: there the reciprocal form compiles to 164 instead of 200 registers and a schedule that runs 11 % SLOWER (153.8 ->
+// 170.7 us at 64 samples, 34 -> 52 us at one).  exp(-x) = inf (x < -88.7) gives rcp = 0 and silu = -0, as the division does.
+__device__ __forceinline__ float pd_sigmoid_r(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float pd_silu_r(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // activation ids shared by prologues/epilogues
 enum { PD_ACT_NONE = 0, PD_ACT_SILU = 1, PD_ACT_SIGMOID = 2, PD_ACT_RELU = 3 };

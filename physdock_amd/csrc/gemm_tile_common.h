@@ -47,7 +47,7 @@ __device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&a
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float a = acc[i][0][4 * g + e] + c0[0], b = acc[i][TN - 1][4 * g + e] + c0[TN - 1];
-                    o[e] = (p.glu == 1 ? pd_silu(a) * b : a * pd_sigmoid(b)) * sc[e];
+                    o[e] = (p.glu == 1 ? pd_silu_r(a) * b : a * pd_sigmoid_r(b)) * sc[e];
                 }
                 *reinterpret_cast<f32x4*>(Yo + 8 * g) = o;
             }
@@ -56,11 +56,11 @@ __device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&a
             if (p.glu == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu(acc[i][0][r] + c0[0]) * (acc[i][TN - 1][r] + c0[TN - 1]));
+                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu_r(acc[i][0][r] + c0[0]) * (acc[i][TN - 1][r] + c0[TN - 1]));
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], (acc[i][0][r] + c0[0]) * pd_sigmoid(acc[i][TN - 1][r] + c0[TN - 1]));
+                    PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], (acc[i][0][r] + c0[0]) * pd_sigmoid_r(acc[i][TN - 1][r] + c0[TN - 1]));
             }
         } else {
 #pragma unroll
@@ -142,7 +142,7 @@ __device__ __forceinline__ void epilogue(const pd_gemm_args& p, const f32x16 (&a
                     if (p.act == PD_ACT_SILU) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu(acc[i][j][r] + c0[j]));
+                            PD_ST((Yo + pd_frag_row(r, 0) * ldy)[yoff], pd_silu_r(acc[i][j][r] + c0[j]));
                     } else if (p.act == PD_ACT_NONE) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)

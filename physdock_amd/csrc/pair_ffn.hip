@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 1) void atom_pair_ffn_kernel(float* __restrict
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float hid = pd_silu(a[r]) * b[r];
+                const float hid = pd_silu_r(a[r]) * b[r];
                 y = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[hb][r], hid, y, 0, 0, 0);
             }
         }

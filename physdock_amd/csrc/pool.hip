@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 4) void downscale_pool_kernel(const float* __r
             u32x4 fh, fm, fl;
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
-                const pd_parts t = pd_split2(pd_silu(__builtin_fmaf(acc[i][e8 + 2 * s2], cs, bv)), pd_silu(__builtin_fmaf(acc[i][e8 + 2 * s2 + 1], cs, bv)));
+                const pd_parts t = pd_split2(pd_silu_r(__builtin_fmaf(acc[i][e8 + 2 * s2], cs, bv)), pd_silu_r(__builtin_fmaf(acc[i][e8 + 2 * s2 + 1], cs, bv)));
                 fh[s2] = t.h; fm[s2] = t.m; fl[s2] = t.l;
             }
             pz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pm[q], __builtin_bit_cast(bf16x8, fl), pz, 0, 0, 0);
