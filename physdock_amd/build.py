@@ -87,6 +87,8 @@ def compile_cmd(src, out, mode=("-c",)):
         cmd[1:1] = ["-DPD_PIPE_XCD=" + os.environ["PD_PIPE_XCD"]]
     if os.environ.get("PD_PIPE_ABL") and base == "attn_pipe.hip":      # lab: timing ablations of the pipelined attention (wrong results)
         cmd[1:1] = ["-DPD_PIPE_ABL=" + os.environ["PD_PIPE_ABL"]]
+    if os.environ.get("PD_TR_SILU") and base == "transition_f16.hip":     # lab: form of the SiLU in the fused transition (0 division, 1 / 2 reciprocal)
+        cmd[1:1] = ["-DPD_TR_SILU=" + os.environ["PD_TR_SILU"]]
     if os.environ.get("PD_TRANSITION_MIN128") and base == "transition_f16.hip":     # lab: 128-row tiles from which the fused transition takes a launch
         cmd[1:1] = ["-DPD_TRANSITION_MIN128=" + os.environ["PD_TRANSITION_MIN128"]]
     if os.environ.get("PD_TRANSITION_BM") and base == "transition_f16.hip":     # lab: 128-row tiles, one block per CU
