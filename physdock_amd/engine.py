@@ -697,7 +697,7 @@ class Engine:
             "token") is taken off the fp16 format for this engine (bf16 x 6 needs no bound), with a warning.
         "Typical magnitude" = root mean square over the rows' median |x| would be costlier; the rms of the operand is used.
         Returns the set of families switched off by THIS check (the caller then re-prepares the call).  Not part of any
-        captured graph; costs three eager denoiser passes once per (weights, shape)."""
+        captured graph; costs three eager denoiser passes once per (weights, noise schedule)."""
         import warnings
         # (while self.probe is set, dit_block materialises v, o and h as fp32 tensors: no pre-split k | v, no split attention output, no
         #  fused atom transition - a per-ENGINE switch: replicas of a StreamPool run their checks while other replicas sample)
