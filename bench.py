@@ -381,8 +381,11 @@ def main():
             td.gather(x, gathered, dst=0)
         return x
 
-    for i in range(args.warmup):
+    warm_ms = []
+    for i in range(args.warmup):          # (timed one by one for `extra.first_call_ms`: nothing here is part of the measured region)
+        torch.cuda.synchronize(); t_w = time.perf_counter()
         one_call(i)
+        torch.cuda.synchronize(); warm_ms.append(1e3 * (time.perf_counter() - t_w))
     logger = None
     if args.launch_log and rank == 0:        # profiling runs only (eager calls): shapes of every launch, no events, no timing claim
         from physdock_amd import ops as _ops
@@ -499,7 +502,8 @@ def main():
         extra = {}
         for Bx in (1, 20):
             kwx = dict(kw, num_sample=Bx)
-            model.sample_diffusion(dbatch, seed=7, **kwx)                 # graph capture / warm-up
+            model.sample_diffusion(dbatch, seed=6, **kwx)                 # unit capture
+            model.sample_diffusion(dbatch, seed=7, **kwx)                 # whole-loop capture / warm-up
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(3):
@@ -518,7 +522,8 @@ def main():
         # (every round runs its own trunk, as when the loader re-samples the MSA per round - `batch_msa_feat`, redocking.py:83;
         #  `shared_trunk_*`: rounds that see identical features take round 0's conditioning, driver.redock(reuse_conditioning=True))
         rk["reuse_conditioning"] = False
-        driver.redock(model, dbatch, seed=5, **rk)
+        for _w in range(2):                     # (unit capture, then whole-loop capture of each round's schedule)
+            driver.redock(model, dbatch, seed=5, **rk)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(2):
@@ -529,7 +534,8 @@ def main():
                                      "samples_per_round": 20, "poses_kept": int(res["poses"].shape[0]),
                                      "pdb_blocks": len(res["pdb_blocks"])}
         rks = dict(rk, reuse_conditioning=True)
-        driver.redock(model, dbatch, seed=5, **rks)
+        for _w in range(2):
+            driver.redock(model, dbatch, seed=5, **rks)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(2):
@@ -550,13 +556,18 @@ def main():
         torch.cuda.synchronize(); t_miss = time.perf_counter() - t0
         cap_ms = model.last_capture_ms
         t0 = time.perf_counter()
+        model.sample_diffusion(rdb, seed=71, **kwr)                         # second call of the schedule: unit replay + whole-loop capture
+        torch.cuda.synchronize(); t_second = time.perf_counter() - t0
+        t0 = time.perf_counter()
         for i in range(2):
-            model.sample_diffusion(rdb, seed=71 + i, **kwr)
+            model.sample_diffusion(rdb, seed=72 + i, **kwr)
         torch.cuda.synchronize(); t_hit = (time.perf_counter() - t0) / 2
-        extra["graph_cache"] = {"new_shape_call_ms": 1e3 * t_miss, "cached_shape_call_ms": 1e3 * t_hit, "capture_ms": cap_ms,
+        extra["graph_cache"] = {"new_shape_call_ms": 1e3 * t_miss, "second_call_ms": 1e3 * t_second, "cached_shape_call_ms": 1e3 * t_hit, "capture_ms": cap_ms,
+                                "unit_graphs_cached": len(model._units), "whole_loop_graphs_cached": sum(1 for g_ in model._graphs.values() if g_["exec"]),
                                 "max_cached_graphs": model.max_cached_graphs,
-                                "note": "new shape = ragged T 256 / A 1803 system at 20 samples: workspace allocation + eager pass + capture; "
-                                        "graphs are keyed by padded AND real atom / token counts and the ligand size"}
+                                "note": "new shape = ragged T 256 / A 1803 system at 20 samples: workspace allocation + eager pass + capture of the step "
+                                        "units (one hipGraph per step head / tail; heads keyed by shape + schedule + step, tails by what the physics "
+                                        "branch depends on); the second call of a schedule captures the whole loop as one graph"}
         # the same ligands two at a time on two HIP streams of this GPU (parallel.StreamPool): their half-empty tail rounds overlap
         from physdock_amd.parallel import StreamPool
         pool = StreamPool(model, n=2)
@@ -577,7 +588,8 @@ def main():
         kwm = dict(kw, ref_mol=terms, mmff_iters=5)
         sig, plan = model._step_plan(nsteps, 0.8, 1.0, 1.5, 1.0, kw.get("mmff_gamma_0_factor", 1.0), kw.get("align_ref_pos", True), 1000)
         n_relax = sum(1 for p_ in plan if p_["mmff"] and not p_["align"])
-        model.sample_diffusion(dbatch, seed=40, **kwm)
+        for _w in range(2):
+            model.sample_diffusion(dbatch, seed=40, **kwm)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(2):
@@ -587,11 +599,46 @@ def main():
         assert torch.isfinite(xm).all()
         extra["samples_64_mmff"] = {"poses_per_s": B / dt, "ms_per_call": 1e3 * dt, "relaxation_steps": n_relax,
                                     "ligand_atoms": int(lig.sum()), "mmff_iters": 5, "backend": "device (pd_mmff_relax, fp64)"}
+        # ---- the headline's own worst cases
+        # (a) first calls at B = 64: call 1 = workspace allocation + trunk + first-call bound check (three eager denoiser passes) + eager
+        #     loop + capture of the 80 step units; call 2 = unit replay + capture of the whole-loop graph; call 3+ = one graph replay
+        extra["first_calls_b64_ms"] = {"call_1": round(warm_ms[0], 1) if warm_ms else None,
+                                       "call_2": round(warm_ms[1], 1) if len(warm_ms) > 1 else None,
+                                       "steady_state": round(1e3 * elapsed / args.steps, 1)}
+        # (b) a NEW physics threshold on a cached shape (redocking.py:318-322 changes mmff_gamma_0_factor every round): the 40 denoiser
+        #     heads replay, only the tails whose branch changed run eagerly and are captured
+        if not args.no_physics and not args.no_graph:
+            kwf = dict(kw, mmff_gamma_0_factor=6.9)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            model.sample_diffusion(dbatch, seed=60, **kwf)
+            torch.cuda.synchronize(); t_new = time.perf_counter() - t0
+            extra["new_threshold_call_b64"] = {"ms": round(1e3 * t_new, 1), "unit_misses": model.last_unit_misses,
+                                               "head_misses": model.last_head_misses, "capture_ms": round(model.last_capture_ms or 0.0, 2)}
+        # (c) weights whose magnitude bounds turn out too loose for the two-part fp16 format run the DiT on bf16 x 6 (engine.check_dit_bounds
+        #     switches a family off): the same 64-sample call with BOTH families forced off the fp16 format
+        eng_ = model.engine(device)
+        saved_off = set(eng_.f16_off)
+        eng_.f16_off = {"atom", "token"}
+        model._drop_graphs()
+        try:
+            for i in range(2):
+                model.sample_diffusion(dbatch, seed=61 + i, **kw)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(2):
+                xf = model.sample_diffusion(dbatch, seed=63 + i, **kw)
+            torch.cuda.synchronize(); dtf = (time.perf_counter() - t0) / 2
+            assert torch.isfinite(xf).all()
+            extra["bf16x6_fallback"] = {"poses_per_s": B / dtf, "ms_per_call": 1e3 * dtf,
+                                        "note": "DiT atom + token families off the fp16 x 3 format (bf16 x 6, no bounds needed); trunk unchanged"}
+        finally:
+            eng_.f16_off = saved_off
+            model._drop_graphs()
         # ---- BASELINE config #4: synthetic crop at crop_size=512 / atom_crop_size=4096 (tiling stress), same model and call
         model.release_workspace()
         batch2, dbatch2, confs2 = make_crop("cfg2", device)
         kw2c = dict(kw, ref_mol_poses=confs2.to(device)) if not args.no_physics else dict(kw)
-        model.sample_diffusion(dbatch2, seed=50, **kw2c)
+        for _w in range(2):
+            model.sample_diffusion(dbatch2, seed=50, **kw2c)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(2):

@@ -304,7 +304,8 @@ int pd_unpool_add(float* ba, const float* us, const long long* a2t, int B, int A
  * layers/transformers.py:205-212; csrc/pool.hip): out[b,t,:] = sum_{atoms l of t} silu(W ba[b,l,:] + bias) / (n_t + 1e-3) + add[t,:].
  * ba [B][A][128]; W2 / w_inv = the two fp16 parts of W [N][128] (fragment-major) and its inverse row scales (packing.split2_f16) -
  * the A operand's power-of-two scale is the block's own: the maximum of the tile it stages; tok_start [T + 1]; tpb tokens per block
- * (1..32) with the caller's guarantee that tpb consecutive tokens hold at most 64 atoms.  PD_ERR_UNSUPPORTED: other shapes.        */
+ * (1..32) with the caller's guarantee that tpb consecutive tokens hold at most 64 atoms (the table is device memory: a block that
+ * finds more writes NaN into its tokens' rows instead of a wrong mean).  PD_ERR_UNSUPPORTED: other shapes.                         */
 int pd_downscale_pool(const float* ba, const void* W2, const float* w_inv, const float* bias, const int* tok_start, const float* add,
                       float* out, int B, int A, int T, int Cin, int N, int tpb, void* stream);
 int pd_gather_rows_add(float* y, const float* x, const long long* idx, int R, int C, void* stream);

@@ -279,11 +279,12 @@ def template_pair_embedder(P, name, batch, z, inf, eps):
     return linear(P, name + ".linear_out", F.relu(rms_norm(P, name + ".norm_out", u, eps))) * batch["t_mask"]
 
 
-def token_embedder(P, name, batch, a, inf, eps, return_parts=False):
-    """layers/diffusion_conditioning.py:178-202."""
+def token_embedder(P, name, batch, a, inf, eps, return_parts=False, s_pool=None):
+    """layers/diffusion_conditioning.py:178-202.  ``s_pool`` (diagnostics only, tools/pool_noise_cpu.py): a replacement for
+    the pooled atom activations (the output of the reference's `downscale`, :168-176)."""
     chunk = batch["token_id_to_chunk_sizes"]
     z_mask = batch["z_mask"]
-    s = segment_mean_pool(F.silu(linear(P, name + ".linear_a", a)), chunk)
+    s = segment_mean_pool(F.silu(linear(P, name + ".linear_a", a)), chunk) if s_pool is None else s_pool
     s = s + linear(P, name + ".linear_target_feat", batch["target_feat"]) \
           + linear(P, name + ".linear_key_res_feat", batch["key_res_feat"]) \
           + linear(P, name + ".linear_pocket_res_feat", batch["pocket_res_feat"][..., None])
@@ -305,11 +306,11 @@ def token_embedder(P, name, batch, a, inf, eps, return_parts=False):
     return s, z
 
 
-def diffusion_conditioning(P, batch, inf=1e9, eps=1e-8, name="diffusion_conditioning"):
+def diffusion_conditioning(P, batch, inf=1e9, eps=1e-8, name="diffusion_conditioning", s_pool=None):
     """layers/diffusion_conditioning.py:232-238 -> (a, ap, s, z)."""
     a2t = batch["atom_id_to_token_id"]
     a, ap = atom_embedder(P, name + ".atom_embedder", batch, inf, eps)
-    s, z = token_embedder(P, name + ".token_embedder", batch, a, inf, eps)
+    s, z = token_embedder(P, name + ".token_embedder", batch, a, inf, eps, s_pool=s_pool)
     a = a + linear(P, name + ".linear_s", rms_norm(P, name + ".norm_s", s, eps))[a2t]
     ap = ap + linear(P, name + ".linear_z", rms_norm(P, name + ".norm_z", z, eps))[a2t][:, a2t]
     return a, ap, s, z

@@ -20,6 +20,7 @@ Nothing here touches the HIP library: importing stays CPU-safe, the first kernel
 """
 import importlib
 import importlib.util
+import os
 import runpy
 import sys
 import types
@@ -88,8 +89,14 @@ def main(argv=None):
     if not argv:
         sys.stderr.write("usage: python -m physdock_amd.compat <reference driver .py> [its arguments]\n")
         return 2
+    # the driver's own directory first, as `python redocking.py` would have it (runpy.run_path does not add it for a plain file):
+    # the reference checkout beside the script must be found BEFORE install() decides between patching it and synthesising modules
+    sys.path.insert(0, os.path.dirname(os.path.abspath(argv[0])))
     mode = install()
     sys.stderr.write(f"physdock_amd.compat: PhysDock import paths bound ({mode})\n")
+    if mode == "synthetic":
+        sys.stderr.write("physdock_amd.compat: no PhysDock checkout beside the script or on sys.path - only PhysDock.models.model, "
+                         "PhysDock.utils.* and the top-level names are bound; a driver that imports PhysDock.data will fail\n")
     sys.argv = argv
     runpy.run_path(argv[0], run_name="__main__")
     return 0

@@ -40,7 +40,11 @@ __global__ __launch_bounds__(256, 4) void downscale_pool_kernel(const float* __r
     const int ntok = T - t0 < tpb ? T - t0 : tpb;
     const int a0 = tok_start[t0];
     int n = tok_start[t0 + ntok] - a0;
-    n = n > ROWS ? ROWS : n;                               // (the launcher guarantees n <= 64)
+    // The launcher's contract is n <= 64 (tpb = 64 / max atoms per token).  The token table lives in device memory, so the C entry point
+    // cannot check it: a block that finds more atoms writes NaN for its tokens - the caller's finite check fails loudly instead of a
+    // silently wrong mean.
+    const bool over = n > ROWS;
+    n = over ? ROWS : n;
 
     // ---- stage the block's atom rows: the tile's own maximum -> power-of-two scale -> two fp16 parts, once
     float a_s;
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256, 4) void downscale_pool_kernel(const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tt = pd_frag_row(r, hh);
-            if (tt < ntok) op[(long long)tt * N] = pz[r] * inv[r] + (ad ? ad[(long long)tt * N] : 0.f);
+            if (tt < ntok) op[(long long)tt * N] = over ? __builtin_nanf("") : pz[r] * inv[r] + (ad ? ad[(long long)tt * N] : 0.f);
         }
     }
 }
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(256, 4) void downscale_pool_kernel(const float* __r
 // ba [B][A][128] fp32 (row pitch 128), W2 / w_inv = packing.split2_f16 of the [N][128] weight (two fp16 parts, fragment-major, and the
 // inverse row scales), bias [N] or NULL, tok_start [T + 1] (atoms of a token contiguous, tokens ascending), add [T][N] or NULL, out
 // [B][T][N].  tpb tokens per block, 1 .. 32, and the caller guarantees that tpb consecutive tokens never hold more than 64 atoms (tpb =
-// 64 / max atoms per token).  PD_ERR_UNSUPPORTED for other shapes: run pd_gemm (act = SiLU) + pd_segment_pool.
+// 64 / max atoms per token); a block that finds more writes NaN into its tokens' rows.  PD_ERR_UNSUPPORTED for other shapes: run pd_gemm
+// (act = SiLU) + pd_segment_pool.
 PD_EXPORT int pd_downscale_pool(const float* ba, const void* W2, const float* w_inv, const float* bias, const int* tok_start, const float* add,
                                 float* out, int B, int A, int T, int Cin, int N, int tpb, void* stream) {
     if (!ba || !W2 || !w_inv || !tok_start || !out || B <= 0 || A <= 0 || T <= 0) return PD_ERR_ARG;

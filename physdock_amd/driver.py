@@ -211,5 +211,5 @@ def redock_many(model, systems, *, streams: Optional[int] = None, **common) -> L
     if n <= 1 or len(items) <= 1 or not on_gpu:
         return [redock(model, b, **dict(common, **kw)) for b, kw in items]
     from .parallel import StreamPool
-    pool = StreamPool(model, n=n)
+    pool = common.pop("pool", None) or StreamPool.for_model(model, n=n)      # cached on the model: replicas are built once
     return pool.map(lambda m, it: redock(m, it[0], **dict(common, **it[1])), items)

@@ -70,8 +70,12 @@ class PhysDock(nn.Module):
         self._packed: Optional[PackedWeights] = None
         self._engine: Optional[Engine] = None
         self._packed_versions = None
-        self._graphs = {}                 # step-loop hipGraphs, LRU-ordered (dict insertion order)
+        self._graphs = {}                 # whole step-loop hipGraphs per (shape, schedule, physics plan), LRU-ordered (dict insertion order)
+        self._units = {}                  # per-step head / tail hipGraphs (sample_diffusion: "the loop as UNITS"), LRU-ordered
         self.max_cached_graphs = 64       # a screening stream over one receptor needs one graph per ligand SIZE (18 - 44 atoms in the demo)
+        self.max_cached_units = 64 * 96   # 40 heads + 40 tails (+ gathers) per shape
+        self.unit_captures = self.whole_captures = 0     # counters (tests, bench.py): unit graphs / whole-loop graphs captured so far
+        self.last_unit_misses = self.last_head_misses = 0
         self.last_capture_ms = None       # host time of the most recent graph capture + instantiation (bench.py reports it)
         #: workspace buffers are cached per shape (288 GB of HBM make re-allocation pointless for a stream of
         #: same-size crops); when systems of many different sizes pass through, the cache is dropped beyond this size
@@ -82,13 +86,17 @@ class PhysDock(nn.Module):
     def _invalidate(self):
         self._packed = None
         self._engine = None
+        self._stream_pool = None          # parallel.StreamPool.for_model: replicas hold copies of the old weights
         self._drop_graphs()
 
     def _drop_graphs(self):
         for g in self._graphs.values():
-            for ex in g["exec"]:
+            for ex in g["exec"] or ():
                 ops._lib.lib().pd_graph_destroy(ex)
+        for u in self._units.values():
+            ops._lib.lib().pd_graph_destroy(u["exec"])
         self._graphs = {}
+        self._units = {}
 
     def release_workspace(self):
         """free every cached activation buffer and captured step-loop graph (they are rebuilt on the next call)"""
@@ -288,8 +296,15 @@ class PhysDock(nn.Module):
         # family to bf16 x 6 and the call is re-prepared.  Once per (weights, schedule); replays and later systems pay nothing.
         ck = (steps, float(sig[0]), float(sig[-2]), float(gamma_0), float(gamma_min))
         if _BOUND_CHECK and ops.F16_GEMM and ops.SPLIT_GEMM and ck not in eng._bounds_checked:
-            eng._bounds_checked.add(ck)
-            if eng.check_dit_bounds(batch, a, s, prep, plan, B, float(self.sigma_data)):
+            if ck in eng._bounds_failed:         # a violated bound stays an exception on EVERY later call of this engine + schedule
+                raise eng._bounds_failed[ck]
+            try:
+                switched = eng.check_dit_bounds(batch, a, s, prep, plan, B, float(self.sigma_data))
+            except FloatingPointError as e:
+                eng._bounds_failed[ck] = e
+                raise
+            eng._bounds_checked.add(ck)          # only a check that RETURNED counts
+            if switched:
                 self._drop_graphs()
                 prep = eng.prepare_dit(a, ap, s, z, batch, tau, B=B)
 
@@ -361,7 +376,7 @@ class PhysDock(nn.Module):
         k_noisy = [sum(q["noisy"] for q in plan[:i]) for i in range(steps)]
 
         def step_head(i):
-            """model.py:212-221: augmentation, noise injection, denoiser (and the ligand read-out of a host relaxation)"""
+            """model.py:212-221: augmentation, noise injection, denoiser (the ligand read-out of a host relaxation: gather_fn below)"""
             p = plan[i]
             sp_ = ops.stream()
             if i == 0 and any_align:     # `batch_ref_pos = ref_pos[None].repeat(...)` (model.py:183): part of the replayed loop
@@ -380,8 +395,6 @@ class PhysDock(nn.Module):
             ops.check(L.pd_augment(ops.ptr(src), x_scale, ops.ptr(batch["a_mask"]), ru, tr, nz, float(noise_scale_lambda),
                                    p["sdev"], sd_ptr, i, sample_offset, ops.ptr(x_hat), B, A, sp_), "augment")
             eng.af3_dit(batch, x_hat, x_den, a, s, prep, B, p, row=i)
-            if p["mmff"] and relaxer.kind == "host":
-                ops.check(L.pd_ligand_gather(ops.ptr(x_den), ops.ptr(lig_idx), ops.ptr(lig_in), B, A, n_lig, sp_), "ligand_gather")
 
         def step_tail(i):
             """model.py:223-281: physics correction and Euler update"""
@@ -408,79 +421,128 @@ class PhysDock(nn.Module):
             ops.check(L.pd_euler(ops.ptr(x_hat), ops.ptr(x_den), ops.ptr(x_proj), ops.ptr(lig_w), p["t_hat"], p["eta"],
                                  p["dt"], ops.ptr(x_a), B, A, sp_), "euler")
 
-        # The loop is host-deterministic except for a host relaxation, which needs the denoised ligand on the host in
-        # the middle of a step: segments end after the head of such a step and the next one starts with its tail.
-        segments, cur = [], []
-        for i, p in enumerate(plan):
-            cur.append((step_head, i))
-            if p["mmff"] and relaxer.kind == "host":
-                segments.append((cur, i))
-                cur = []
-            cur.append((step_tail, i))
-        segments.append((cur, None))
+        # ---- the loop as UNITS (round 6): one unit = the launches of one step's head (augmentation + denoiser: ~115 kernels, the
+        #      expensive part) or of one step's tail (physics correction + Euler update: 1 - 4 kernels).  A head depends on the shape,
+        #      the schedule and the step index only; what the drivers change between calls - the physics threshold
+        #      (`mmff_gamma_0_factor` x 1.15 / x 0.7 per round, redocking.py:318-322), the template pool size, the relaxation - lives in
+        #      the tails.  Every unit is captured as its own hipGraph, keyed by exactly what its launches depend on, so a call with a new
+        #      threshold or pool replays all 40 heads and the unchanged tails and runs (then captures) only the few tails that changed.
+        #      A whole schedule seen twice is additionally captured as ONE graph (segments around a host relaxation), as before.
+        sched_id = (steps, float(sig[0]), float(sig[-2]), float(gamma_0), float(gamma_min), float(karras_noise_schedule_power))
+        common = (B, A, batch["target_feat"].shape[0], batch["_A_real"], batch["_T_real"], sched_id, noise is not None,
+                  float(noise_scale_lambda), sample_offset)
+        host_relax_steps = relaxer.kind == "host"
+        pool_sig = poses is not None and (n_conf, n_lig)
+        relax_sig = (relaxer.kind, relaxer.kind == "device" and relaxer.terms.signature(), int(mmff_iters), n_lig)
 
-        def run_segment(seg):
-            for fn, i in seg:
+        def gather_fn(i):
+            ops.check(L.pd_ligand_gather(ops.ptr(x_den), ops.ptr(lig_idx), ops.ptr(lig_in), B, A, n_lig, ops.stream()), "ligand_gather")
+
+        units = []                   # (key, [(fn, i), ...], host break after this unit?)
+        for i, p in enumerate(plan):
+            units.append(((common, "H", i, p["noisy"], p["sdev"], p["t_hat"], i == 0 and any_align), [(step_head, i)], False))
+            if p["mmff"] and host_relax_steps:
+                units.append(((common, "G", i, n_lig), [(gather_fn, i)], True))
+            kind = ("align", pool_sig) if p["align"] else (("mmff", relax_sig) if p["mmff"] else ("plain",))
+            units.append(((common, "T", i, p["t_hat"], p["eta"], p["dt"], kind), [(step_tail, i)], False))
+        segments, cur = [], []
+        for ukey, fns, brk in units:
+            cur.extend(fns)
+            if brk:
+                segments.append(cur)
+                cur = []
+        segments.append(cur)
+
+        def run_fns(fns):
+            for fn, i in fns:
                 fn(i)
 
         def host_relax():
             lig_out.copy_(relaxer(lig_in.clone(), int(mmff_iters)).to(device=device, dtype=torch.float32))
 
-        graphs = None
+        def capture(fn_lists):
+            """record (not run) each launch list as one hipGraph; one capture at a time per process: objects driven from several host
+            threads (parallel.StreamPool) replay concurrently, but two overlapping captures make unrelated launches of the other
+            thread fail"""
+            import time as _time
+            with _CAPTURE_LOCK:
+                torch.cuda.synchronize()
+                t_cap = _time.perf_counter()
+                execs = []
+                cap = torch.cuda.Stream()
+                with torch.cuda.stream(cap):
+                    for fns in fn_lists:
+                        ops.check(L.pd_graph_begin(ops.stream()), "graph_begin")
+                        run_fns(fns)
+                        ex = C.c_void_p()
+                        ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
+                        execs.append(ex)
+                torch.cuda.synchronize()
+                self.last_capture_ms = 1e3 * (_time.perf_counter() - t_cap)
+            return execs
+
+        fresh = not use_graph                 # did any launch of this call run eagerly (= was not replayed from a checked capture)?
+        entry = None
         if use_graph:
             # (the REAL atom / token counts are launch arguments - reduction bounds - of the captured kernels: two systems that pad
             #  to the same shape must not share a graph)
-            key = (B, A, batch["target_feat"].shape[0], batch["_A_real"], batch["_T_real"], steps, noise is not None,
-                   poses is not None and (n_conf, n_lig),
-                   relaxer.kind, relaxer.kind == "device" and relaxer.terms.signature(), any_mmff and int(mmff_iters),
-                   tuple((p["t_hat"], p["align"], p["mmff"], p["eta"]) for p in plan), float(noise_scale_lambda), sample_offset)
-            graphs = self._graphs.get(key)
-            if graphs is not None:
+            key = (common, tuple(u[0] for u in units))
+            entry = self._graphs.get(key)
+            if entry is not None:
                 self._graphs[key] = self._graphs.pop(key)          # LRU order
-        if graphs is not None:
-            for (seg, brk), g in zip(segments, graphs["exec"]):
+        if entry is not None and entry["exec"] is not None:
+            for k, g in enumerate(entry["exec"]):
                 ops.check(L.pd_graph_launch(g, sp), "graph_launch")
-                if brk is not None:
+                if k + 1 < len(segments):
+                    host_relax()
+        elif not use_graph:
+            for k, seg in enumerate(segments):
+                run_fns(seg)
+                if k + 1 < len(segments):
                     host_relax()
         else:
-            # eager pass: it produces this call's result AND allocates every workspace buffer, so the capture below
-            # (which only records) needs no launch of its own - a cache miss costs one loop, not two
-            for seg, brk in segments:
-                run_segment(seg)
-                if brk is not None:
+            # replay the units that exist; run the others eagerly - they produce this call's result AND allocate their workspace
+            # buffers, so the capture below (which only records) needs no launch of its own
+            missing = []
+            for ukey, fns, brk in units:
+                u = self._units.get(ukey)
+                if u is not None:
+                    self._units[ukey] = self._units.pop(ukey)      # LRU order
+                    ops.check(L.pd_graph_launch(u["exec"], sp), "graph_launch")
+                else:
+                    fresh = True
+                    run_fns(fns)
+                    missing.append((ukey, fns))
+                if brk:
                     host_relax()
-            if use_graph:
-                # one capture at a time per process: objects driven from several host threads (parallel.StreamPool) replay
-                # concurrently, but two overlapping captures make unrelated launches of the other thread fail
-                with _CAPTURE_LOCK:
-                    torch.cuda.synchronize()
-                    import time as _time
-                    t_cap = _time.perf_counter()
-                    execs = []
-                    cap = torch.cuda.Stream()
-                    with torch.cuda.stream(cap):
-                        for seg, brk in segments:
-                            ops.check(L.pd_graph_begin(ops.stream()), "graph_begin")
-                            run_segment(seg)
-                            ex = C.c_void_p()
-                            ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
-                            execs.append(ex)
-                    torch.cuda.synchronize()
-                    self.last_capture_ms = 1e3 * (_time.perf_counter() - t_cap)
-                # the captured launches hold raw device addresses: keep the MMFF table object whose tables were captured alive
-                # with the graph (a later call with an EQUAL table - same signature, e.g. rebuilt from the same RDKit
-                # molecule - replays against these tables, not against its own freshly built and soon freed ones)
-                self._graphs[key] = {"exec": execs, "terms": relaxer.terms if relaxer.kind == "device" else None}
-                while len(self._graphs) > self.max_cached_graphs:
-                    old = self._graphs.pop(next(iter(self._graphs)))
-                    for ex in old["exec"]:
-                        L.pd_graph_destroy(ex)
+            self.last_unit_misses = len(missing)
+            self.last_head_misses = sum(1 for k, _ in missing if k[1] == "H")
+            if missing:
+                # the captured launches hold raw device addresses: a unit keeps the MMFF table object whose tables it captured alive
+                # (a later call with an EQUAL table - same signature, e.g. rebuilt from the same RDKit molecule - replays against
+                # these tables, not against its own freshly built and soon freed ones)
+                terms = relaxer.terms if relaxer.kind == "device" else None
+                for (ukey, _), ex in zip(missing, capture([fns for _, fns in missing])):
+                    self._units[ukey] = {"exec": ex, "terms": terms if ukey[1] == "T" and ukey[-1][0] == "mmff" else None}
+                self.unit_captures += len(missing)
+                while len(self._units) > self.max_cached_units:
+                    L.pd_graph_destroy(self._units.pop(next(iter(self._units)))["exec"])
+            if entry is None:
+                entry = self._graphs[key] = {"exec": None, "terms": relaxer.terms if relaxer.kind == "device" else None}
+            else:
+                # the second call of the same schedule on the same shape: the whole N-step loop as ONE graph from here on
+                entry["exec"] = capture(segments)
+                self.whole_captures += 1
+            while len(self._graphs) > self.max_cached_graphs:
+                old = self._graphs.pop(next(iter(self._graphs)))
+                for ex in old["exec"] or ():
+                    L.pd_graph_destroy(ex)
         out = x_a[:, :A_real].clone()
         # Finite check: ALWAYS on the first call of a (shape, schedule, weights version) - the eager pass that precedes a graph capture,
         # and every eager call - and on every call with PD_CHECK_FINITE=1 (one tiny reduction + a host sync; replays stay sync-free).
         # A violated magnitude bound (weights changed behind the engine's back through `.data`, a caller-supplied bound that does not
         # hold) overflows the fp16 operand format to inf / NaN: that must be an exception, not a pose.
-        if (_CHECK_FINITE or graphs is None) and not bool(torch.isfinite(out).all()):
+        if (_CHECK_FINITE or fresh) and not bool(torch.isfinite(out).all()):
             if use_graph:
                 self._drop_graphs()          # the loop captured from this pass would replay the same overflow
             raise FloatingPointError("sample_diffusion produced non-finite coordinates: an fp16-format operand bound was violated "

@@ -209,7 +209,7 @@ def gemm(A, W, Y, M, N, K, *, lda=None, ldw=None, ldy=None, batch=1, sA=0, sW=0,
             a.stats_inline = 0
             a.stats = P(stats)
             rowstats(A, stats, M, K, ldx=a.lda, mode=mode_, eps=eps_)
-    if GEMM_HOOK is not None:
+    if GEMM_HOOK is not None and not getattr(_TLS, "no_hooks", False):
         return GEMM_HOOK(a, lambda: check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm"))
     check(_lib.init().pd_gemm(C.byref(a), stream()), "pd_gemm")
 
@@ -298,6 +298,9 @@ F16_TRUNK_GEMM = True
 #: optional profiling hook: GEMM_HOOK(args_struct, launch_fn) (bench.py brackets launches with HIP events)
 GEMM_HOOK = None
 ATTN_HOOK = None
+#: per-thread switch: `_TLS.no_hooks = True` hides the hooks from the launches of THIS host thread (engine.check_dit_bounds runs on
+#: StreamPool worker threads while other threads sample: it must not touch the process-wide hook variables)
+_TLS = threading.local()
 
 
 def rowstats(x, stats, M, Cdim, *, ldx=None, kmajor=False, mode=RMS, eps=1e-8):
@@ -463,7 +466,7 @@ def attention(Q, K, V, O, *, nq, nk, nbatch, nheads, q_strides, k_strides, v_str
         a.ws, a.ws_bytes = ptr(ws), ws.numel() * 4
     if query_only:            # the kernel pd_attention would pick (pd_attention_variant): >= 2000 = fp16-parts kernel
         return _lib.init().pd_attention_variant(C.byref(a))
-    if ATTN_HOOK is not None:
+    if ATTN_HOOK is not None and not getattr(_TLS, "no_hooks", False):
         return ATTN_HOOK(a, lambda: check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention"))
     check(_lib.init().pd_attention(C.byref(a), stream()), "pd_attention")
 

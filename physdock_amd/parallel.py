@@ -110,6 +110,20 @@ class StreamPool:
     (weights + split weights + workspace) - 2 x ~6 GB at the benchmark crop.
     """
 
+    @classmethod
+    def for_model(cls, model, n: int = 2):
+        """The pool cached ON the model (`model._stream_pool`): replicas (a state-dict copy, re-packed weights, the first-call bound
+        check and the captured step-loop graphs - seconds and ~6 GB each) are built once per (model, n, weights version), not once
+        per `redock_many` call.  A model whose parameters changed since (load_state_dict, in-place updates: the sum of the
+        parameters' version counters, `PhysDock._param_versions`) gets a fresh pool."""
+        ver = model._param_versions() if hasattr(model, "_param_versions") else 0
+        cached = getattr(model, "_stream_pool", None)
+        if cached is not None and cached[0] == (n, ver):
+            return cached[1]
+        pool = cls(model, n=n)
+        model._stream_pool = ((n, ver), pool)
+        return pool
+
     def __init__(self, model, n: int = 2):
         import torch
         from .model import PhysDock

@@ -338,6 +338,49 @@ def test_driver_redock_rounds_on_device(small):
     assert torch.equal(out["poses"], out2["poses"])
 
 
+def test_physics_rounds_replay_the_denoiser_units(small):
+    """Round 6 (reference redocking.py:181-335): the round loop changes `mmff_gamma_0_factor` (x 1.15 / x 0.7) and the
+    template pool between `sample_diffusion` calls, and every system has its own shape.  The step loop is captured as UNITS - one
+    hipGraph per step head (augmentation + denoiser, ~115 launches: depends on shape, schedule and step index only) and one per
+    step tail (physics + Euler, 1 - 4 launches) - so over the rounds of one system the heads are captured ONCE per shape, a changed
+    threshold or pool re-runs only the tails it changes, and the poses are bit-identical to the eager loop."""
+    from physdock_amd import driver, mmff
+    from physdock_amd.synthetic import reference_conformers
+    model, cfg, P, batch, dbatch = small
+    steps = 12
+    confs = reference_conformers(batch, n_conf=6).cuda()
+    lig = batch["is_ligand"][batch["atom_id_to_token_id"]].bool()
+    terms, _ = mmff.synthetic_terms(int(lig.sum()), seed=3)
+    verdicts = iter([True, False, True] * 20)
+    kw = dict(ref_mol=terms, ref_mol_poses=confs, accept_fn=lambda x: next(verdicts), physics_correction=True, max_samples=12,
+              max_rounds=4, num_samples_per_round=3, steps=steps, seed=11, mmff_gamma_0_factor_start=3.0)
+
+    def run(use_graph):
+        nonlocal verdicts
+        verdicts = iter([True, False, True] * 20)
+        return driver.redock(model, dbatch, sampler_kwargs=dict(use_graph=use_graph), **kw)
+    model.release_workspace()
+    eager = run(False)
+    factors = [r["gamma_factor"] for r in eager["rounds"]]
+    assert len(factors) == 4 and len(set(factors)) == 4, factors         # four rounds, four thresholds
+    u0, w0 = model.unit_captures, model.whole_captures
+    first = run(True)
+    assert torch.equal(first["poses"], eager["poses"])
+    heads = sum(1 for k in model._units if k[1] == "H")
+    # round 0 runs without the template branch (no reference copy in step 0's head), rounds 1+ with it: steps + 1 head units in all
+    assert heads == steps + 1, heads
+    assert model.whole_captures == w0                                     # no schedule was seen twice: no whole-loop capture
+    tails = model.unit_captures - u0 - heads
+    print(f"4 rounds x {steps} steps: {heads} head units captured once, {tails} tail units (of {4 * steps} tail launches)")
+    assert tails < 4 * steps
+    u1 = model.unit_captures
+    again = run(True)                                                     # every schedule now seen twice: whole-loop graphs, no new units
+    assert torch.equal(again["poses"], eager["poses"])
+    assert model.unit_captures == u1 and model.whole_captures == w0 + 4
+    third = run(True)                                                     # ... and replayed
+    assert torch.equal(third["poses"], eager["poses"]) and model.whole_captures == w0 + 4
+
+
 def test_graph_replay_is_independent_of_caller_tensors(small):
     """a captured step loop replays raw addresses: inputs of a later call (another system of the same shape, other
     reference conformers) must reach it although the first call's tensors are gone"""

@@ -78,7 +78,7 @@ def main():
     import warnings
     warnings.filterwarnings("ignore")
     ap_ = argparse.ArgumentParser()
-    ap_.add_argument("--sets", default="g1-7,g8,g9,g10,g11,g12,g13")
+    ap_.add_argument("--sets", default="g1-7,g8,g9,g10,g11,g12,g13,g14")
     sets = set(ap_.parse_args().sets.split(","))
     install_shims()
     os.makedirs(OUT, exist_ok=True)
@@ -115,6 +115,8 @@ def main():
         main_g12(RefConfig)
     if "g13" in sets:
         main_g13()
+    if "g14" in sets:
+        main_g14(RefPhysDock, RefConfig)
 
 
 class Recorder:
@@ -233,8 +235,13 @@ def main_g9(RefPhysDock, RefConfig, ref_model_module):
         # gains and AdaLN rows x 32-64, divided out of their consumers - the function is preserved, the operands of the
         # projections are not): the static magnitude bounds of the two-part fp16 format must hold and must not cost the precision
         ("cfg1_outlier", cfg1_batch(0), 8, 10, False),
+        # round 6: cfg2 on the schedule the metric is quoted on - 40 steps, p = 1000 (every other cfg2 fixture stops after 10)
+        ("cfg2_40", cfg2_batch(0), 8, 40, False),
     )
-    seed_stored = ("cfg1_b32", "cfg1_b64_40", "cfg2_b16", "cfg1_outlier")
+    seed_stored = ("cfg1_b32", "cfg1_b64_40", "cfg2_b16", "cfg1_outlier", "cfg2_40")
+    # round 6: fixtures that also record how far the REFERENCE ends from ITSELF when the atom activations entering the trunk's
+    # token pooling (`TokenEmbedder.downscale`, diffusion_conditioning.py:168-176) are moved by ONE fp32 ulp (OneUlpDownscale)
+    one_ulp_twin = ("cfg2_b16", "cfg2_40", "cfg1_b32")
     cpu_distance = ("cfg2_b16", "cfg1_b32")          # non-physics cases whose fixture also records the CPU restatement's own distance
     only = os.environ.get("PD_G9_ONLY")              # e.g. PD_G9_ONLY=cfg2: regenerate one case
     for tag, batch, B, steps, physics in cases:
@@ -256,6 +263,16 @@ def main_g9(RefPhysDock, RefConfig, ref_model_module):
             x_pred = ref_model.sample_diffusion(batch, num_sample=B, steps=steps, karras_noise_schedule_power=1000, **kw)
         nz = split_draws(r.log, B, steps, A)
         print(f"  reference medium/{tag}: T={batch['target_feat'].shape[0]} A={A} B={B} steps={steps}: {time.time() - t0:.0f} s")
+        if tag in one_ulp_twin:
+            t1 = time.time()
+            torch.manual_seed(900 + steps)
+            with OneUlpDownscale(ref_model):
+                x_twin = ref_model.sample_diffusion(batch, num_sample=B, steps=steps, karras_noise_schedule_power=1000, **kw)
+            per = (x_twin - x_pred).pow(2).sum(-1).mean(-1).sqrt()
+            extra["ref_one_ulp_rmsd"] = float(per.max())
+            extra["ref_one_ulp_rmsd_median"] = float(per.median())
+            print(f"  reference vs reference with ONE ulp in front of the trunk's token pooling on {tag}: worst sample "
+                  f"{float(per.max()):.3e} A, median {float(per.median()):.3e} A ({time.time() - t1:.0f} s)", flush=True)
         if tag in cpu_distance:
             # how far a SECOND CPU fp32 execution of the same mathematics (the oracle: stock PyTorch CPU fp32, same BLAS, a different
             # association in a few places) ends from the reference on this fixture: stored beside the trajectory, because at cfg2 it
@@ -278,6 +295,118 @@ def main_g9(RefPhysDock, RefConfig, ref_model_module):
             npz(f"g9_medium_{tag}", x_pred=x_pred, steps=steps, noise_seed=900 + steps, n_noisy=nz["diffuse"].shape[0], **extra)
             continue
         npz(f"g9_medium_{tag}", x_pred=x_pred, steps=steps, **extra, **{"noise_" + k: v for k, v in nz.items()})
+
+
+class OneUlpDownscale:
+    """While active, the atom activations entering `TokenEmbedder.downscale` (diffusion_conditioning.py:168-176) are moved by one
+    fp32 ulp each (sign from a seeded generator).  Nothing else changes: what the reference's outputs then differ by is the
+    reference's own response to the smallest representable change in front of its cumsum / diff pooling."""
+
+    def __init__(self, ref_model, seed=1):
+        self.te, self.seed = ref_model.diffusion_conditioning.token_embedder, seed
+
+    def __enter__(self):
+        orig = self.orig = self.te.downscale
+
+        def moved(b, a):
+            g = torch.Generator().manual_seed(self.seed)
+            up = torch.randint(0, 2, a.shape, generator=g).bool()
+            big = torch.full_like(a, 3e38)
+            return orig(b, torch.where(up, torch.nextafter(a, big), torch.nextafter(a, -big)))
+        self.te.downscale = moved
+        return self
+
+    def __exit__(self, *e):
+        del self.te.downscale            # the instance attribute; the class method is back
+
+
+def main_g14(RefPhysDock, RefConfig):
+    """G14 (round 6): the conditioning trunk pinned to the reference TENSOR BY TENSOR at the benchmark shapes, and the one place
+    where two fp32 executions of it part: the token pooling.  Per shape (cfg1, cfg2; medium model, seeded weights):
+      * s_pool [T, c_s]: the output of `TokenEmbedder.downscale` (diffusion_conditioning.py:168-176), and prefix_exp_end [T, c_s]
+        (int8): the binary exponents of the prefix sums the reference differences - torch's CPU cumsum accumulates in double and
+        rounds every prefix to fp32, so a token's pooled value (end prefix - start prefix) / (n + 1e-3) carries
+        (ulp(C_end) + ulp(C_start)) / 2 / n of rounding, C the prefixes over ALL atoms in front (|C| reaches 1800 at cfg1 and
+        3500 at cfg2 where the pooled sums are ~4): tests/conftest.py pool_rounding_bound turns the exponents into that bound;
+      * running tensors after every block (z sub-sampled [::32, ::32, ::4], s [::16, ::4], m [::16, ::16, ::8]) and the outputs
+        (a [::8], ap [::64, ::64], s [::2], z [::16, ::16]);
+      * how far the reference's OWN outputs move when the atoms entering the pooling move by one ulp (OneUlpDownscale)."""
+    import time
+    from physdock_amd.configs import PhysDockConfig
+    from physdock_amd.params import param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import cfg1_batch, cfg2_batch
+    ref_model = RefPhysDock(RefConfig(model_name="medium"))
+    ref_model.load_state_dict(seeded_state_dict(param_shapes(PhysDockConfig(model_name="medium")), seed=0), strict=True)
+    ref_model.eval()
+    dc = ref_model.diffusion_conditioning
+    te = dc.token_embedder
+    only = os.environ.get("PD_G14_ONLY")
+
+    def rel_rms(u, v):
+        return float(((u.double() - v.double()).pow(2).mean() / v.double().pow(2).mean()).sqrt())
+
+    for tag, batch in (("cfg1", cfg1_batch(0)), ("cfg2", cfg2_batch(0))):
+        if only and tag not in only.split(","):
+            continue
+        out, box, hooks = {}, {}, []
+
+        def block_hook(name, kinds):
+            def f(mod, inp, res):
+                for kind, t in zip(kinds, res if isinstance(res, tuple) else (res,)):
+                    t = t.detach()
+                    sub = t[::32, ::32, ::4] if kind == "z" else (t[::16, ::4] if kind == "s" else t[::16, ::16, ::8])
+                    out[f"{name}.{kind}"] = sub.clone()
+            return f
+        for i, b in enumerate(te.evoformer.blocks):
+            hooks.append(b.register_forward_hook(block_hook(f"evoformer.{i}", "mz")))
+        for i, b in enumerate(te.pairformer.blocks):
+            hooks.append(b.register_forward_hook(block_hook(f"pairformer.{i}", "sz")))
+        hooks.append(te.template_pair_embedder.register_forward_hook(block_hook("template", "z")))
+        hooks.append(dc.atom_embedder.register_forward_hook(
+            lambda mod, inp, res: out.update({"atom_embedder.a": res[0].detach()[::4].clone(),
+                                              "atom_embedder.ap": res[1].detach()[::64, ::64].clone()})))
+        # (atom_embedder.a is sub-sampled [::4] - the un-pooled atom activations in front of the pooling)
+        orig = te.downscale
+
+        def capture(b, a):
+            box["a_in"] = a.detach().clone()
+            box["s_pool"] = orig(b, a)
+            return box["s_pool"]
+        te.downscale = capture
+        t0 = time.time()
+        with torch.no_grad():
+            a, ap, s, z = dc(batch)
+        del te.downscale
+        for h in hooks:
+            h.remove()
+        print(f"  reference trunk medium/{tag}: {time.time() - t0:.0f} s")
+        with torch.no_grad():
+            # the reference's own prefixes, in double as torch's CPU cumsum accumulates them (ReduceOps: acc_type<float, false>)
+            u = torch.nn.functional.silu(te.linear_a(box["a_in"]))
+            C = torch.cumsum(u.double(), 0)
+            assert torch.equal(C.float(), torch.cumsum(u, 0)), "torch's CPU cumsum is not round(double prefix)"
+            chunk = batch["token_id_to_chunk_sizes"]
+            end = torch.cumsum(chunk, 0) - 1
+            Ce = C[end]
+            Cs = torch.cat([torch.zeros_like(Ce[:1]), Ce[:-1]])
+
+            # exponent of every end prefix as the fp32 value the reference gathers (int8): ulp(C) = 2^(e - 24) for 2^(e-1) <= |C| < 2^e
+            exp_end = torch.frexp(Ce.float().abs())[1].clamp(-126, 127).to(torch.int8)
+            sys.path.insert(0, os.path.join(REPO, "tests"))
+            from conftest import pool_rounding_bound
+            tol = pool_rounding_bound(exp_end, chunk, box["s_pool"])
+            exact = ((Ce - Cs) / (chunk[:, None].double() + 1e-3)).float()
+            worst = float(((box["s_pool"] - exact).abs() / tol).max())
+            print(f"  {tag}: max |prefix| {float(C.abs().max()):.0f}, rms s_pool {float(box['s_pool'].pow(2).mean().sqrt()):.3f}, "
+                  f"reference s_pool vs the exact segment mean of its own inputs: rms {rel_rms(box['s_pool'], exact):.2e}, "
+                  f"max |d| / bound {worst:.2f}")
+            assert worst <= 1.0, "the rounding bound does not cover the reference's own arithmetic"
+            with OneUlpDownscale(ref_model):
+                a1, ap1, s1, z1 = dc(batch)
+        twin = {"one_ulp_a": rel_rms(a1, a), "one_ulp_ap": rel_rms(ap1, ap), "one_ulp_s": rel_rms(s1, s), "one_ulp_z": rel_rms(z1, z)}
+        print("  reference vs reference, one ulp in front of the pooling: " + "  ".join(f"{k[8:]} {v:.2e}" for k, v in twin.items()))
+        npz(f"g14_trunk_{tag}", s_pool=box["s_pool"], prefix_exp_end=exp_end, a=a[::8], ap=ap[::64, ::64], s=s[::2], z=z[::16, ::16],
+            names=sorted(out), **out, **twin)
 
 
 def main_g10():
