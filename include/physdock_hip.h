@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 8
+#define PD_ABI_VERSION 9
 
 enum { PD_OUT_ROWMAJOR = 0, PD_OUT_TRANSPOSED = 1, PD_OUT_OPM = 2, PD_OUT_BIASFRAG = 3 };
 
@@ -186,6 +186,28 @@ typedef struct pd_tri_tail_args {
                                     (row-major, Co = C, |o| <= *on_amax = the v bound), a RAW gate, w_out unused              */
 } pd_tri_tail_args;
 int pd_tri_tail(const pd_tri_tail_args* args, void* stream);
+
+/* ---- pd_tri_attention (ABI 9): TriangleAttention up to the attention output with the q | k | v projection INSIDE the attention
+ * block (reference primitives/attentions.py:194-211; csrc/tri_attn.hip).  Replaces, per instance, pd_gemm (RMSNorm prologue, q | k | v)
+ * + pd_attention:  o[b, r, 32 h + d] = sum_k softmax_k( q[b,r,h,:] . k[b,k,h,:] / sqrt(32) + bias[h, r, k] ) v[b,k,h,d]  with
+ * q | k | v = (z[b, r, :] / rms(z[b, r, :])) . Wf^T, Wf = the [3 C][C] projection with the norm gain folded in (Wf[n][c] = W[n][c] w[c]).
+ * z, o: [T][T][C] pair tensors; transpose == 0: batch b = first index, sequence r = second; 1: the other way round (the column
+ * variant - nothing is transposed in memory).  stats [T*T][2] = (mean, rstd) per pair row as pd_pair_bias' stats_out writes them;
+ * W2 / w_inv = packing.split2_f16 of Wf (two fp16 parts, fragment-major, + inverse row scales); bias: fragment layout for
+ * (nq = T, nk = bias_nk) ALREADY multiplied by bias_prescale = the power of two pd_attention_bias_prescale_log2 derives from
+ * qkv_amax[0..1]; qkv_amax: device floats [3] bounding |q|, |k|, |v|; zn_amax: host float bounding |z / rms| (sqrt(C));
+ * Treal: real key count (keys >= Treal are masked).  C = 128, nheads = 4, T <= 256, T % 4 == 0; else PD_ERR_UNSUPPORTED.        */
+typedef struct pd_tri_attn_args {
+    const float* z; const float* stats;
+    const void* W2; const float* w_inv;
+    const float* bias; float bias_prescale; int bias_nk;
+    float* o;
+    int T, Treal, C, nheads, transpose;
+    float zn_amax; const float* qkv_amax;
+    float scale;                 /* 1 / sqrt(32) */
+} pd_tri_attn_args;
+int pd_tri_attention(const pd_tri_attn_args* args, void* stream);
+int pd_tri_attn_args_size(void);
 
 /* ---- pd_tri_mul (ABI 7): the triangle-multiplication einsum (attentions.py:164) on the two-part fp16 format ----------------------
  * transpose == 0:  o[c,i,I] = sum_{j < Treal} q[c,i,j] k[c,I,j];   transpose == 1:  o[c,a,b] = sum_{j < Treal} k[c,j,a] q[c,j,b]

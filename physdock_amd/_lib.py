@@ -94,6 +94,13 @@ class TriTailArgs(C.Structure):
                 ("zn_amax", _fp), ("on_amax", _fp), ("mode", C.c_int)]
 
 
+class TriAttnArgs(C.Structure):
+    """mirror of pd_tri_attn_args"""
+    _fields_ = [("z", _fp), ("stats", _fp), ("W2", _fp), ("w_inv", _fp), ("bias", _fp), ("bias_prescale", C.c_float), ("bias_nk", C.c_int),
+                ("o", _fp), ("T", C.c_int), ("Treal", C.c_int), ("C", C.c_int), ("nheads", C.c_int), ("transpose", C.c_int),
+                ("zn_amax", C.c_float), ("qkv_amax", _fp), ("scale", C.c_float)]
+
+
 class TriMulArgs(C.Structure):
     """mirror of pd_tri_mul_args"""
     _fields_ = [("q", _fp), ("k", _fp), ("o", _fp), ("T", C.c_int), ("Treal", C.c_int), ("nch", C.c_int), ("ch_stride", C.c_longlong),
@@ -122,6 +129,8 @@ def lib():
                                "(python -m physdock_amd.build --force)")
         if _lib.pd_gemm_args_size() != C.sizeof(GemmArgs) or _lib.pd_attn_args_size() != C.sizeof(AttnArgs):
             raise RuntimeError("ctypes mirrors of pd_gemm_args / pd_attn_args differ in size from the compiled structs")
+        if _lib.pd_tri_attn_args_size() != C.sizeof(TriAttnArgs):
+            raise RuntimeError("ctypes mirror of pd_tri_attn_args differs in size from the compiled struct")
     return _lib
 
 
@@ -190,6 +199,8 @@ def _declare(L):
     sig("pd_norm_split2", p, i, i, i, i, f, p, p, i, i, p, p, p)
     sig("pd_transition_f16", C.POINTER(TransitionArgs), p)
     sig("pd_tri_tail", C.POINTER(TriTailArgs), p)
+    sig("pd_tri_attention", C.POINTER(TriAttnArgs), p)
+    sig("pd_tri_attn_args_size")
     sig("pd_tri_mul", C.POINTER(TriMulArgs), p)
     sig("pd_mmff_energy_grad", p, p, p, p, i, p)
     sig("pd_mmff_relax", p, p, p, p, p, ll, i, i, i, p)

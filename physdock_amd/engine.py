@@ -290,14 +290,20 @@ class Engine:
         else:
             W, b = P.qkvg(prefix)
             qkvg = self.ws.get("qkvg", M, 4 * C)
-        self.gemm(z, W, qkvg, M, nq * C, C, stats=st, pro_w=nw, bias=b)
-        if not transpose:
-            st4, sto = (T * nq * C, nq * C), (T * C, C)
-        else:
-            st4, sto = (nq * C, T * nq * C), (C, T * C)
-        ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
-                      q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T,
-                      f16_amax=bnd, bias_prescale=ps)
+        # round 6: the q | k | v projection INSIDE the attention block (csrc/tri_attn.hip): q | k | v never exist in HBM.  Needs the fused
+        # tail (the gate is projected there), the pre-scaled bias of the fp16-format kernels and T <= 256; the projections carry no bias
+        in_block = (fused and ops.FUSED_TRI_ATTN and ps > 0.0 and T <= 256
+                    and ops.tri_attention(z, st, P.qkv_folded_w2(prefix, nw), bias, o, T, self.Tr, C, H, transpose=transpose,
+                                          bias_prescale=ps, bias_nk=T, qkv_amax=bnd, zn_amax=math.sqrt(C) * 1.0001))
+        if not in_block:
+            self.gemm(z, W, qkvg, M, nq * C, C, stats=st, pro_w=nw, bias=b)
+            if not transpose:
+                st4, sto = (T * nq * C, nq * C), (T * C, C)
+            else:
+                st4, sto = (nq * C, T * nq * C), (C, T * C)
+            ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
+                          q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T,
+                          f16_amax=bnd, bias_prescale=ps)
         if fused and ops.tri_tail(z, o, M, C, C, w_in=nw, w_out=None, eps=self.eps, Wg=P.w2(Wg, C), bg=bg, Wz=P.w2(Wo, C), bz=bo,
                                   zn_amax=P.norm_bound(nw, None, C), on_amax=self.o_bound(bnd), mode=1):
             return

@@ -532,6 +532,7 @@ class PhysDock(nn.Module):
             else:
                 # the second call of the same schedule on the same shape: the whole N-step loop as ONE graph from here on
                 entry["exec"] = capture(segments)
+                entry["terms"] = relaxer.terms if relaxer.kind == "device" else None      # the tables THIS capture recorded
                 self.whole_captures += 1
             while len(self._graphs) > self.max_cached_graphs:
                 old = self._graphs.pop(next(iter(self._graphs)))

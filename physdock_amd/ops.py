@@ -364,6 +364,25 @@ def tri_tail(z, o, M, Cdim, Co, *, w_in, w_out, eps, Wg, bg, Wz, bz, zn_amax, on
     return rc != -3
 
 
+#: TriangleAttention with the q | k | v projection inside the attention block (csrc/tri_attn.hip, round 6); False: projection GEMM + pd_attention
+FUSED_TRI_ATTN = os.environ.get("PD_FUSED_TRI_ATTN", "1") != "0"
+
+
+def tri_attention(z, stats, W2, bias, o, T, Treal, Cdim, nheads, *, transpose, bias_prescale, bias_nk, qkv_amax, zn_amax):
+    """TriangleAttention up to the attention output in one launch (pd_tri_attention): RMSNorm(z) (statistics given) -> q | k | v
+    projection -> biased attention.  W2: (parts, w_inv) of packing.split2_f16 of the [3 C][C] projection with the norm gain folded in.
+    Returns False when the library does not cover the shape."""
+    a = _lib.TriAttnArgs()
+    a.z, a.stats, a.W2, a.w_inv = ptr(z), ptr(stats), W2[0].data_ptr(), W2[1].data_ptr()
+    a.bias, a.bias_prescale, a.bias_nk, a.o = ptr(bias), float(bias_prescale), int(bias_nk), ptr(o)
+    a.T, a.Treal, a.C, a.nheads, a.transpose = T, Treal, Cdim, nheads, int(bool(transpose))
+    a.zn_amax, a.qkv_amax, a.scale = float(zn_amax), (qkv_amax if isinstance(qkv_amax, int) else ptr(qkv_amax)), 1.0 / math.sqrt(32.0)
+    rc = _lib.init().pd_tri_attention(C.byref(a), stream())
+    if rc != -3:
+        check(rc, "pd_tri_attention")
+    return rc != -3
+
+
 def tri_mul(q, k, o, T, Treal, nch, ch_stride, *, transpose, q_amax, k_amax):
     """triangle-multiplication einsum on the two-part fp16 format (pd_tri_mul); q / k / o: tensors or raw device addresses.
     Returns False when the library does not cover the shape."""

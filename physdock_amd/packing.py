@@ -61,14 +61,19 @@ def split3_bf16(W):
     return v.contiguous()
 
 
-def split2_f16(W):
+def split2_f16(W, rows_per_scale=1):
     """The B operand of csrc/gemm_f16.hip: W [N,K] times a per-row power of two (max_k |W[n,k]| w_scale[n] in [2^14, 2^15)),
     split into two fp16 parts (hi = fp16(w'), lo = fp16(w' - hi): 22 significand bits), stored FRAGMENT-MAJOR like split3_bf16:
-    [2][ceil(N/32)][Kp/16][64][8].  Returns (parts, w_inv [N] fp32 = 1 / w_scale).  Rows of zeros get scale 1."""
+    [2][ceil(N/32)][Kp/16][64][8].  Returns (parts, w_inv [N] fp32 = 1 / w_scale).  Rows of zeros get scale 1.
+    rows_per_scale = 32: ONE scale per 32-row fragment tile (its largest row decides) - for kernels that undo the scale with a scalar
+    per tile (csrc/tri_attn.hip); w_inv then repeats the tile's value for its rows."""
     W = W.float()
     N, K = W.shape
     Kp = (K + 31) // 32 * 32
     amax = W.abs().amax(1)
+    if rows_per_scale > 1:
+        assert N % rows_per_scale == 0
+        amax = amax.reshape(-1, rows_per_scale).amax(1, keepdim=True).expand(-1, rows_per_scale).reshape(-1)
     # w_scale = 2^(14 - floor(log2(amax))): frexp gives amax = m 2^e with m in [0.5, 1) -> floor(log2) = e - 1
     e = torch.frexp(amax)[1]
     w_scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), 15 - e), torch.ones_like(amax))
@@ -199,6 +204,16 @@ class PackedWeights:
         W, b = self.qkvg(prefix)
         C3 = 3 * (W.shape[0] // 4)
         return W[:C3], b[:C3], self.p[prefix + ".linear_g.weight"], self.p[prefix + ".linear_g.bias"]
+
+    def qkv_folded_w2(self, prefix, norm_weight):
+        """two-part fp16 split (parts, w_inv) of the q | k | v projection [3 C][C] with the RMSNorm gain folded into its columns
+        (Wf[n][c] = W[n][c] w[c]), ONE power-of-two scale per (projection, head) tile of 32 rows: the operand of pd_tri_attention, which
+        reads z / rms(z) without the gain and undoes the weight scale with a scalar per tile"""
+        def mk():
+            Wf = (self.qkv(prefix) * norm_weight[None, :]).contiguous()
+            return (Wf,) + split2_f16(Wf, rows_per_scale=32)
+        v = self._c(("qkv_folded_w2", prefix, norm_weight.data_ptr()), mk)
+        return v[1], v[2]
 
     def attn_static_bounds_host(self, prefix, norm_weight):
         """[|q|, |k|, |v|] rigorous upper bounds of a trunk attention whose projections (no bias) read an RMS- / LayerNorm-ed row
