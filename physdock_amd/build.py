@@ -85,6 +85,8 @@ def compile_cmd(src, out, mode=("-c",)):
         cmd[1:1] = ["-DPD_PIPE_NW4_MAXNK=" + os.environ["PD_PIPE_NW4_MAXNK"]]
     if os.environ.get("PD_PIPE_XCD") and base == "attn_pipe.hip":      # lab: XCD-aware block order
         cmd[1:1] = ["-DPD_PIPE_XCD=" + os.environ["PD_PIPE_XCD"]]
+    if os.environ.get("PD_TRI_ABL") and base == "tri_attn.hip":        # lab: timing ablations of the fused triangle attention (wrong results)
+        cmd[1:1] = ["-DPD_TRI_ABL=" + os.environ["PD_TRI_ABL"]]
     if os.environ.get("PD_PIPE_ABL") and base == "attn_pipe.hip":      # lab: timing ablations of the pipelined attention (wrong results)
         cmd[1:1] = ["-DPD_PIPE_ABL=" + os.environ["PD_PIPE_ABL"]]
     if os.environ.get("PD_TR_SILU") and base == "transition_f16.hip":     # lab: form of the SiLU in the fused transition (0 division, 1 / 2 reciprocal)

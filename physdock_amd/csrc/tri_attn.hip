@@ -38,7 +38,25 @@ constexpr float PSH = 14.0f - (float)LAZY;
 
 #define PD_SB() __builtin_amdgcn_sched_barrier(0)
 
+// lab ablations (timing only, wrong results; tools/abl_tri_attn.sh): 1 no attention phase, 2 weight fragments not loaded, 4 no
+// projection MFMAs, 8 no bias fetches, 16 rows of z not loaded
+#ifdef PD_TRI_ABL
+constexpr int ABL = PD_TRI_ABL;
+#else
+constexpr int ABL = 0;
+#endif
+
 __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// MFMA of the projection (ablation 4 removes it)
+__device__ __forceinline__ f32x16 jmma(frag a, frag b, f32x16 c) {
+#ifdef PD_TRI_ABL
+    if (PD_TRI_ABL & 4) {
+        c[0] += __builtin_bit_cast(f32x4, a)[0] * 0.f + __builtin_bit_cast(f32x4, b)[0] * 0.f;
+        return c;
+    }
+#endif
+    return mma(a, b, c);
+}
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 __device__ __forceinline__ void lds_barrier() {
@@ -82,6 +100,7 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         const int zoff = (int)((long long)row * ss * 4) + 32 * hh;      // rows >= T: beyond the range, read as zero
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
+            if constexpr (ABL & 16) { raw[s][0] = f32x4{1.f, -2.f, 0.5f, 3.f}; raw[s][1] = f32x4{-1.f, 2.f, 0.25f, 1.f}; continue; }
             raw[s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, zoff, 64 * s, 0));
             raw[s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, zoff, 64 * s + 16, 0));
         }
@@ -111,7 +130,10 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
 
     // ---- 2. projection: weight fragments [2 parts][12 tiles][8 k-steps][64 lanes][8] (packing.split2_f16 of the [3 C][C] matrix)
     const frag* wbase = reinterpret_cast<const frag*>(p.W2) + lane;
-    auto wfrag = [&](int tile, int s, int part) { return wbase[((part * 12 + tile) * NKS + s) * 64]; };
+    auto wfrag = [&](int tile, int s, int part) {
+        if constexpr (ABL & 2) return __builtin_bit_cast(frag, u32x4{0x3c003c00u + tile, 0x3c003c00u + s, 0x3c003c00u + part, 0x3c003c00u});
+        return wbase[((part * 12 + tile) * NKS + s) * 64];
+    };
     // one 32-row output tile of the projection: 24 MFMAs, the weight fragments of k-step s + 1 requested in front of the MFMAs of
     // k-step s and no further ahead (sched_barrier: the row fragments already hold 64 registers).  transposed: rows of the
     // accumulator = output channels (A = weights, B = rows of z); else rows = rows of z
@@ -127,13 +149,13 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
             if (s + 1 < NKS) { nh = wfrag(wtile, s + 1, 0); nl = wfrag(wtile, s + 1, 1); nz = *reinterpret_cast<const frag*>(zl + (s + 1) * 512); }
             PD_SB();
             if (transposed) {
-                acc = mma(wh, zlo, acc);
-                acc = mma(wl, zh[s], acc);
-                acc = mma(wh, zh[s], acc);
+                acc = jmma(wh, zlo, acc);
+                acc = jmma(wl, zh[s], acc);
+                acc = jmma(wh, zh[s], acc);
             } else {
-                acc = mma(zlo, wh, acc);
-                acc = mma(zh[s], wl, acc);
-                acc = mma(zh[s], wh, acc);
+                acc = jmma(zlo, wh, acc);
+                acc = jmma(zh[s], wl, acc);
+                acc = jmma(zh[s], wh, acc);
             }
             PD_SB();
             wh = nh; wl = nl; zlo = nz;
@@ -217,6 +239,11 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
     const auto rs_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias_base), 0, nkt32 * 4096, 0x00020000);
     const int boff = lane * 16;
     auto load_bias = [&](f32x16& s, int kt32) {
+        if constexpr (ABL & 8) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, boff, kt32 * 4096 + g * 1024, 0));
@@ -377,7 +404,7 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         l_run = l_run * alpha + ps;
     };
 
-    if (wave_active) {
+    if (wave_active && !(ABL & 1)) {
         float mloc;
         frag kf0[2];
         scores(sA, kbase(0));

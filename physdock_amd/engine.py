@@ -281,21 +281,23 @@ class Engine:
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
         # With the fused tail (pd_tri_tail mode 1: gate projection + linear_o + gate + residual in one launch) the projection in
         # front is q|k|v only and the gate tensor never exists
-        fused = bnd is not None and ops.FUSED_TRI_ATTN_TAIL and ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM and C == 128 and ldw == C
-        nq = 3 if fused else 4
+        f16 = bnd is not None and ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM and C == 128 and ldw == C
+        fused = f16 and ops.FUSED_TRI_ATTN_TAIL
         o = self.ws.get("attn_o", M, C)
-        if fused:
-            W, b, Wg, bg = P.qkv_g(prefix)
-            qkvg = self.ws.get("qkv3", M, 3 * C)
-        else:
-            W, b = P.qkvg(prefix)
-            qkvg = self.ws.get("qkvg", M, 4 * C)
-        # round 6: the q | k | v projection INSIDE the attention block (csrc/tri_attn.hip): q | k | v never exist in HBM.  Needs the fused
-        # tail (the gate is projected there), the pre-scaled bias of the fp16-format kernels and T <= 256; the projections carry no bias
-        in_block = (fused and ops.FUSED_TRI_ATTN and ps > 0.0 and T <= 256
+        # round 6: the q | k | v projection INSIDE the attention block (csrc/tri_attn.hip): q | k | v never exist in HBM.  Needs the
+        # pre-scaled bias of the fp16-format kernels and T <= 256; the gate is then projected by the fused tail or on its own
+        in_block = (f16 and ops.FUSED_TRI_ATTN and ps > 0.0 and T <= 256
                     and ops.tri_attention(z, st, P.qkv_folded_w2(prefix, nw), bias, o, T, self.Tr, C, H, transpose=transpose,
                                           bias_prescale=ps, bias_nk=T, qkv_amax=bnd, zn_amax=math.sqrt(C) * 1.0001))
+        nq = 3 if fused else 4
+        qkvg = None
         if not in_block:
+            if fused:
+                W, b, _, _ = P.qkv_g(prefix)
+                qkvg = self.ws.get("qkv3", M, 3 * C)
+            else:
+                W, b = P.qkvg(prefix)
+                qkvg = self.ws.get("qkvg", M, 4 * C)
             self.gemm(z, W, qkvg, M, nq * C, C, stats=st, pro_w=nw, bias=b)
             if not transpose:
                 st4, sto = (T * nq * C, nq * C), (T * C, C)
@@ -304,10 +306,11 @@ class Engine:
             ops.attention(off(qkvg, 0), off(qkvg, C), off(qkvg, 2 * C), o, nq=T, nk=self.Tr, nbatch=T, nheads=H,
                           q_strides=st4, k_strides=st4, v_strides=st4, o_strides=sto, bias=bias, bias_nk=T,
                           f16_amax=bnd, bias_prescale=ps)
+        Wg, bg = P[prefix + ".linear_g.weight"], P[prefix + ".linear_g.bias"]
         if fused and ops.tri_tail(z, o, M, C, C, w_in=nw, w_out=None, eps=self.eps, Wg=P.w2(Wg, C), bg=bg, Wz=P.w2(Wo, C), bz=bo,
                                   zn_amax=P.norm_bound(nw, None, C), on_amax=self.o_bound(bnd), mode=1):
             return
-        if fused:         # (shape outside the kernel: the gate as its own projection, then the three-operand epilogue)
+        if fused or in_block:   # no gate tensor yet: the gate as its own projection, then the three-operand epilogue
             gt = self.ws.get("tri_g", M, C)
             self.gemm(z, Wg, gt, M, C, C, stats=st, pro_w=nw, bias=bg)
             self.gemm(o, Wo, z, M, C, C, ldw=ldw, bias=bo, mul=gt, ldmul=C, res=z, a_amax=self.o_bound(bnd))
