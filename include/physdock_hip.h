@@ -191,14 +191,15 @@ int pd_tri_tail(const pd_tri_tail_args* args, void* stream);
  * block (reference primitives/attentions.py:194-211; csrc/tri_attn.hip).  Replaces, per instance, pd_gemm (RMSNorm prologue, q | k | v)
  * + pd_attention:  o[b, r, 32 h + d] = sum_k softmax_k( q[b,r,h,:] . k[b,k,h,:] / sqrt(32) + bias[h, r, k] ) v[b,k,h,d]  with
  * q | k | v = (z[b, r, :] / rms(z[b, r, :])) . Wf^T, Wf = the [3 C][C] projection with the norm gain folded in (Wf[n][c] = W[n][c] w[c]).
- * z, o: [T][T][C] pair tensors; transpose == 0: batch b = first index, sequence r = second; 1: the other way round (the column
- * variant - nothing is transposed in memory).  stats [T*T][2] = (mean, rstd) per pair row as pd_pair_bias' stats_out writes them;
- * W2 / w_inv = packing.split2_f16 of Wf (two fp16 parts, fragment-major, + inverse row scales); bias: fragment layout for
+ * z2: the normalised rows, scaled, split into two fp16 parts and in fragment order, as pd_pair_bias_split writes them (same zn_amax,
+ * same transpose flag); o: [T][T][C] in the pair tensor's own layout - transpose == 0: batch b = first index, sequence r = second;
+ * 1: the other way round (the column variant - nothing is transposed in memory).  W2 / w_inv = packing.split2_f16(Wf, rows_per_scale =
+ * 32) (two fp16 parts, fragment-major, ONE power-of-two scale per 32-row tile; w_inv[n] = its inverse); bias: fragment layout for
  * (nq = T, nk = bias_nk) ALREADY multiplied by bias_prescale = the power of two pd_attention_bias_prescale_log2 derives from
  * qkv_amax[0..1]; qkv_amax: device floats [3] bounding |q|, |k|, |v|; zn_amax: host float bounding |z / rms| (sqrt(C));
  * Treal: real key count (keys >= Treal are masked).  C = 128, nheads = 4, T <= 256, T % 4 == 0; else PD_ERR_UNSUPPORTED.        */
 typedef struct pd_tri_attn_args {
-    const float* z; const float* stats;
+    const void* z2;
     const void* W2; const float* w_inv;
     const float* bias; float bias_prescale; int bias_nk;
     float* o;
@@ -231,6 +232,12 @@ int pd_tri_mul(const pd_tri_mul_args* args, void* stream);
 int pd_pair_bias(const float* x, const float* Wf, const float* c2, float* stats_out, const float* maskadd, float maskval,
                  float out_scale, float* frag, int T1, int T2, int C, int H, int frag_transpose, int mode, float eps,
                  void* stream);
+/* pd_pair_bias_split (ABI 9): pd_pair_bias for the TriangleAttention (x [T*T][128], H = 4, RMS) that ALSO writes x / rms(x) times the
+ * power-of-two operand scale of zn_amax (= sqrt(C) 1.0001), split into two fp16 parts, in pd_tri_attention's fragment order:
+ * z2 [T batches][ceil(T/32) row tiles][8 k-steps][2 parts][64 lanes][8] halves (batch / row = the pair indices, swapped when
+ * frag_transpose).  Rows beyond T of the last tile are not written: zero the buffer once.                                         */
+int pd_pair_bias_split(const float* x, const float* Wf, const float* c2, float* stats_out, const float* maskadd, float maskval,
+                       float out_scale, float* frag, int T, int frag_transpose, float eps, void* z2, float zn_amax, void* stream);
 
 /* ---- pd_attention: O = softmax(Q K^T * scale + bias) V, head width 32 ------------------
  * replaces F.scaled_dot_product_attention at attentions.py:48,92,130,211,259.

@@ -96,7 +96,7 @@ class TriTailArgs(C.Structure):
 
 class TriAttnArgs(C.Structure):
     """mirror of pd_tri_attn_args"""
-    _fields_ = [("z", _fp), ("stats", _fp), ("W2", _fp), ("w_inv", _fp), ("bias", _fp), ("bias_prescale", C.c_float), ("bias_nk", C.c_int),
+    _fields_ = [("z2", _fp), ("W2", _fp), ("w_inv", _fp), ("bias", _fp), ("bias_prescale", C.c_float), ("bias_nk", C.c_int),
                 ("o", _fp), ("T", C.c_int), ("Treal", C.c_int), ("C", C.c_int), ("nheads", C.c_int), ("transpose", C.c_int),
                 ("zn_amax", C.c_float), ("qkv_amax", _fp), ("scale", C.c_float)]
 
@@ -157,6 +157,7 @@ def _declare(L):
     sig("pd_rownorm", p, p, p, p, p, i, i, i, f, i, p)
     sig("pd_norm_split", p, i, i, i, i, f, p, p, i, i, p, p)
     sig("pd_pair_bias", p, p, p, p, p, f, f, p, i, i, i, i, i, i, f, p)
+    sig("pd_pair_bias_split", p, p, p, p, p, f, f, p, i, i, f, p, f, p)
     sig("pd_attention", C.POINTER(AttnArgs), p)
     sig("pd_attention_variant", C.POINTER(AttnArgs))
     sig("pd_attention_tail", C.POINTER(AttnArgs), C.POINTER(C.c_int))

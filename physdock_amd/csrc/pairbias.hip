@@ -10,6 +10,7 @@
 // the lanes of the row with DPP adds, and written straight into the attention kernel's bias fragment layout through a
 // per-wave LDS transpose (16-byte stores of four consecutive keys).  The (mean, rstd) pairs are stored as a by-product:
 // the q|k|v|g projection that follows consumes the same statistics.  HBM-bound: bytes = M C 4 read + M H 4 written.
+#include <string.h>
 #include "common.h"
 #include "physdock_hip.h"
 
@@ -38,12 +39,17 @@ __device__ __forceinline__ float group_sum(float v) {       // sum over the LPR 
 // C = 4 LPR channels, H heads; 4 waves per block, every wave walks TR-row tiles.  TR = 16 for C = 128: the per-row work is a
 // chain of dependent DPP reductions, so the kernel wants many short waves per SIMD (65 536 rows = 4 096 wave tiles), not 1 024
 // long ones (21 -> see NOTES); C = 16 rows are cheap and stay at 64.
-template <int LPR, int H, int TR>
+// Z2 (round 6, C = 128 / RMS only): the normalised rows x / rms(x), times the power-of-two operand scale z2_scale, are ALSO written in
+// the two-part fp16 format and in the FRAGMENT-MAJOR order pd_tri_attention reads them in (csrc/tri_attn.hip):
+//   z2[batch b][32-row tile][k-step s = 16 channels][part][lane' = (row & 31) + 32 hh][8 halves],  channels 16 s + 8 hh .. + 8,
+// batch / row = the two pair indices (swapped for the column variant).  The lane that holds channels 4 sub .. + 4 of a row owns 8 bytes
+// of one 16-byte fragment slot per part.
+template <int LPR, int H, int TR, bool Z2 = false>
 __global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict__ x, const float* __restrict__ Wf,
                                                        const float* __restrict__ c2, float* __restrict__ stats,
                                                        const float* __restrict__ maskadd, float maskval, float out_scale,
                                                        float* __restrict__ frag, long long M, int T1, int T2, int transpose,
-                                                       int mode, float eps) {
+                                                       int mode, float eps, unsigned short* __restrict__ z2 = nullptr, float z2_scale = 0.f) {
     constexpr int C = 4 * LPR, RPI = 64 / LPR, NI = TR / RPI;
     static_assert(TR % RPI == 0 && TR % 4 == 0 && TR <= 64, "tile rows");
     __shared__ float tile[4][TR][H + 1];
@@ -97,6 +103,20 @@ __global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict_
                     if (sub == h % LPR) tile[wave][r][h] = ((d * rstd + cb[h]) + madd) * out_scale;   // spread the LDS writes over lanes
                 }
                 if (ok && stats && sub == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+                if constexpr (Z2) {
+                    if (ok) {
+                        const int i0 = (int)(row / T2), i1 = (int)(row - (long long)i0 * T2);
+                        const int bz = transpose ? i1 : i0, rz = transpose ? i0 : i1;
+                        const float f = rstd * z2_scale;
+                        const pd_parts2 p0 = pd_split2h(v[0] * f, v[1] * f), p1 = pd_split2h(v[2] * f, v[3] * f);
+                        const int ntile = (T2 + 31) >> 5;
+                        // ((((b NT + tile) 8 + s) 2 + part) 64 + lane') 8 + 4 e   halves;  s = sub >> 2, hh = (sub >> 1) & 1, e = sub & 1
+                        const long long o = (((((long long)bz * ntile + (rz >> 5)) * 8 + (sub >> 2)) * 2) * 64 + (rz & 31) + 32 * ((sub >> 1) & 1)) * 8 + 4 * (sub & 1);
+                        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2_*>(z2 + o) = u32x2_{p0.h, p1.h};
+                        *reinterpret_cast<u32x2_*>(z2 + o + 512) = u32x2_{p0.l, p1.l};
+                    }
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);          // this wave's LDS writes have landed (the tile is private to the wave)
@@ -133,12 +153,20 @@ __global__ __launch_bounds__(256) void pair_bias_kernel(const float* __restrict_
 
 template <int LPR, int H, int TR>
 int launch(const float* x, const float* Wf, const float* c2, float* stats, const float* maskadd, float maskval, float out_scale,
-           float* frag, long long M, int T1, int T2, int transpose, int mode, float eps, hipStream_t s) {
+           float* frag, long long M, int T1, int T2, int transpose, int mode, float eps, hipStream_t s, unsigned short* z2 = nullptr,
+           float z2_scale = 0.f) {
     const long long ntile = (M + TR - 1) / TR;
     long long blocks = (ntile + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
+    if constexpr (LPR == 32 && H == 4) {
+        if (z2) {
+            hipLaunchKernelGGL((pair_bias_kernel<LPR, H, TR, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, Wf, c2, stats, maskadd, maskval,
+                               out_scale, frag, M, T1, T2, transpose, mode, eps, z2, z2_scale);
+            return pd_check_launch();
+        }
+    }
     hipLaunchKernelGGL((pair_bias_kernel<LPR, H, TR>), dim3((unsigned)blocks), dim3(256), 0, s, x, Wf, c2, stats, maskadd, maskval,
-                       out_scale, frag, M, T1, T2, transpose, mode, eps);
+                       out_scale, frag, M, T1, T2, transpose, mode, eps, nullptr, 0.f);
     return pd_check_launch();
 }
 
@@ -158,4 +186,29 @@ PD_EXPORT int pd_pair_bias(const float* x, const float* Wf, const float* c2, flo
     PD_PB(32, 4) PD_PB(32, 8) PD_PB(32, 16) PD_PB(4, 4) PD_PB(4, 24)
 #undef PD_PB
     return PD_ERR_UNSUPPORTED;
+}
+
+// pd_pair_bias for the TriangleAttention (C = 128, H = 4, RMS, T1 == T2) that ALSO writes the normalised rows x / rms(x), scaled and split
+// into the two-part fp16 format, in pd_tri_attention's fragment-major order (see pair_bias_kernel): z2 [T][ceil(T/32)][8][2][64][8]
+// halves; rows beyond T of the last tile are never written (the caller zeroes the buffer once).  zn_amax: the bound of |x / rms(x)|
+// (sqrt(C)) the operand scale derives from - the same float pd_tri_attention is given.
+PD_EXPORT int pd_pair_bias_split(const float* x, const float* Wf, const float* c2, float* stats_out, const float* maskadd,
+                                 float maskval, float out_scale, float* frag, int T, int frag_transpose, float eps, void* z2,
+                                 float zn_amax, void* stream) {
+    if (!x || !Wf || !frag || !z2 || T <= 0 || !(zn_amax > 0.f)) return PD_ERR_ARG;
+    if (T % 4 != 0) return PD_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)Wf | (uintptr_t)frag | (uintptr_t)z2) & 15) return PD_ERR_UNSUPPORTED;
+    if (out_scale == 0.f) out_scale = 1.f;
+    int e;                                                   // pd_pow2_scale on the host (csrc/common.h): 2^(14 - floor(log2 amax))
+    {
+        unsigned u;
+        memcpy(&u, &zn_amax, 4);
+        e = (int)((u >> 23) & 0xff);
+        e = e < 87 ? 87 : (e > 200 ? 200 : e);
+    }
+    const unsigned sb = (unsigned)(268 - e) << 23;
+    float z2_scale;
+    memcpy(&z2_scale, &sb, 4);
+    return launch<32, 4, PD_PB_TR>(x, Wf, c2, stats_out, maskadd, maskval, out_scale, frag, (long long)T * T, T, T, frag_transpose, 0, eps,
+                                   (hipStream_t)stream, reinterpret_cast<unsigned short*>(z2), z2_scale);
 }

@@ -1,17 +1,16 @@
 // Triangle attention with the q | k | v projection INSIDE the attention block (round 6; reference primitives/attentions.py:194-217).
 //
-// The chain  RMSNorm(z) -> q | k | v projection (pd_gemm: 44 us, 168 MB written and read back) -> attention (attn_pipe_kernel: 43 us, a
-// four-tile launch that is mostly prologue: MfmaUtil 0.23)  becomes one launch.  A block owns one (pair row i, head h): 256 query rows
+// The chain  RMSNorm(z) -> q | k | v projection (pd_gemm: 44 us, 168 MB written and read back) -> attention (attn_pipe_kernel: 35 - 43 us,
+// a four-tile launch that is mostly prologue: MfmaUtil 0.23)  becomes one launch.  A block owns one (pair row i, head h): 256 query rows
 // = the 256 key rows of that row of z.  Every wave
-//   1. reads ITS 32 rows of z[i] (128 channels), scales them by the row's 1 / rms (statistics from pd_pair_bias' pass over z; the
-//      norm gain is folded into the weights at pack time) and splits them into the two-part fp16 format IN REGISTERS - the rows are the
-//      B / A operand fragments of the projection as they are (lane = row, eight channels per k-step);
+//   1. reads ITS 32 rows of z[i] / rms(z[i]) as two-part fp16 FRAGMENTS: pd_pair_bias_split - the streaming pass over z that produces the
+//      bias tiles and knows the row statistics - writes them scaled, split and in fragment order (lane = row, eight channels per
+//      k-step), so a request is one coalesced kilobyte per wave and needs no conversion; the norm gain is folded into the weights;
 //   2. contracts them with the head's 96 weight rows (q, k, v: 32 each; fragment-major two-part fp16, packing.split2_f16, straight from
-//      L2): 72 MFMAs of uninterrupted matrix work, three accumulator tiles;
+//      L2): 72 MFMAs, three accumulator tiles;
 //   3. turns the q tile into its own Q fragments (v_permlane32_swap: no LDS round trip), writes its 32 keys' K rows and V^T columns
 //      into the block's LDS tiles (the layouts of attn_pipe.hip);
-// and two block barriers later (the row fragments' low parts borrow the tile space during the projection) all 256 keys of the (row,
-// head) are resident: the software-pipelined wave program of attn_pipe.hip (score
+// and after ONE block barrier all 256 keys of the (row, head) are resident: the software-pipelined wave program of attn_pipe.hip (score
 // MFMAs of sub-tile j + 1 under the softmax of sub-tile j, bias tile as the accumulator's initial value, lazy running maximum) runs
 // over them without staging, without global K / V requests and without another barrier.
 // q | k | v never exist in HBM.  T <= 256 (four 64-key tiles, 78 KB of LDS: two blocks per CU); C = 128.
@@ -32,7 +31,16 @@ constexpr int KT = 64, KP = 40, VP = 72;        // attn_pipe.hip's tile layouts
 constexpr int K_PART = KT * KP, V_PART = 32 * VP;
 constexpr int STAGE = 2 * (K_PART + V_PART);
 constexpr int NTILE = 4;                        // 256 keys
-constexpr int LDS_BYTES = NTILE * STAGE * 2;
+// PD_TRI_WLDS = 1 (lab, measured and NOT shipped): the head's 96 weight rows (48 KB) staged once per block in LDS behind the K / V tiles and
+// both parts of the wave's rows of z in registers: 126 KB of LDS and up to 256 registers = ONE block (eight waves) per CU.  It removes
+// 0.8 MB of per-wave weight requests per pair of blocks from the CU's vector-memory path, and is slower: 73 - 75 us against 65 - 67 us -
+// with two waves per SIMD the attention phase alone takes 45 us instead of 32 (profiles/r06_tri_attn_forms.txt).
+#ifndef PD_TRI_WLDS
+#define PD_TRI_WLDS 0
+#endif
+constexpr bool WLDS = PD_TRI_WLDS != 0;
+constexpr int W_HALVES = 3 * 2 * NKS * 64 * 8;              // q, k, v tiles x 2 parts x 8 k-steps x 64 lanes x 8 halves = 48 KB
+constexpr int LDS_BYTES = NTILE * STAGE * 2 + (WLDS ? W_HALVES * 2 : 0);
 constexpr int LAZY = 3;
 constexpr float PSH = 14.0f - (float)LAZY;
 
@@ -66,7 +74,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args p) {
+__global__ __launch_bounds__(512, WLDS ? 2 : 4) void tri_attn_kernel(const pd_tri_attn_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,46 +99,45 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
     const float a_s = pd_pow2_scale(p.zn_amax);
     const float inv_as = 1.0f / a_s;
 
-    // ---- 1. the wave's rows of z[i]: every request first
-    f32x4 raw[NKS][2];
-    float rstd = 0.f;
-    {
-        const auto rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.z + (long long)i * bs), 0,
-                                                            (int)(((long long)T - 1) * ss * 4 + CZ * 4), 0x00020000);
-        const int zoff = (int)((long long)row * ss * 4) + 32 * hh;      // rows >= T: beyond the range, read as zero
+    // ---- 1. the wave's 32 rows of z[i] / rms, already scaled and split, in fragment order (written by pd_pair_bias_split)
+    const int ntile = (T + 31) >> 5;
+    const frag* zbase = reinterpret_cast<const frag*>(p.z2) + ((long long)i * ntile + wave) * (NKS * 2 * 64) + lane;
+    frag zh[NKS], zlr[WLDS ? NKS : 1];                                  // high parts (and, WLDS, low parts) of all eight k-steps
+    auto zfrag_g = [&](int s, int part) {
+        if constexpr (ABL & 16) return __builtin_bit_cast(frag, part ? u32x4{0x1c001c00u, 0x1c009c00u, 0x18001c00u, 0x1c001400u}
+                                                                      : u32x4{0x3c003c00u, 0x3c00bc00u, 0x38003c00u, 0x3c003400u});
+        return wave_active ? zbase[(2 * s + part) * 64] : frag{};
+    };
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            if constexpr (ABL & 16) { raw[s][0] = f32x4{1.f, -2.f, 0.5f, 3.f}; raw[s][1] = f32x4{-1.f, 2.f, 0.25f, 1.f}; continue; }
-            raw[s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, zoff, 64 * s, 0));
-            raw[s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, zoff, 64 * s + 16, 0));
-        }
-        if (row < T) rstd = p.stats[2 * (p.transpose ? (long long)row * T + i : (long long)i * T + row) + 1];
+    for (int s = 0; s < NKS; ++s) {
+        zh[s] = zfrag_g(s, 0);
+        if constexpr (WLDS) zlr[s] = zfrag_g(s, 1);
     }
-    PD_SB();
-    // rows -> two-part fp16 fragments (lane = row, k-step s = channels 16 s + 8 hh .. + 8): [s][0] high, [s][1] low parts
-    // The HIGH parts stay in registers (32); the LOW parts go to a wave-private 8 KB slot of the (still unused) K / V tile space, one
-    // 16-byte fragment per (k-step, lane): 64 registers of row fragments + accumulator + weight fragments would not fit four waves per SIMD
-    frag zh[NKS];
-    unsigned short* zl = lds + wave * (NKS * 64 * 8) + lane * 8;
-    {
-        const float f = rstd * a_s;
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            const f32x4 v0 = raw[s][0], v1 = raw[s][1];
-            u32x4 fh, fl;
-            pd_parts2 t;
-            t = pd_split2h(v0[0] * f, v0[1] * f); fh[0] = t.h; fl[0] = t.l;
-            t = pd_split2h(v0[2] * f, v0[3] * f); fh[1] = t.h; fl[1] = t.l;
-            t = pd_split2h(v1[0] * f, v1[1] * f); fh[2] = t.h; fl[2] = t.l;
-            t = pd_split2h(v1[2] * f, v1[3] * f); fh[3] = t.h; fl[3] = t.l;
-            zh[s] = __builtin_bit_cast(frag, fh);
-            *reinterpret_cast<u32x4*>(zl + s * 512) = fl;
-        }
-    }
+    auto zlo_frag = [&](int s) {
+        if constexpr (WLDS) return zlr[s];
+        else return zfrag_g(s, 1);
+    };
 
     // ---- 2. projection: weight fragments [2 parts][12 tiles][8 k-steps][64 lanes][8] (packing.split2_f16 of the [3 C][C] matrix)
     const frag* wbase = reinterpret_cast<const frag*>(p.W2) + lane;
+    unsigned short* const ldsW = lds + NTILE * STAGE;                   // WLDS: [3 tiles q, k, v][2 parts][8 k-steps][64 lanes][8]
+    if constexpr (WLDS) {
+        // 3 072 fragments of 16 bytes, six per thread: thread t takes fragments t, t + 512, ... of the head's slice, read in the order
+        // they are stored in (coalesced kilobytes)
+        frag tmp[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int f = tid + 512 * j;                                // (tile3 * 2 + part) * 512 + s * 64 + lane'
+            const int tp = f >> 9, sl = f & 511;
+            const int t3 = tp >> 1, part = tp & 1;
+            tmp[j] = (ABL & 2) ? frag{} : reinterpret_cast<const frag*>(p.W2)[((part * 12 + 4 * t3 + h) * NKS) * 64 + sl];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<frag*>(ldsW + (tid + 512 * j) * 8) = tmp[j];
+        lds_barrier();
+    }
     auto wfrag = [&](int tile, int s, int part) {
+        if constexpr (WLDS) return *reinterpret_cast<const frag*>(ldsW + ((((tile >> 2) * 2 + part) * NKS + s) * 64 + lane) * 8);
         if constexpr (ABL & 2) return __builtin_bit_cast(frag, u32x4{0x3c003c00u + tile, 0x3c003c00u + s, 0x3c003c00u + part, 0x3c003c00u});
         return wbase[((part * 12 + tile) * NKS + s) * 64];
     };
@@ -141,24 +148,26 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        frag wh = wfrag(wtile, 0, 0), wl = wfrag(wtile, 0, 1);
-        frag zlo = *reinterpret_cast<const frag*>(zl);
+        // fragments of k-steps s + 1 and s + 2 are in flight while the MFMAs of k-step s issue (L2 round trips of ~1 us against 96 matrix
+        // cycles per k-step; the sched_barriers keep hipcc from hoisting all sixteen requests - 64 registers - to the top)
+        frag wh[3], wl[3], zl[3];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) { wh[d] = wfrag(wtile, d, 0); wl[d] = wfrag(wtile, d, 1); zl[d] = zlo_frag(d); }
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
-            frag nh = wh, nl = wl, nz = zlo;
-            if (s + 1 < NKS) { nh = wfrag(wtile, s + 1, 0); nl = wfrag(wtile, s + 1, 1); nz = *reinterpret_cast<const frag*>(zl + (s + 1) * 512); }
+            const int c = s % 3, n = (s + 2) % 3;
+            if (s + 2 < NKS) { wh[n] = wfrag(wtile, s + 2, 0); wl[n] = wfrag(wtile, s + 2, 1); zl[n] = zlo_frag(s + 2); }
             PD_SB();
             if (transposed) {
-                acc = jmma(wh, zlo, acc);
-                acc = jmma(wl, zh[s], acc);
-                acc = jmma(wh, zh[s], acc);
+                acc = jmma(wh[c], zl[c], acc);
+                acc = jmma(wl[c], zh[s], acc);
+                acc = jmma(wh[c], zh[s], acc);
             } else {
-                acc = jmma(zlo, wh, acc);
-                acc = jmma(zh[s], wl, acc);
-                acc = jmma(zh[s], wh, acc);
+                acc = jmma(zl[c], wh[c], acc);
+                acc = jmma(zh[s], wl[c], acc);
+                acc = jmma(zh[s], wh[c], acc);
             }
             PD_SB();
-            wh = nh; wl = nl; zlo = nz;
         }
         return acc;
     };
@@ -195,17 +204,17 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
             qf[st][1] = __builtin_bit_cast(frag, fl);
         }
     }
-    u32x2 kh2[4], kl2[4];                                               // the wave's K rows, packed (stored behind the barrier below)
     {
         // k (transposed): acc[r] = k[dim pd_frag_row(r, hh)][key l31] -> the key's row of the K tile
         f32x16 acc = project(4 + h, true);
         const float fk = sk * inv_as * p.w_inv[CZ + 32 * h];
+        const int ko = (half * 32 + l31) * KP + 4 * hh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const pd_parts2 t0 = pd_split2h(acc[4 * g] * fk, acc[4 * g + 1] * fk);
             const pd_parts2 t1 = pd_split2h(acc[4 * g + 2] * fk, acc[4 * g + 3] * fk);
-            kh2[g] = u32x2{t0.h, t1.h};
-            kl2[g] = u32x2{t0.l, t1.l};
+            *reinterpret_cast<u32x2*>(sK + ko + 8 * g) = u32x2{t0.h, t1.h};
+            *reinterpret_cast<u32x2*>(sK + K_PART + ko + 8 * g) = u32x2{t0.l, t1.l};
         }
     }
     {
@@ -214,13 +223,6 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         f32x16 acc = project(8 + h, false);
         const float fv = sv * inv_as * p.w_inv[2 * CZ + 32 * h];
         const int vo = l31 * VP + half * 32 + 8 * hh;
-        const int ko = (half * 32 + l31) * KP + 4 * hh;
-        lds_barrier();                  // every wave has read the last of its row fragments: the tile space is free for K / V
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *reinterpret_cast<u32x2*>(sK + ko + 8 * g) = kh2[g];
-            *reinterpret_cast<u32x2*>(sK + K_PART + ko + 8 * g) = kl2[g];
-        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const pd_parts2 t0 = pd_split2h(acc[4 * g] * fv, acc[4 * g + 1] * fv);
@@ -438,12 +440,12 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
 PD_EXPORT int pd_tri_attn_args_size(void) { return (int)sizeof(pd_tri_attn_args); }
 
 PD_EXPORT int pd_tri_attention(const pd_tri_attn_args* a, void* stream) {
-    if (!a || !a->z || !a->stats || !a->W2 || !a->w_inv || !a->bias || !a->o || !a->qkv_amax) return PD_ERR_ARG;
+    if (!a || !a->z2 || !a->W2 || !a->w_inv || !a->bias || !a->o || !a->qkv_amax) return PD_ERR_ARG;
     if (a->T <= 0 || a->Treal <= 0 || a->Treal > a->T) return PD_ERR_ARG;
     if (a->C != CZ || a->nheads != CZ / 32 || a->T > NTILE * KT || a->T % 4 != 0 || !(a->bias_prescale > 0.f) || !(a->zn_amax > 0.f))
         return PD_ERR_UNSUPPORTED;
     if (a->bias_prescale > 0x1p90f) return PD_ERR_UNSUPPORTED;         // (masked entries must stay finite: pd_attention_pipe_ok)
-    if ((((uintptr_t)a->z | (uintptr_t)a->W2 | (uintptr_t)a->o | (uintptr_t)a->w_inv) & 15) != 0) return PD_ERR_UNSUPPORTED;
+    if ((((uintptr_t)a->z2 | (uintptr_t)a->W2 | (uintptr_t)a->o | (uintptr_t)a->w_inv) & 15) != 0) return PD_ERR_UNSUPPORTED;
     if ((long long)a->T * a->T * CZ * 4 >= 0xffffff00ll) return PD_ERR_UNSUPPORTED;
     static bool raised = false;
     if (!raised) {

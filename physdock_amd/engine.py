@@ -276,9 +276,21 @@ class Engine:
         bias = self.ws.get("tri_bias", ops.bias_frag_numel(H, T, T), zero=True)
         # (strides of the widest projection layout, q|k|v|g: the fused-tail q|k|v form only shrinks them)
         ps = self.trunk_prescale(prefix, nw, T, T, self.Tr, H, strides=(4 * C, T * 4 * C) if transpose else (T * 4 * C, 4 * C))
-        self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, norm="norm", st_out=st, prescale=ps)
         bnd = self.trunk_attn_bounds(prefix, nw)
         Wo, bo, _, _, ldw = P.linear(prefix + ".linear_o")
+        # round 6: when the attention projects q | k | v inside its blocks (csrc/tri_attn.hip) the bias pass over z also writes the
+        # normalised rows, scaled and split, in that kernel's fragment order (33.5 MB at T = 256, read by the four head blocks of a row)
+        zn_amax = math.sqrt(C) * 1.0001
+        want_in_block = (bnd is not None and ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM and C == 128 and ldw == C and H == 4
+                         and ops.FUSED_TRI_ATTN and ps > 0.0 and T <= 256 and T % 4 == 0)
+        z2 = None
+        if want_in_block:
+            z2 = self.ws.get("tri_z2", ops.tri_z2_numel(T), dtype=torch.float16, zero=True)
+            if not ops.pair_bias_split(z, P.bias_w(prefix, "norm"), bias, T, z2, stats_out=st, maskadd=mask, maskval=-self.inf,
+                                       out_scale=LOG2E * ps, transpose=transpose, eps=self.eps, zn_amax=zn_amax):
+                z2 = None
+        if z2 is None:
+            self.pair_bias(prefix, z, T, T, C, mask, nw, bias, transpose=transpose, norm="norm", st_out=st, prescale=ps)
         # With the fused tail (pd_tri_tail mode 1: gate projection + linear_o + gate + residual in one launch) the projection in
         # front is q|k|v only and the gate tensor never exists
         f16 = bnd is not None and ops.F16_GEMM and ops.F16_TRUNK_GEMM and ops.SPLIT_GEMM and C == 128 and ldw == C
@@ -286,9 +298,11 @@ class Engine:
         o = self.ws.get("attn_o", M, C)
         # round 6: the q | k | v projection INSIDE the attention block (csrc/tri_attn.hip): q | k | v never exist in HBM.  Needs the
         # pre-scaled bias of the fp16-format kernels and T <= 256; the gate is then projected by the fused tail or on its own
-        in_block = (f16 and ops.FUSED_TRI_ATTN and ps > 0.0 and T <= 256
-                    and ops.tri_attention(z, st, P.qkv_folded_w2(prefix, nw), bias, o, T, self.Tr, C, H, transpose=transpose,
-                                          bias_prescale=ps, bias_nk=T, qkv_amax=bnd, zn_amax=math.sqrt(C) * 1.0001))
+        in_block = (z2 is not None
+                    and ops.tri_attention(z2, P.qkv_folded_w2(prefix, nw), bias, o, T, self.Tr, C, H, transpose=transpose,
+                                          bias_prescale=ps, bias_nk=T, qkv_amax=bnd, zn_amax=zn_amax))
+        if z2 is not None and not in_block:
+            raise RuntimeError("pd_tri_attention refused a shape pd_pair_bias_split accepted")
         nq = 3 if fused else 4
         qkvg = None
         if not in_block:

@@ -275,10 +275,10 @@ FUSED_TRUNK_TRANSITION = True
 #: the tail of the TriangleUpdate (gate projection, norm of the einsum output, K = 32 projection, gate, residual) in one launch
 FUSED_TRI_TAIL = True
 #: ... and the tail of the TriangleAttention (gate projection, linear_o, gate, residual; the projection in front shrinks to q|k|v).
-#: Correct (tests/test_tri_tail_gpu.py) but OFF: measured 45.4 (q|k|v) + 39.6 us (tail) against 50.5 (q|k|v|g) + 24.8 us (linear_o with
-#: the gate tensor) per triangle attention at T = 256 - the tail kernel's per-tile latency chain at two blocks per CU costs more than
-#: the 67 MB of gate traffic it removes (profiles/r04_trunk_kernels.txt)
-FUSED_TRI_ATTN_TAIL = False
+#: Round 4 measured it slower behind a q|k|v GEMM (45.4 + 39.6 us against 50.5 (q|k|v|g) + 24.8 us) and left it off; with the projection
+#: inside the attention block (FUSED_TRI_ATTN, round 6) the gate has no projection to ride on, and the tail (one launch) against gate
+#: GEMM + linear_o GEMM (two) measures 22.9 - 23.3 ms against 23.4 ms per trunk pass: on.  PD_FUSED_TRI_ATTN_TAIL=0 switches it off.
+FUSED_TRI_ATTN_TAIL = os.environ.get("PD_FUSED_TRI_ATTN_TAIL", "1") != "0"
 #: the triangle einsum on the two-part fp16 format (csrc/tri_mul.hip) instead of 32 batched fp32-MFMA GEMMs: "row" = the outgoing
 #: form only (15.8 vs 16.1 us at T = 256, error vs float64 6.8e-8 vs 1.0e-7 rms); the incoming form's transposing LDS scatter
 #: measured 23.4 vs 16.6 us and stays on the k-major fp32 kernel; True = both forms
@@ -368,12 +368,28 @@ def tri_tail(z, o, M, Cdim, Co, *, w_in, w_out, eps, Wg, bg, Wz, bz, zn_amax, on
 FUSED_TRI_ATTN = os.environ.get("PD_FUSED_TRI_ATTN", "1") != "0"
 
 
-def tri_attention(z, stats, W2, bias, o, T, Treal, Cdim, nheads, *, transpose, bias_prescale, bias_nk, qkv_amax, zn_amax):
-    """TriangleAttention up to the attention output in one launch (pd_tri_attention): RMSNorm(z) (statistics given) -> q | k | v
-    projection -> biased attention.  W2: (parts, w_inv) of packing.split2_f16 of the [3 C][C] projection with the norm gain folded in.
-    Returns False when the library does not cover the shape."""
+def tri_z2_numel(T):
+    """fp16 elements of the split normalised rows pd_pair_bias_split writes for pd_tri_attention: [T][ceil(T/32)][8][2][64][8]"""
+    return T * ((T + 31) // 32) * 8 * 2 * 64 * 8
+
+
+def pair_bias_split(x, Wf, frag, T, z2, *, stats_out=None, maskadd=None, maskval=0.0, out_scale=1.0, transpose=False, eps=1e-8,
+                    zn_amax):
+    """pd_pair_bias for a TriangleAttention (C = 128, H = 4, RMS) that also writes the normalised rows, scaled and split, in
+    pd_tri_attention's fragment order into z2 (int16 / fp16 tensor of tri_z2_numel(T) elements, zeroed once by the caller)"""
+    if T % 4 != 0:
+        return False
+    check(_lib.init().pd_pair_bias_split(ptr(x), ptr(Wf), None, ptr(stats_out), ptr(maskadd), maskval, out_scale, ptr(frag), T,
+                                         int(transpose), eps, z2.data_ptr(), float(zn_amax), stream()), "pd_pair_bias_split")
+    return True
+
+
+def tri_attention(z2, W2, bias, o, T, Treal, Cdim, nheads, *, transpose, bias_prescale, bias_nk, qkv_amax, zn_amax):
+    """TriangleAttention up to the attention output in one launch (pd_tri_attention): q | k | v projection of the normalised rows z2
+    (pair_bias_split's output) -> biased attention.  W2: (parts, w_inv) of packing.split2_f16(rows_per_scale=32) of the [3 C][C]
+    projection with the norm gain folded in.  Returns False when the library does not cover the shape."""
     a = _lib.TriAttnArgs()
-    a.z, a.stats, a.W2, a.w_inv = ptr(z), ptr(stats), W2[0].data_ptr(), W2[1].data_ptr()
+    a.z2, a.W2, a.w_inv = z2.data_ptr(), W2[0].data_ptr(), W2[1].data_ptr()
     a.bias, a.bias_prescale, a.bias_nk, a.o = ptr(bias), float(bias_prescale), int(bias_nk), ptr(o)
     a.T, a.Treal, a.C, a.nheads, a.transpose = T, Treal, Cdim, nheads, int(bool(transpose))
     a.zn_amax, a.qkv_amax, a.scale = float(zn_amax), (qkv_amax if isinstance(qkv_amax, int) else ptr(qkv_amax)), 1.0 / math.sqrt(32.0)

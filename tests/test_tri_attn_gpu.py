@@ -1,5 +1,6 @@
-"""pd_tri_attention (csrc/tri_attn.hip, round 6): TriangleAttention up to the attention output in ONE launch - RMSNorm (statistics
-given), q | k | v projection on the two-part fp16 format inside the attention block, pipelined biased attention - against a float64
+"""pd_pair_bias_split + pd_tri_attention (csrc/pairbias.hip, csrc/tri_attn.hip, round 6): TriangleAttention up to the attention output
+in two launches - the bias pass over z that also writes the normalised rows split and in fragment order, then q | k | v projection on
+the two-part fp16 format INSIDE the attention block + pipelined biased attention - against a float64
 statement of reference primitives/attentions.py:194-211, next to the two-launch form it replaces (pd_gemm + pd_attention) and to
 plain fp32 torch.  Row and column variants, ragged key counts, fully masked rows.  GPU only."""
 import math
@@ -56,12 +57,19 @@ def test_tri_attention_vs_float64(T, Tr, transpose):
     st = torch.empty(M, 2, device="cuda")
     bias = torch.zeros(ops.bias_frag_numel(H, T, T), device="cuda")
     Wf = (Wb * nw[None]).contiguous()
-    assert ops.pair_bias(z, Wf, bias, T, T, C, H, stats_out=st, maskadd=mt, maskval=-1e9, out_scale=1.4426950408889634 * ps,
+    zn_amax = math.sqrt(C) * 1.0001
+    z2 = torch.zeros(ops.tri_z2_numel(T), dtype=torch.float16, device="cuda")
+    assert ops.pair_bias_split(z, Wf, bias, T, z2, stats_out=st, maskadd=mt, maskval=-1e9, out_scale=1.4426950408889634 * ps,
+                               transpose=transpose, eps=eps, zn_amax=zn_amax)
+    # the bias tiles and the statistics of the split variant are those of pd_pair_bias, bit for bit
+    st0, bias0 = torch.empty_like(st), torch.zeros_like(bias)
+    assert ops.pair_bias(z, Wf, bias0, T, T, C, H, stats_out=st0, maskadd=mt, maskval=-1e9, out_scale=1.4426950408889634 * ps,
                          transpose=transpose, mode=ops.RMS, eps=eps)
+    assert torch.equal(st, st0) and torch.equal(bias, bias0)
     o = torch.full((T, T, C), float("nan"), device="cuda")
     W2 = split2_f16((Wqkv * nw[None]).contiguous(), rows_per_scale=32)
-    ok = ops.tri_attention(z, st, W2, bias, o, T, Tr, C, H, transpose=transpose, bias_prescale=ps, bias_nk=T, qkv_amax=bounds,
-                           zn_amax=math.sqrt(C) * 1.0001)
+    ok = ops.tri_attention(z2, W2, bias, o, T, Tr, C, H, transpose=transpose, bias_prescale=ps, bias_nk=T, qkv_amax=bounds,
+                           zn_amax=zn_amax)
     assert ok
     torch.cuda.synchronize()
     # o in "batch, query" order; query rows beyond the real tokens are padding.  Query row 3 is fully masked: in fp32 the -1e9 absorbs

@@ -36,10 +36,16 @@ def timeit(fn, n=50):
     return 1e3 * e0.elapsed_time(e1) / n
 
 
+zn_amax = math.sqrt(C) * 1.0001
+z2 = torch.zeros(ops.tri_z2_numel(T), dtype=torch.float16, device="cuda")
+Wf = (Wb * nw[None]).contiguous()
 for tr in (False, True):
-    assert ops.pair_bias(z, (Wb * nw[None]).contiguous(), bias, T, T, C, H, stats_out=st, maskadd=mask, maskval=-1e9, out_scale=1.4426950408889634 * ps,
-                         transpose=tr, mode=ops.RMS, eps=1e-8)
-    t = timeit(lambda: ops.tri_attention(z, st, W2, bias, o, T, T, C, H, transpose=tr, bias_prescale=ps, bias_nk=T, qkv_amax=bounds,
-                                         zn_amax=math.sqrt(C) * 1.0001))
+    tb = timeit(lambda: ops.pair_bias(z, Wf, bias, T, T, C, H, stats_out=st, maskadd=mask, maskval=-1e9, out_scale=1.4426950408889634 * ps,
+                                      transpose=tr, mode=ops.RMS, eps=1e-8))
+    tbs = timeit(lambda: ops.pair_bias_split(z, Wf, bias, T, z2, stats_out=st, maskadd=mask, maskval=-1e9, out_scale=1.4426950408889634 * ps,
+                                             transpose=tr, eps=1e-8, zn_amax=zn_amax))
+    t = timeit(lambda: ops.tri_attention(z2, W2, bias, o, T, T, C, H, transpose=tr, bias_prescale=ps, bias_nk=T, qkv_amax=bounds,
+                                         zn_amax=zn_amax))
     flop = 2.0 * T * T * 3 * C * C + 4.0 * T * H * T * T * 32
-    print(f"tri_attention T={T} transpose={tr}: {t:.1f} us  ({flop / t * 1e-6:.0f} TF algorithmic, {3 * flop / t * 1e-6 / 2516.6:.3f} of the fp16 pipe executed)")
+    print(f"tri_attention T={T} transpose={tr}: {t:.1f} us  ({flop / t * 1e-6:.0f} TF algorithmic, {3 * flop / t * 1e-6 / 2516.6:.3f} of the fp16 pipe executed); "
+          f"pair_bias {tb:.1f} us, pair_bias_split {tbs:.1f} us")
