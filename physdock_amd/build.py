@@ -66,7 +66,7 @@ def compile_cmd(src, out, mode=("-c",)):
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_KSPLIT_MAX_BYTES") and base == "gemm_stream.hip":
         cmd[1:1] = ["-DPD_KSPLIT_MAX_BYTES=" + os.environ["PD_KSPLIT_MAX_BYTES"]]
-    for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES", "PD_F16_MIN_TILES_SMALL", "PD_F16_MIN_TILES_SMALL_LONGK", "PD_F16_ABL", "PD_F16_T256", "PD_F16_T256_BPC", "PD_F16_ROWS_MIN_TILES", "PD_F16_ROWS_MIN_TILES64", "PD_F16_ROWS_NO_XPF", "PD_F16_ROWS_GIVEN_STATS", "PD_F16_WROWS_MIN_TILES", "PD_F16_WROWS_MIN_TILES_SPLIT", "PD_F16_WROWS_MAX_SPLIT", "PD_F16_WROWS_TINY", "PD_F16_WROWS_MIN_ITEMS", "PD_F16_WROWS_A2", "PD_F16_WCHUNK", "PD_F16_WROWS_GLU12", "PD_F16_WROWS_12", "PD_F16_WROWS_KS", "PD_F16_WROWS_PLAIN", "PD_F16_WROWS_PLAIN_MAX_TILES"):
+    for knob in ("PD_F16_GLU_LDSW", "PD_F16_MIN_TILES", "PD_F16_MIN_TILES_SMALL", "PD_F16_MIN_TILES_SMALL_LONGK", "PD_F16_ABL", "PD_F16_T256", "PD_F16_T256_BPC", "PD_F16_ROWS_MIN_TILES", "PD_F16_ROWS_MIN_TILES64", "PD_F16_ROWS_NO_XPF", "PD_F16_ROWS_GIVEN_STATS", "PD_F16_WROWS_MIN_TILES", "PD_F16_WROWS_MIN_TILES_SPLIT", "PD_F16_WROWS_MAX_SPLIT", "PD_F16_WROWS_TINY", "PD_F16_WROWS_MIN_ITEMS", "PD_F16_WROWS_A2", "PD_F16_WCHUNK", "PD_F16_WROWS_GLU12", "PD_F16_WROWS_12", "PD_F16_WROWS_KS", "PD_F16_WROWS_PLAIN", "PD_F16_WROWS_PLAIN_MAX_TILES", "PD_F16_WROWS_ROUNDS"):
         if os.environ.get(knob) and base == "gemm_f16.hip":
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_ATTN_NOSPLIT_BLOCKS") and base == "attention.hip":     # lab: block count from which a launch is not key-split

@@ -999,6 +999,9 @@ inline bool wrows_ks_shape(const pd_gemm_args* p) {
 #ifndef PD_F16_WROWS_MIN_ITEMS
 #define PD_F16_WROWS_MIN_ITEMS 8
 #endif
+#ifndef PD_F16_WROWS_ROUNDS
+#define PD_F16_WROWS_ROUNDS 1      // lab: 0 = the round-5 split rule (256 / ntiles) for 129 - 255 row tiles
+#endif
 template <int PRO, int EPI, int TM, int TN, int GK = 4, int NWV = 16>
 int run_f16_wrows(int op, const pd_gemm_args* p, hipStream_t s) {
     auto k = gemm_f16_wrows_kernel<PRO, EPI, TM, TN, GK, NWV>;
@@ -1015,6 +1018,18 @@ int run_f16_wrows(int op, const pd_gemm_args* p, hipStream_t s) {
     const int max_split = few ? 4 * PD_F16_WROWS_MAX_SPLIT : PD_F16_WROWS_MAX_SPLIT;
     nsplit = nsplit > max_split ? max_split : nsplit;
     while (nsplit > 1 && nitems / nsplit < (few ? PD_F16_WROWS_MIN_ITEMS / 4 : PD_F16_WROWS_MIN_ITEMS)) --nsplit;
+    // Round 6 (the sample-count cliffs): between 129 and 255 row tiles (33 - 63 samples of 256 tokens) 256 / ntiles is 1 and
+    // every block walks ALL columns while up to half the CUs idle - 36 samples ran the SwiGLU projection in 92 us against 68 us at 32.  One
+    // block per CU means whole rounds: s blocks per row tile cost ceil(ntiles s / 256) rounds of (staging + 1 / s of the columns), staging
+    // ~ 15 % of a full tile (fitted: with 8 % the model picked s = 4 for 48 samples, measured 326.8 -> 333.8 ms per call; 36 / 40 samples
+    // take s = 3: 291.1 -> 277.8 / 299.4 -> 288.9 ms, profiles/r06_ab_wrows_rounds.txt); take the cheapest s (the smallest on a tie).
+    if (PRO != 3 && ntiles > 128 && ntiles < 256 && PD_F16_WROWS_ROUNDS) {
+        float best = 1e9f;
+        for (int sp = 1; sp <= 6 && nitems / sp >= PD_F16_WROWS_MIN_ITEMS; ++sp) {
+            const float c = (float)((ntiles * sp + 255) / 256) * (0.15f + 1.0f / (float)sp);
+            if (c < best - 1e-4f) { best = c; nsplit = sp; }
+        }
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)(nsplit > 1 ? ntiles * nsplit : (ntiles < 256 ? ntiles : 256))), dim3(64 * NWV), WROWS_LDS_BYTES, s, *p);
     return pd_check_launch();
 }

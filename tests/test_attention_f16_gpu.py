@@ -285,11 +285,16 @@ def test_trunk_attention_on_static_bounds():
         ops.F16_TRUNK_ATTN = ops.F16_TRUNK_GEMM = flag        # (the projections that consume o and the transitions' hidden rows too)
         seen = []
         ops.ATTN_HOOK = lambda a, launch: (seen.append(L.pd_attention_variant(C_.byref(a))), launch())
+        # (round 6: the triangle attentions of the fp16-format trunk project q | k | v inside their own kernel, pd_tri_attention, and
+        #  no longer pass through pd_attention: counted as fp16-format launches, variant 4000)
+        tri = ops.tri_attention
+        ops.tri_attention = lambda *a_, **k_: (seen.append(4000), tri(*a_, **k_))[1]
         try:
             a_, ap_, s_, z_ = eng.conditioning(batch)
             outs[flag] = (a_.clone(), s_.clone(), z_.clone())
         finally:
             ops.ATTN_HOOK = None
+            ops.tri_attention = tri
             ops.F16_TRUNK_ATTN = ops.F16_TRUNK_GEMM = True
         variants[flag] = list(seen)
     n16 = sum(v >= 2000 for v in variants[True])
