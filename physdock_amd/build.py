@@ -89,6 +89,8 @@ def compile_cmd(src, out, mode=("-c",)):
         cmd[1:1] = ["-DPD_TRI_WLDS=" + os.environ["PD_TRI_WLDS"]]
     if os.environ.get("PD_TRI_ABL") and base == "tri_attn.hip":        # lab: timing ablations of the fused triangle attention (wrong results)
         cmd[1:1] = ["-DPD_TRI_ABL=" + os.environ["PD_TRI_ABL"]]
+    if os.environ.get("PD_PIPE_RES") and base == "attn_pipe.hip":      # lab: 0 = no resident-K/V form for launches of <= 256 keys
+        cmd[1:1] = ["-DPD_PIPE_RES=" + os.environ["PD_PIPE_RES"]]
     if os.environ.get("PD_PIPE_ABL") and base == "attn_pipe.hip":      # lab: timing ablations of the pipelined attention (wrong results)
         cmd[1:1] = ["-DPD_PIPE_ABL=" + os.environ["PD_PIPE_ABL"]]
     if os.environ.get("PD_TR_SILU") and base == "transition_f16.hip":     # lab: form of the SiLU in the fused transition (0 division, 1 / 2 reciprocal)

@@ -92,8 +92,14 @@ __device__ __forceinline__ void lds_barrier() {
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-// PRE: K and V arrive already scaled and split (pd_attn_args.K2 / V2); HASBIAS: bias fragments multiplied by bias_prescale
-template <int NW, bool PRE, bool HASBIAS>
+// PRE: K and V arrive already scaled and split (pd_attn_args.K2 / V2); HASBIAS: bias fragments multiplied by bias_prescale;
+// RES (round 6): ALL key tiles of the block resident - launches with at most RES_TILES x 64 keys (token DiT attention, MSA row / pair-biased
+// attention of the trunk: 256 keys) request every K / V tile in the prologue, stage them into four LDS tiles (78 KB: still two blocks per
+// CU) and pass ONE block barrier; the main loop then has no staging, no requests but the bias tiles, and no barrier.  A four-tile block
+// of the streaming form spends two thirds of its life outside the pipelined phases (profiles/r05_attn_pipe_block_life_token_shape.txt);
+// the same wave program over resident keys measured 19 us net inside tri_attn_kernel against 35 - 43 us here.
+constexpr int RES_TILES = 4;
+template <int NW, bool PRE, bool HASBIAS, bool RES = false>
 __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2, 4))) void attn_pipe_kernel(const pd_attn_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -170,14 +176,15 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
         voff_g[i] = (int)((srow + RPP * i) * vss) + 16 * sc;
     }
     const int ktile_b = (int)(KT * kss), vtile_b = (int)(KT * vss);      // bytes per 64-key tile
-    auto gload = [&](int tile) {
+    auto gload_to = [&](f32x4 (&rk)[NST], f32x4 (&rv)[NST], int tile) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
             rk[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_k, koff_g[i], tile * ktile_b, 0));
             rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff_g[i], tile * vtile_b, 0));
         }
     };
-    auto sstore = [&](int stage_off) {
+    auto gload = [&](int tile) { gload_to(rk, rv, tile); };
+    auto sstore_from = [&](const f32x4 (&rk)[NST], const f32x4 (&rv)[NST], int stage_off) {
         unsigned short* sK = lds + stage_off;
         unsigned short* sV = sK + 2 * K_PART;
 #pragma unroll
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
             }
         }
     };
+    auto sstore = [&](int stage_off) { sstore_from(rk, rv, stage_off); };
 
     // ---- fragment addresses: lane offsets are loop-invariant, stage / sub-tile offsets are scalars
     const int koff = l31 * KP + 8 * hh;                    // K fragment (A operand: 8 dims of key l31), + part * K_PART + 16 st
@@ -409,7 +417,12 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
 
     // ---- prologue: every independent request first (K / V tile 0, bias tiles 0 / 1 into the two score accumulators, the lane's
     // query row) - their latencies overlap instead of adding up, which is most of a short launch (256 keys: 4 tiles per block)
+    f32x4 rkr[RES ? RES_TILES - 1 : 1][NST], rvr[RES ? RES_TILES - 1 : 1][NST];      // RES: tiles 1 .. 3 (tile 0 in rk / rv)
     gload(0);
+    if constexpr (RES) {
+#pragma unroll
+        for (int t = 1; t < RES_TILES; ++t) gload_to(rkr[t - 1], rvr[t - 1], t);      // (tiles beyond the last key read as zero)
+    }
     load_bias(sA, 0);
     load_bias(sB, 1);
     f32x4 qraw[2][2];
@@ -441,7 +454,12 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     PD_PSTAMP(2);                                          // Q arrived and split
     sstore(0);
     PD_PSTAMP(3);                                          // K / V tile 0 arrived and staged
-    gload(1);
+    if constexpr (RES) {
+#pragma unroll
+        for (int t = 1; t < RES_TILES; ++t) sstore_from(rkr[t - 1], rvr[t - 1], t * STAGE);
+    } else {
+        gload(1);
+    }
     lds_barrier();
     PD_PSTAMP(4);                                          // first barrier passed
     int s_cur = 0, s_nxt = STAGE, s_nn = 2 * STAGE;
@@ -457,20 +475,23 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
     if constexpr (ABL & 16) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
     if (wave_active) {
         for (int it = 0; it < nit - 1; ++it) {
-            if constexpr (!(ABL & 64)) sstore(s_nxt);      // tile it + 1 (requested one iteration ago)
-            if constexpr (!(ABL & 1)) lds_barrier();
-            if constexpr (!(ABL & 64)) gload(it + 2);      // tile it + 2 (rows beyond the last key read as zero)
+            if constexpr (!RES) {
+                if constexpr (!(ABL & 64)) sstore(s_nxt);      // tile it + 1 (requested one iteration ago)
+                if constexpr (!(ABL & 1)) lds_barrier();
+                if constexpr (!(ABL & 64)) gload(it + 2);      // tile it + 2 (rows beyond the last key read as zero)
+            }
             PD_SB();
             // sub-tile 2 it (cur = sA): next scores = sub-tile 2 it + 1 (same tile, second half)
             phase(sA, sB, mloc, kf0, s_cur + 32 * KP, s_cur, s_nxt, 2 * it + 2);
             // sub-tile 2 it + 1 (cur = sB): next scores = first half of tile it + 1
             phase(sB, sA, mloc, kf0, s_nxt, s_cur + 32, s_nxt + 32 * KP, 2 * it + 3);
-            const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t;
+            if constexpr (RES) { s_cur = s_nxt; s_nxt += STAGE; }          // resident tiles sit at it x STAGE
+            else { const int t = s_cur; s_cur = s_nxt; s_nxt = s_nn; s_nn = t; }
 #ifdef PD_LAB
             if (it < 6) PD_PSTAMP(6 + it);                 // end of main-loop iteration it
 #endif
         }
-    } else {                                               // a wave without queries (ragged last block) only stages
+    } else if constexpr (!RES) {                           // a wave without queries (ragged last block) only stages
         for (int it = 0; it < nit - 1; ++it) {
             sstore(s_nxt);
             lds_barrier();
@@ -524,12 +545,20 @@ __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW =
 }
 
 constexpr int LDS_BYTES = NSTAGE * STAGE * 2;
+constexpr int LDS_BYTES_RES = RES_TILES * STAGE * 2;
 
 template <int NW, bool PRE, bool HASBIAS>
 bool raise_lds() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<NW, PRE, HASBIAS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               LDS_BYTES) == hipSuccess;
+                               LDS_BYTES) == hipSuccess &&
+           (NW != 8 || hipFuncSetAttribute(reinterpret_cast<const void*>(attn_pipe_kernel<8, PRE, HASBIAS, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_RES) == hipSuccess);
 }
+
+// lab: 0 = launches of at most 256 keys stay on the streaming form (A/B of the resident form)
+#ifndef PD_PIPE_RES
+#define PD_PIPE_RES 1
+#endif
 
 // Short key ranges (<= PD_PIPE_NW4_MAXNK keys: token / triangle / MSA attention at 256 - 512 tokens) run on FOUR-wave blocks of 128
 // queries: a block lives for only four to eight key tiles, most of it prologue and tail, and twice as many independent blocks per CU
@@ -542,6 +571,9 @@ void launch(const pd_attn_args* a, hipStream_t stream) {
     if (a->nq > 128 && a->nk <= PD_PIPE_NW4_MAXNK) {
         dim3 grid(a->nbatch, (a->nq + 127) / 128, a->nheads);
         hipLaunchKernelGGL((attn_pipe_kernel<4, PRE, HASBIAS>), grid, dim3(256), LDS_BYTES, stream, *a);
+    } else if (a->nq > 128 && PD_PIPE_RES && a->nk <= RES_TILES * KT && a->nk > KT) {
+        dim3 grid(a->nbatch, (a->nq + 255) / 256, a->nheads);       // every key tile resident: one barrier, no staging in the loop
+        hipLaunchKernelGGL((attn_pipe_kernel<8, PRE, HASBIAS, true>), grid, dim3(512), LDS_BYTES_RES, stream, *a);
     } else if (a->nq > 128) {
         dim3 grid(a->nbatch, (a->nq + 255) / 256, a->nheads);
         hipLaunchKernelGGL((attn_pipe_kernel<8, PRE, HASBIAS>), grid, dim3(512), LDS_BYTES, stream, *a);
