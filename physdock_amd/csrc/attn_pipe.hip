@@ -96,8 +96,8 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 // RES (round 6): ALL key tiles of the block resident - launches with at most RES_TILES x 64 keys (token DiT attention, MSA row / pair-biased
 // attention of the trunk: 256 keys) request every K / V tile in the prologue, stage them into four LDS tiles (78 KB: still two blocks per
 // CU) and pass ONE block barrier; the main loop then has no staging, no requests but the bias tiles, and no barrier.  A four-tile block
-// of the streaming form spends two thirds of its life outside the pipelined phases (profiles/r05_attn_pipe_block_life_token_shape.txt);
-// the same wave program over resident keys measured 19 us net inside tri_attn_kernel against 35 - 43 us here.
+// of the streaming form spends two thirds of its life outside the pipelined phases (profiles/r05_attn_pipe_block_life_token_shape.txt).
+// Built, correct, and no faster (see PD_PIPE_RES below): kept as a lab form.
 constexpr int RES_TILES = 4;
 template <int NW, bool PRE, bool HASBIAS, bool RES = false>
 __global__ __launch_bounds__(64 * NW, 2) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2, 4))) void attn_pipe_kernel(const pd_attn_args p) {
@@ -555,9 +555,11 @@ bool raise_lds() {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_RES) == hipSuccess);
 }
 
-// lab: 0 = launches of at most 256 keys stay on the streaming form (A/B of the resident form)
+// lab: 1 = launches of at most 256 keys take the resident form.  Measured and OFF (profiles/r06_ab_pipe_resident.txt): token DiT attention
+// 44.4 vs 44.5 us, triangle shape 42.4 vs 43.9 us, 64-sample call 402.4 / 401.9 vs 401.7 / 402.7 ms - the per-tile barrier and staging
+// are not what a four-tile launch waits for
 #ifndef PD_PIPE_RES
-#define PD_PIPE_RES 1
+#define PD_PIPE_RES 0
 #endif
 
 // Short key ranges (<= PD_PIPE_NW4_MAXNK keys: token / triangle / MSA attention at 256 - 512 tokens) run on FOUR-wave blocks of 128
