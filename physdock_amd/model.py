@@ -37,6 +37,9 @@ _CAPTURE_LOCK = threading.Lock()
 _CHECK_FINITE = os.environ.get("PD_CHECK_FINITE") == "1"
 #: PD_BOUND_CHECK=0 switches the first-call check of the fp16-format operand bounds off (engine.check_dit_bounds)
 _BOUND_CHECK = os.environ.get("PD_BOUND_CHECK", "1") != "0"
+#: missing step units whose kind has already run on the shape are recorded first and launched like cached ones (sample_diffusion, "the
+#: loop as UNITS"); 0: every missing unit runs eagerly and is recorded behind the loop (round 6's first form; A/B knob)
+PIPELINED_CAPTURE = os.environ.get("PD_PIPELINED_CAPTURE", "1") != "0"
 
 
 def _register(root: nn.Module, name: str, tensor: torch.Tensor):
@@ -76,6 +79,8 @@ class PhysDock(nn.Module):
         self.max_cached_units = 64 * 96   # 40 heads + 40 tails (+ gathers) per shape
         self.unit_captures = self.whole_captures = 0     # counters (tests, bench.py): unit graphs / whole-loop graphs captured so far
         self.last_unit_misses = self.last_head_misses = 0
+        self._warm_kinds = set()          # (shape key, unit kind) pairs whose workspace buffers exist: their units may be recorded before they run
+        self._capture_stream = None
         self.last_capture_ms = None       # host time of the most recent graph capture + instantiation (bench.py reports it)
         #: workspace buffers are cached per shape (288 GB of HBM make re-allocation pointless for a stream of
         #: same-size crops); when systems of many different sizes pass through, the cache is dropped beyond this size
@@ -97,6 +102,7 @@ class PhysDock(nn.Module):
             ops._lib.lib().pd_graph_destroy(u["exec"])
         self._graphs = {}
         self._units = {}
+        self._warm_kinds = set()
 
     def release_workspace(self):
         """free every cached activation buffer and captured step-loop graph (they are rebuilt on the next call)"""
@@ -460,16 +466,19 @@ class PhysDock(nn.Module):
         def host_relax():
             lig_out.copy_(relaxer(lig_in.clone(), int(mmff_iters)).to(device=device, dtype=torch.float32))
 
-        def capture(fn_lists):
+        def capture(fn_lists, sync=True):
             """record (not run) each launch list as one hipGraph; one capture at a time per process: objects driven from several host
             threads (parallel.StreamPool) replay concurrently, but two overlapping captures make unrelated launches of the other
-            thread fail"""
+            thread fail.  sync=False (units recorded in the middle of a call, below): no device synchronisation around the recording -
+            nothing is enqueued on the recording stream, and the launch stream keeps executing the units issued before"""
             import time as _time
             with _CAPTURE_LOCK:
-                torch.cuda.synchronize()
+                if sync:
+                    torch.cuda.synchronize()
                 t_cap = _time.perf_counter()
                 execs = []
-                cap = torch.cuda.Stream()
+                cap = self._capture_stream if getattr(self, "_capture_stream", None) is not None else torch.cuda.Stream()
+                self._capture_stream = cap
                 with torch.cuda.stream(cap):
                     for fns in fn_lists:
                         ops.check(L.pd_graph_begin(ops.stream()), "graph_begin")
@@ -477,8 +486,11 @@ class PhysDock(nn.Module):
                         ex = C.c_void_p()
                         ops.check(L.pd_graph_end(ops.stream(), C.byref(ex)), "graph_end")
                         execs.append(ex)
-                torch.cuda.synchronize()
-                self.last_capture_ms = 1e3 * (_time.perf_counter() - t_cap)
+                if sync:
+                    torch.cuda.synchronize()
+                    self.last_capture_ms = 1e3 * (_time.perf_counter() - t_cap)
+                else:
+                    self.last_capture_ms = (self.last_capture_ms or 0.0) + 1e3 * (_time.perf_counter() - t_cap)
             return execs
 
         fresh = not use_graph                 # did any launch of this call run eagerly (= was not replayed from a checked capture)?
@@ -503,9 +515,24 @@ class PhysDock(nn.Module):
         else:
             # replay the units that exist; run the others eagerly - they produce this call's result AND allocate their workspace
             # buffers, so the capture below (which only records) needs no launch of its own
-            missing = []
+            # A missing unit whose KIND (head / gather / tail of one physics branch) has already run once on this shape - earlier in this
+            # call or in an earlier one - finds every workspace buffer it touches allocated: it is RECORDED first (no execution: ~12 us
+            # per launch on the host against ~35 us for an eager launch) and then launched like a cached one, while the GPU still works on
+            # the units issued before.  Only the first unit of a kind runs eagerly (it allocates).  A new shape at 20 samples: 323 ->
+            # (measured, bench.py extra.graph_cache) ms per call.
+            missing, recorded = [], 0
+            terms = relaxer.terms if relaxer.kind == "device" else None
+            if PIPELINED_CAPTURE:
+                self.last_capture_ms = 0.0
             for ukey, fns, brk in units:
                 u = self._units.get(ukey)
+                kind = (common, ukey[1], ukey[-1][0] if ukey[1] == "T" else None)
+                if u is None and PIPELINED_CAPTURE and kind in self._warm_kinds:
+                    ex = capture([fns], sync=False)[0]
+                    u = self._units[ukey] = {"exec": ex, "terms": terms if ukey[1] == "T" and ukey[-1][0] == "mmff" else None}
+                    self.unit_captures += 1
+                    recorded += 1
+                    fresh = True                                   # (its first execution: the finite check below applies)
                 if u is not None:
                     self._units[ukey] = self._units.pop(ukey)      # LRU order
                     ops.check(L.pd_graph_launch(u["exec"], sp), "graph_launch")
@@ -513,15 +540,15 @@ class PhysDock(nn.Module):
                     fresh = True
                     run_fns(fns)
                     missing.append((ukey, fns))
+                    self._warm_kinds.add(kind)
                 if brk:
                     host_relax()
-            self.last_unit_misses = len(missing)
+            self.last_unit_misses = len(missing) + recorded
             self.last_head_misses = sum(1 for k, _ in missing if k[1] == "H")
             if missing:
                 # the captured launches hold raw device addresses: a unit keeps the MMFF table object whose tables it captured alive
                 # (a later call with an EQUAL table - same signature, e.g. rebuilt from the same RDKit molecule - replays against
                 # these tables, not against its own freshly built and soon freed ones)
-                terms = relaxer.terms if relaxer.kind == "device" else None
                 for (ukey, _), ex in zip(missing, capture([fns for _, fns in missing])):
                     self._units[ukey] = {"exec": ex, "terms": terms if ukey[1] == "T" and ukey[-1][0] == "mmff" else None}
                 self.unit_captures += len(missing)
