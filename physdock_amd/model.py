@@ -518,8 +518,8 @@ class PhysDock(nn.Module):
             # A missing unit whose KIND (head / gather / tail of one physics branch) has already run once on this shape - earlier in this
             # call or in an earlier one - finds every workspace buffer it touches allocated: it is RECORDED first (no execution: ~12 us
             # per launch on the host against ~35 us for an eager launch) and then launched like a cached one, while the GPU still works on
-            # the units issued before.  Only the first unit of a kind runs eagerly (it allocates).  A new shape at 20 samples: 323 ->
-            # (measured, bench.py extra.graph_cache) ms per call.
+            # the units issued before.  Only the first unit of a kind runs eagerly (it allocates).  First call of a new shape at 20 samples:
+            # 225 -> 179 ms against 164 ms cached; at 64 samples 392 -> 334 ms against 333 ms (profiles/r06_new_shape_call.txt).
             missing, recorded = [], 0
             terms = relaxer.terms if relaxer.kind == "device" else None
             if PIPELINED_CAPTURE:
