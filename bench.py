@@ -574,13 +574,15 @@ def main():
         extra["graph_cache"] = {"new_shape_call_ms": 1e3 * t_miss, "second_call_ms": 1e3 * t_second, "cached_shape_call_ms": 1e3 * t_hit, "capture_ms": cap_ms,
                                 "unit_graphs_cached": len(model._units), "whole_loop_graphs_cached": sum(1 for g_ in model._graphs.values() if g_["exec"]),
                                 "max_cached_graphs": model.max_cached_graphs,
-                                "note": "new shape = ragged T 256 / A 1803 system at 20 samples: workspace allocation + eager pass + capture of the step "
-                                        "units (one hipGraph per step head / tail; heads keyed by shape + schedule + step, tails by what the physics "
-                                        "branch depends on); the second call of a schedule captures the whole loop as one graph"}
+                                "note": "new shape = ragged T 256 / A 1803 system at 20 samples, first call: workspace allocation + the first step unit of "
+                                        "each kind eager, every other unit recorded and launched while the GPU works (one hipGraph per step head / "
+                                        "tail; heads keyed by shape + schedule + step, tails by what the physics branch depends on); the second call "
+                                        "of a schedule also records the whole loop as one graph, without a device synchronisation"}
         # the same ligands two at a time on two HIP streams of this GPU (parallel.StreamPool): their half-empty tail rounds overlap
         from physdock_amd.parallel import StreamPool
         pool = StreamPool(model, n=2)
-        pool.map(lambda m, sd_: driver.redock(m, dbatch, seed=sd_, **rk), [20, 21])
+        for _w in range(2):                     # (each replica: step units, then the whole-loop graphs of both rounds' schedules)
+            pool.map(lambda m, sd_: driver.redock(m, dbatch, seed=sd_, **rk), [20 + 2 * _w, 21 + 2 * _w])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pool.map(lambda m, sd_: driver.redock(m, dbatch, seed=sd_, **rk), [30, 31, 32, 33])
@@ -608,9 +610,27 @@ def main():
         assert torch.isfinite(xm).all()
         extra["samples_64_mmff"] = {"poses_per_s": B / dt, "ms_per_call": 1e3 * dt, "relaxation_steps": n_relax,
                                     "ligand_atoms": int(lig.sum()), "mmff_iters": 5, "backend": "device (pd_mmff_relax, fp64)"}
+        # ---- BASELINE config #3 in miniature: a STREAM of different systems (Posebusters: every system has its own token / atom counts, so
+        #      every call is the first of its shape), 64 samples per system, one round, ranking, PDB text - through driver.redock, each
+        #      system seen ONCE: workspace allocation for the shape, trunk, eager first unit of each kind, the other step units recorded
+        #      and launched behind, alignment, ranking, PDB formatting all inside the clock
+        shapes3 = [(200, 27), (180, 41), (224, 18), (210, 33), (190, 24), (216, 38)]
+        systems3 = [_syn.system(npro, 9, nlig, 128, seed=40 + j, n_conf=8) for j, (npro, nlig) in enumerate(shapes3)]
+        for s3 in systems3:
+            s3["dbatch"] = {k_: v_.to(device) for k_, v_ in s3["batch"].items()}
+        rk3 = dict(max_samples=64, max_rounds=1, num_samples_per_round=64, steps=nsteps, karras_noise_schedule_power=1000, ranking=True,
+                   physics_correction=False)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for j, s3 in enumerate(systems3):
+            r3 = driver.redock(model, s3["dbatch"], seed=80 + j, infer_meta_data=s3["infer_meta_data"], **rk3)
+        torch.cuda.synchronize(); dt3 = time.perf_counter() - t0
+        extra["stream_of_new_systems_64"] = {"systems": len(systems3), "poses_per_s": 64 * len(systems3) / dt3, "ms_per_system": 1e3 * dt3 / len(systems3),
+                                             "tokens_atoms": [[int(s3["batch"]["target_feat"].shape[0]), int(s3["batch"]["ref_pos"].shape[0])] for s3 in systems3],
+                                             "note": "every system a new shape (first call: no cached graph), ranking + PDB text included"}
         # ---- the headline's own worst cases
-        # (a) first calls at B = 64: call 1 = workspace allocation + trunk + first-call bound check (three eager denoiser passes) + eager
-        #     loop + capture of the 80 step units; call 2 = unit replay + capture of the whole-loop graph; call 3+ = one graph replay
+        # (a) first calls at B = 64: call 1 = workspace allocation + weight packing + trunk + first-call bound check (three eager denoiser
+        #     passes) + the step units recorded and launched; call 2 = unit replay (the whole-loop graph is recorded meanwhile);
+        #     call 3+ = one graph replay
         extra["first_calls_b64_ms"] = {"call_1": round(warm_ms[0], 1) if warm_ms else None,
                                        "call_2": round(warm_ms[1], 1) if len(warm_ms) > 1 else None,
                                        "steady_state": round(1e3 * elapsed / args.steps, 1)}

@@ -549,7 +549,7 @@ class PhysDock(nn.Module):
                 # the captured launches hold raw device addresses: a unit keeps the MMFF table object whose tables it captured alive
                 # (a later call with an EQUAL table - same signature, e.g. rebuilt from the same RDKit molecule - replays against
                 # these tables, not against its own freshly built and soon freed ones)
-                for (ukey, _), ex in zip(missing, capture([fns for _, fns in missing])):
+                for (ukey, _), ex in zip(missing, capture([fns for _, fns in missing], sync=not PIPELINED_CAPTURE)):
                     self._units[ukey] = {"exec": ex, "terms": terms if ukey[1] == "T" and ukey[-1][0] == "mmff" else None}
                 self.unit_captures += len(missing)
                 while len(self._units) > self.max_cached_units:
@@ -558,7 +558,10 @@ class PhysDock(nn.Module):
                 entry = self._graphs[key] = {"exec": None, "terms": relaxer.terms if relaxer.kind == "device" else None}
             else:
                 # the second call of the same schedule on the same shape: the whole N-step loop as ONE graph from here on
-                entry["exec"] = capture(segments)
+                # (recorded without a device synchronisation while the GPU executes the units launched above: a synchronising capture
+                #  stalled every stream of the device - the other replica of a StreamPool too: two systems at a time fell from 3.1 to 2.7
+                #  ligands/s when the promotion landed in the measured region)
+                entry["exec"] = capture(segments, sync=not PIPELINED_CAPTURE)
                 entry["terms"] = relaxer.terms if relaxer.kind == "device" else None      # the tables THIS capture recorded
                 self.whole_captures += 1
             while len(self._graphs) > self.max_cached_graphs:
