@@ -207,3 +207,44 @@ def test_g7_reselect():
     order, e_c = orc.template_reselect(g["ligand_poses"], g["ref_mol_poses"], len(g["order"]))
     close(e_c, g["eps_c"], atol=1e-6)
     assert torch.equal(order, g["order"])
+
+
+# ------------------------------------------------------------------ G14: the trunk at the benchmark shape, and the pooling's rounding
+def test_trunk_cfg1_vs_reference_tensors_and_the_pooling_bound():
+    """G14 (round 6, tools/make_golden.py main_g14): the oracle's conditioning trunk at cfg1 (medium model, T 256 / A 2048) against the
+    REFERENCE's own tensors.  The reference pools atoms into tokens by cumsum over all atoms -> diff (diffusion_conditioning.py:168-176);
+    the fp32 prefixes (|C| up to 1 800) carry half an ulp of rounding each, which flips under a one-ulp change of the inputs.  Hence:
+    (1) the oracle's own pooled tensor (same torch cumsum, inputs 6e-7 away) lies within FOUR of the reference's rounding bounds of the
+    reference's - one for each side's rounded prefixes, two for the distance between the two sides' exact prefixes (6e-7 relative per
+    element, summed over up to 2 048 atoms) - where the HIP path, which pools exactly, stays within one (tests/test_trunk_pins_gpu.py); (2) with the reference's pooled tensor injected the four trunk outputs agree with the
+    reference to fp32 rounding level; (3) with its own pooling the oracle is as far from the reference as the reference is from itself
+    after a one-ulp move in front of the pooling (fixture scalars one_ulp_*)."""
+    from conftest import pool_rounding_bound
+    from physdock_amd.configs import PhysDockConfig
+    from physdock_amd.params import param_shapes, seeded_state_dict
+    from physdock_amd.synthetic import cfg1_batch
+    g = load_golden("g14_trunk_cfg1")
+    P = seeded_state_dict(param_shapes(PhysDockConfig(model_name="medium")), seed=0)
+    batch = cfg1_batch(0)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+    def rel_rms(u, v):
+        return float(((u.double() - v.double()).pow(2).mean() / v.double().pow(2).mean()).sqrt())
+
+    def sub(a, ap, s, z):
+        return dict(a=a[::8], ap=ap[::64, ::64], s=s[::2], z=z[::16, ::16])
+    with torch.no_grad():
+        name = "diffusion_conditioning"
+        a0, _ = orc.atom_embedder(P, name + ".atom_embedder", batch, 1e9, 1e-8)
+        u = torch.nn.functional.silu(orc.linear(P, name + ".token_embedder.linear_a", a0))
+        s_pool = orc.segment_mean_pool(u, batch["token_id_to_chunk_sizes"])
+        bound = pool_rounding_bound(g["prefix_exp_end"], batch["token_id_to_chunk_sizes"], g["s_pool"])
+        ratio = float(((s_pool - g["s_pool"]).abs() / (4 * bound + 1e-6)).max())
+        assert ratio <= 1.0, ratio
+        inj = sub(*orc.diffusion_conditioning(P, batch, s_pool=g["s_pool"]))
+        own = sub(*orc.diffusion_conditioning(P, batch))
+    for k in ("a", "ap", "s", "z"):
+        assert rel_rms(inj[k], g[k]) < 5e-6, (k, rel_rms(inj[k], g[k]))
+    for k in ("a", "s", "z"):
+        assert rel_rms(own[k], g[k]) <= 2.0 * float(g["one_ulp_" + k]), (k, rel_rms(own[k], g[k]), float(g["one_ulp_" + k]))
+        assert rel_rms(own[k], g[k]) > 5 * rel_rms(inj[k], g[k])          # the pooling IS the trunk's deviation
