@@ -80,6 +80,14 @@ __global__ __launch_bounds__(512, WLDS ? 2 : 4) void tri_attn_kernel(const pd_tr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     const int i = blockIdx.x, h = blockIdx.y;
+#ifdef PD_TRI_SKEW
+    // lab: the two blocks resident on a CU are (i, h) and (i, h + 1) (linear id L and L + 256: round-robin over 8 XCDs x 32 CUs): delay the
+    // odd heads by PD_TRI_SKEW x 8 128 cycles so that one block projects (request-bound) while the other attends (issue-bound)
+    if (h & 1) {
+#pragma unroll
+        for (int k = 0; k < PD_TRI_SKEW; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int T = p.T, nk = p.Treal;
     const long long bs = p.transpose ? CZ : (long long)T * CZ;          // floats between the batch rows i
     const long long ss = p.transpose ? (long long)T * CZ : CZ;          // floats between the sequence rows of one batch row
