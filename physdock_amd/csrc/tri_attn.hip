@@ -79,7 +79,19 @@ __global__ __launch_bounds__(512, WLDS ? 2 : 4) void tri_attn_kernel(const pd_tr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int i = blockIdx.x, h = blockIdx.y;
+    int i = blockIdx.x, h = blockIdx.y;
+#ifndef PD_TRI_XCD
+#define PD_TRI_XCD 1
+#endif
+    if (PD_TRI_XCD && (gridDim.x & 7) == 0) {
+        // Workgroups go to the eight XCDs round-robin in dispatch order.  With the plain (row, head) grid the four heads of a pair row are
+        // 256 dispatches apart: same XCD, but two of them a whole round later - the row's 128 KB of split z come from HBM twice.  Here the
+        // four heads of a row are consecutive dispatches of ONE XCD: one fetch per row, the other three blocks hit that XCD's L2.
+        const int L = blockIdx.x + gridDim.x * blockIdx.y;
+        const int slot = L >> 3;
+        i = 8 * (slot >> 2) + (L & 7);
+        h = slot & 3;
+    }
 #ifdef PD_TRI_SKEW
     // lab: the two blocks resident on a CU are (i, h) and (i, h + 1) (linear id L and L + 256: round-robin over 8 XCDs x 32 CUs): delay the
     // odd heads by PD_TRI_SKEW x 8 128 cycles so that one block projects (request-bound) while the other attends (issue-bound)
