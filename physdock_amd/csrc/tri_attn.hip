@@ -31,16 +31,22 @@ constexpr int KT = 64, KP = 40, VP = 72;        // attn_pipe.hip's tile layouts
 constexpr int K_PART = KT * KP, V_PART = 32 * VP;
 constexpr int STAGE = 2 * (K_PART + V_PART);
 constexpr int NTILE = 4;                        // 256 keys
-// PD_TRI_WLDS = 1 (lab, measured and NOT shipped): the head's 96 weight rows (48 KB) staged once per block in LDS behind the K / V tiles and
-// both parts of the wave's rows of z in registers: 126 KB of LDS and up to 256 registers = ONE block (eight waves) per CU.  It removes
-// 0.8 MB of per-wave weight requests per pair of blocks from the CU's vector-memory path, and is slower: 73 - 75 us against 65 - 67 us -
-// with two waves per SIMD the attention phase alone takes 45 us instead of 32 (profiles/r06_tri_attn_forms.txt).
+// PD_TRI_WLDS: where the head's 96 weight rows (48 KB of two-part fp16 fragments) come from during the projection.
+//   0 (form 2): every wave requests its weight fragments - and the low parts of its rows of z once per output tile - from L2: 0.9 MB of
+//     requests per block on the CU's vector-memory path, which is what the projection phase waits for (profiles/r06_tri_attn_forms.txt).
+//   1 (form 4): the weights are staged ONCE per block in LDS - in the space of the K / V tiles, which are not written before every wave
+//     has left the projection (the projected k / v tiles wait, packed, in 32 registers; one more block barrier) - so LDS stays at 78 KB =
+//     two blocks per CU, and the projection runs k-step-major over THREE accumulators (q, k, v), which streams both parts of the wave's
+//     rows of z through a three-deep ring exactly once: 0.43 MB of requests per block.  Every accumulator sees the same MFMA sequence as
+//     in form 0: results bit-identical.  (Form 3 of round 6 - weights in LDS BEHIND the K / V tiles, 126 KB = one block per CU - was slower
+//     than form 2: the attention phase at two waves per SIMD takes 45 us instead of 32.)
 #ifndef PD_TRI_WLDS
-#define PD_TRI_WLDS 0
+#define PD_TRI_WLDS 1
 #endif
 constexpr bool WLDS = PD_TRI_WLDS != 0;
 constexpr int W_HALVES = 3 * 2 * NKS * 64 * 8;              // q, k, v tiles x 2 parts x 8 k-steps x 64 lanes x 8 halves = 48 KB
-constexpr int LDS_BYTES = NTILE * STAGE * 2 + (WLDS ? W_HALVES * 2 : 0);
+static_assert(W_HALVES <= NTILE * STAGE, "the staged weights live in the K / V tiles' space");
+constexpr int LDS_BYTES = NTILE * STAGE * 2;
 constexpr int LAZY = 3;
 constexpr float PSH = 14.0f - (float)LAZY;
 
@@ -74,7 +80,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(512, WLDS ? 2 : 4) void tri_attn_kernel(const pd_tri_attn_args p) {
+__global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,84 +127,24 @@ __global__ __launch_bounds__(512, WLDS ? 2 : 4) void tri_attn_kernel(const pd_tr
 
     // ---- 1. the wave's 32 rows of z[i] / rms, already scaled and split, in fragment order (written by pd_pair_bias_split)
     const int ntile = (T + 31) >> 5;
-    const frag* zbase = reinterpret_cast<const frag*>(p.z2) + ((long long)i * ntile + wave) * (NKS * 2 * 64) + lane;
-    frag zh[NKS], zlr[WLDS ? NKS : 1];                                  // high parts (and, WLDS, low parts) of all eight k-steps
+    // (a wave without rows - T < 256 - reads the rows of wave 0: in bounds, projected, stored into tiles no query reads as keys < nk)
+    const frag* zbase = reinterpret_cast<const frag*>(p.z2) + ((long long)i * ntile + (wave_active ? wave : 0)) * (NKS * 2 * 64) + lane;
     auto zfrag_g = [&](int s, int part) {
         if constexpr (ABL & 16) return __builtin_bit_cast(frag, part ? u32x4{0x1c001c00u, 0x1c009c00u, 0x18001c00u, 0x1c001400u}
                                                                       : u32x4{0x3c003c00u, 0x3c00bc00u, 0x38003c00u, 0x3c003400u});
-        return wave_active ? zbase[(2 * s + part) * 64] : frag{};
-    };
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-        zh[s] = zfrag_g(s, 0);
-        if constexpr (WLDS) zlr[s] = zfrag_g(s, 1);
-    }
-    auto zlo_frag = [&](int s) {
-        if constexpr (WLDS) return zlr[s];
-        else return zfrag_g(s, 1);
-    };
-
-    // ---- 2. projection: weight fragments [2 parts][12 tiles][8 k-steps][64 lanes][8] (packing.split2_f16 of the [3 C][C] matrix)
-    const frag* wbase = reinterpret_cast<const frag*>(p.W2) + lane;
-    unsigned short* const ldsW = lds + NTILE * STAGE;                   // WLDS: [3 tiles q, k, v][2 parts][8 k-steps][64 lanes][8]
-    if constexpr (WLDS) {
-        // 3 072 fragments of 16 bytes, six per thread: thread t takes fragments t, t + 512, ... of the head's slice, read in the order
-        // they are stored in (coalesced kilobytes)
-        frag tmp[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int f = tid + 512 * j;                                // (tile3 * 2 + part) * 512 + s * 64 + lane'
-            const int tp = f >> 9, sl = f & 511;
-            const int t3 = tp >> 1, part = tp & 1;
-            tmp[j] = (ABL & 2) ? frag{} : reinterpret_cast<const frag*>(p.W2)[((part * 12 + 4 * t3 + h) * NKS) * 64 + sl];
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<frag*>(ldsW + (tid + 512 * j) * 8) = tmp[j];
-        lds_barrier();
-    }
-    auto wfrag = [&](int tile, int s, int part) {
-        if constexpr (WLDS) return *reinterpret_cast<const frag*>(ldsW + ((((tile >> 2) * 2 + part) * NKS + s) * 64 + lane) * 8);
-        if constexpr (ABL & 2) return __builtin_bit_cast(frag, u32x4{0x3c003c00u + tile, 0x3c003c00u + s, 0x3c003c00u + part, 0x3c003c00u});
-        return wbase[((part * 12 + tile) * NKS + s) * 64];
-    };
-    // one 32-row output tile of the projection: 24 MFMAs, the weight fragments of k-step s + 1 requested in front of the MFMAs of
-    // k-step s and no further ahead (sched_barrier: the row fragments already hold 64 registers).  transposed: rows of the
-    // accumulator = output channels (A = weights, B = rows of z); else rows = rows of z
-    auto project = [&](int wtile, bool transposed) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // fragments of k-steps s + 1 and s + 2 are in flight while the MFMAs of k-step s issue (L2 round trips of ~1 us against 96 matrix
-        // cycles per k-step; the sched_barriers keep hipcc from hoisting all sixteen requests - 64 registers - to the top)
-        frag wh[3], wl[3], zl[3];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) { wh[d] = wfrag(wtile, d, 0); wl[d] = wfrag(wtile, d, 1); zl[d] = zlo_frag(d); }
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            const int c = s % 3, n = (s + 2) % 3;
-            if (s + 2 < NKS) { wh[n] = wfrag(wtile, s + 2, 0); wl[n] = wfrag(wtile, s + 2, 1); zl[n] = zlo_frag(s + 2); }
-            PD_SB();
-            if (transposed) {
-                acc = jmma(wh[c], zl[c], acc);
-                acc = jmma(wl[c], zh[s], acc);
-                acc = jmma(wh[c], zh[s], acc);
-            } else {
-                acc = jmma(zl[c], wh[c], acc);
-                acc = jmma(zh[s], wl[c], acc);
-                acc = jmma(zh[s], wh[c], acc);
-            }
-            PD_SB();
-        }
-        return acc;
+        return zbase[(2 * s + part) * 64];
     };
     frag qf[2][2];                                                      // the wave's Q fragments (as attn_pipe.hip)
     const int tile = wave >> 1, half = wave & 1;                        // the wave's keys: LDS tile and its 32-key half
     unsigned short* sK = lds + tile * STAGE;
     unsigned short* sV = sK + 2 * K_PART;
-    {
-        // q (transposed): acc[r] = q[dim pd_frag_row(r, hh)][row l31]
-        f32x16 acc = project(h, true);
-        const float fq = qs * inv_as * p.w_inv[32 * h];                 // (one weight scale per 32-row tile: packing.qkv_folded_w2)
+    const float fq = qs * inv_as * p.w_inv[32 * h];                     // (one weight scale per 32-row tile: packing.qkv_folded_w2)
+    const float fk = sk * inv_as * p.w_inv[CZ + 32 * h];
+    const float fv = sv * inv_as * p.w_inv[2 * CZ + 32 * h];
+    const int ko = (half * 32 + l31) * KP + 4 * hh;
+    const int vo = l31 * VP + half * 32 + 8 * hh;
+    // q (transposed accumulator: acc[r] = q[dim pd_frag_row(r, hh)][row l31]) -> the wave's Q fragments
+    auto make_q = [&](const f32x16& acc) {
         unsigned ph[8], pl[8];                                          // packed pairs: group g = dims 8 g + 4 hh .. + 4 -> [2 g], [2 g + 1]
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -223,34 +169,129 @@ __global__ __launch_bounds__(512, WLDS ? 2 : 4) void tri_attn_kernel(const pd_tr
             qf[st][0] = __builtin_bit_cast(frag, fh);
             qf[st][1] = __builtin_bit_cast(frag, fl);
         }
-    }
-    {
-        // k (transposed): acc[r] = k[dim pd_frag_row(r, hh)][key l31] -> the key's row of the K tile
-        f32x16 acc = project(4 + h, true);
-        const float fk = sk * inv_as * p.w_inv[CZ + 32 * h];
-        const int ko = (half * 32 + l31) * KP + 4 * hh;
+    };
+    // a projected 32 x 32 tile scaled and split: [g] = (high pair 0, high pair 1), (low pair 0, low pair 1) of register group g
+    auto pack = [&](const f32x16& acc, float f, u32x2 (&hi)[4], u32x2 (&lo)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const pd_parts2 t0 = pd_split2h(acc[4 * g] * fk, acc[4 * g + 1] * fk);
-            const pd_parts2 t1 = pd_split2h(acc[4 * g + 2] * fk, acc[4 * g + 3] * fk);
-            *reinterpret_cast<u32x2*>(sK + ko + 8 * g) = u32x2{t0.h, t1.h};
-            *reinterpret_cast<u32x2*>(sK + K_PART + ko + 8 * g) = u32x2{t0.l, t1.l};
+            const pd_parts2 t0 = pd_split2h(acc[4 * g] * f, acc[4 * g + 1] * f);
+            const pd_parts2 t1 = pd_split2h(acc[4 * g + 2] * f, acc[4 * g + 3] * f);
+            hi[g] = u32x2{t0.h, t1.h}; lo[g] = u32x2{t0.l, t1.l};
         }
-    }
-    {
-        // v (straight): acc[r] = v[key pd_frag_row(r, hh)][dim l31] -> row l31 of the V^T tile; four consecutive keys of a register
-        // group sit in four consecutive columns of attn_pipe.hip's key permutation: 16 (g >> 1) + 8 hh + 4 (g & 1) + 0..3
-        f32x16 acc = project(8 + h, false);
-        const float fv = sv * inv_as * p.w_inv[2 * CZ + 32 * h];
-        const int vo = l31 * VP + half * 32 + 8 * hh;
+    };
+    // k (transposed: acc[r] = k[dim pd_frag_row(r, hh)][key l31]) -> the key's row of the K tile
+    auto store_k = [&](const u32x2 (&hi)[4], const u32x2 (&lo)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const pd_parts2 t0 = pd_split2h(acc[4 * g] * fv, acc[4 * g + 1] * fv);
-            const pd_parts2 t1 = pd_split2h(acc[4 * g + 2] * fv, acc[4 * g + 3] * fv);
+            *reinterpret_cast<u32x2*>(sK + ko + 8 * g) = hi[g];
+            *reinterpret_cast<u32x2*>(sK + K_PART + ko + 8 * g) = lo[g];
+        }
+    };
+    // v (straight: acc[r] = v[key pd_frag_row(r, hh)][dim l31]) -> row l31 of the V^T tile; four consecutive keys of a register group
+    // sit in four consecutive columns of attn_pipe.hip's key permutation: 16 (g >> 1) + 8 hh + 4 (g & 1) + 0..3
+    auto store_v = [&](const u32x2 (&hi)[4], const u32x2 (&lo)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
             const int c = vo + 16 * (g >> 1) + 4 * (g & 1);
-            *reinterpret_cast<u32x2*>(sV + c) = u32x2{t0.h, t1.h};
-            *reinterpret_cast<u32x2*>(sV + V_PART + c) = u32x2{t0.l, t1.l};
+            *reinterpret_cast<u32x2*>(sV + c) = hi[g];
+            *reinterpret_cast<u32x2*>(sV + V_PART + c) = lo[g];
         }
+    };
+
+    // ---- 2. projection: weight fragments [2 parts][12 tiles][8 k-steps][64 lanes][8] (packing.split2_f16 of the [3 C][C] matrix)
+    if constexpr (WLDS) {
+        // the first two k-steps of the wave's rows travel while the block stages the weights
+        frag zr[3][2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) { zr[d][0] = zfrag_g(d, 0); zr[d][1] = zfrag_g(d, 1); }
+        {
+            // 3 072 fragments of 16 bytes, six per thread: thread t takes fragments t, t + 512, ... of the head's slice, read in the order
+            // they are stored in (coalesced kilobytes): LDS [3 tiles q, k, v][2 parts][8 k-steps][64 lanes][8]
+            frag tmp[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int f = tid + 512 * j;                            // (tile3 * 2 + part) * 512 + s * 64 + lane'
+                const int tp = f >> 9, sl = f & 511;
+                const int t3 = tp >> 1, part = tp & 1;
+                tmp[j] = (ABL & 2) ? frag{} : reinterpret_cast<const frag*>(p.W2)[((part * 12 + 4 * t3 + h) * NKS) * 64 + sl];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<frag*>(lds + (tid + 512 * j) * 8) = tmp[j];
+        }
+        lds_barrier();                                                  // A: the weights are staged
+        auto wl = [&](int t3, int s, int part) { return *reinterpret_cast<const frag*>(lds + ((((t3 * 2 + part) * NKS + s) * 64 + lane) * 8)); };
+        f32x16 aq, ak, av;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ak[r] = 0.f; av[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const int c = s % 3, n = (s + 2) % 3;
+            if (s + 2 < NKS) { zr[n][0] = zfrag_g(s + 2, 0); zr[n][1] = zfrag_g(s + 2, 1); }
+            PD_SB();
+            const frag wqh = wl(0, s, 0), wql = wl(0, s, 1), wkh = wl(1, s, 0), wkl = wl(1, s, 1), wvh = wl(2, s, 0), wvl = wl(2, s, 1);
+            aq = jmma(wqh, zr[c][1], aq);
+            aq = jmma(wql, zr[c][0], aq);
+            aq = jmma(wqh, zr[c][0], aq);
+            ak = jmma(wkh, zr[c][1], ak);
+            ak = jmma(wkl, zr[c][0], ak);
+            ak = jmma(wkh, zr[c][0], ak);
+            av = jmma(zr[c][1], wvh, av);
+            av = jmma(zr[c][0], wvl, av);
+            av = jmma(zr[c][0], wvh, av);
+            PD_SB();
+        }
+        make_q(aq);
+        u32x2 kh[4], kl[4], vh[4], vl[4];
+        pack(ak, fk, kh, kl);
+        pack(av, fv, vh, vl);
+        lds_barrier();                                                  // B: every wave has left the projection: the weights are dead
+        store_k(kh, kl);
+        store_v(vh, vl);
+    } else {
+        frag zh[NKS];                                                   // high parts of all eight k-steps
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) zh[s] = zfrag_g(s, 0);
+        const frag* wbase = reinterpret_cast<const frag*>(p.W2) + lane;
+        auto wfrag = [&](int tile, int s, int part) {
+            if constexpr (ABL & 2) return __builtin_bit_cast(frag, u32x4{0x3c003c00u + tile, 0x3c003c00u + s, 0x3c003c00u + part, 0x3c003c00u});
+            return wbase[((part * 12 + tile) * NKS + s) * 64];
+        };
+        // one 32-row output tile of the projection: 24 MFMAs, the weight fragments of k-step s + 1 requested in front of the MFMAs of
+        // k-step s and no further ahead (sched_barrier: the row fragments already hold 64 registers).  transposed: rows of the
+        // accumulator = output channels (A = weights, B = rows of z); else rows = rows of z
+        auto project = [&](int wtile, bool transposed) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // fragments of k-steps s + 1 and s + 2 are in flight while the MFMAs of k-step s issue (L2 round trips of ~1 us against 96 matrix
+            // cycles per k-step; the sched_barriers keep hipcc from hoisting all sixteen requests - 64 registers - to the top)
+            frag wh[3], wl[3], zl[3];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) { wh[d] = wfrag(wtile, d, 0); wl[d] = wfrag(wtile, d, 1); zl[d] = zfrag_g(d, 1); }
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const int c = s % 3, n = (s + 2) % 3;
+                if (s + 2 < NKS) { wh[n] = wfrag(wtile, s + 2, 0); wl[n] = wfrag(wtile, s + 2, 1); zl[n] = zfrag_g(s + 2, 1); }
+                PD_SB();
+                if (transposed) {
+                    acc = jmma(wh[c], zl[c], acc);
+                    acc = jmma(wl[c], zh[s], acc);
+                    acc = jmma(wh[c], zh[s], acc);
+                } else {
+                    acc = jmma(zl[c], wh[c], acc);
+                    acc = jmma(zh[s], wl[c], acc);
+                    acc = jmma(zh[s], wh[c], acc);
+                }
+                PD_SB();
+            }
+            return acc;
+        };
+        u32x2 ph[4], pl[4];
+        make_q(project(h, true));
+        pack(project(4 + h, true), fk, ph, pl);
+        store_k(ph, pl);
+        pack(project(8 + h, false), fv, ph, pl);
+        store_v(ph, pl);
     }
 
     // ---- 3. attention over the resident tiles (the wave program of attn_pipe.hip)

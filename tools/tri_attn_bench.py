@@ -46,6 +46,9 @@ for tr in (False, True):
                                              transpose=tr, eps=1e-8, zn_amax=zn_amax))
     t = timeit(lambda: ops.tri_attention(z2, W2, bias, o, T, T, C, H, transpose=tr, bias_prescale=ps, bias_nk=T, qkv_amax=bounds,
                                          zn_amax=zn_amax))
+    torch.cuda.synchronize()
+    import hashlib
+    digest = hashlib.sha1(o.cpu().numpy().tobytes()).hexdigest()[:12]      # (A/B of two builds: bit-identical outputs have the same digest)
     flop = 2.0 * T * T * 3 * C * C + 4.0 * T * H * T * T * 32
     print(f"tri_attention T={T} transpose={tr}: {t:.1f} us  ({flop / t * 1e-6:.0f} TF algorithmic, {3 * flop / t * 1e-6 / 2516.6:.3f} of the fp16 pipe executed); "
-          f"pair_bias {tb:.1f} us, pair_bias_split {tbs:.1f} us")
+          f"pair_bias {tb:.1f} us, pair_bias_split {tbs:.1f} us; sha1(o) {digest}")
