@@ -87,6 +87,8 @@ def compile_cmd(src, out, mode=("-c",)):
         cmd[1:1] = ["-DPD_PIPE_XCD=" + os.environ["PD_PIPE_XCD"]]
     if os.environ.get("PD_TRI_WLDS") and base == "tri_attn.hip":       # lab: 0 = the two-blocks-per-CU form (weights / low parts per wave from L2)
         cmd[1:1] = ["-DPD_TRI_WLDS=" + os.environ["PD_TRI_WLDS"]]
+    if os.environ.get("PD_TRI_ZD") and base == "tri_attn.hip":         # lab: depth of the row-fragment ring of the in-block projection
+        cmd[1:1] = ["-DPD_TRI_ZD=" + os.environ["PD_TRI_ZD"]]
     if os.environ.get("PD_TRI_XCD") and base == "tri_attn.hip":        # lab: 0 = the plain (row, head) block order
         cmd[1:1] = ["-DPD_TRI_XCD=" + os.environ["PD_TRI_XCD"]]
     if os.environ.get("PD_TRI_SKEW") and base == "tri_attn.hip":       # lab: start delay of the odd-head blocks (x 8 128 cycles)

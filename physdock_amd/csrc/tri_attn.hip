@@ -44,6 +44,10 @@ constexpr int NTILE = 4;                        // 256 keys
 #define PD_TRI_WLDS 1
 #endif
 constexpr bool WLDS = PD_TRI_WLDS != 0;
+#ifndef PD_TRI_ZD
+#define PD_TRI_ZD 2
+#endif
+constexpr int ZD = PD_TRI_ZD;                    // form 4: k-steps of the wave's rows of z in flight ahead of the MFMAs
 constexpr int W_HALVES = 3 * 2 * NKS * 64 * 8;              // q, k, v tiles x 2 parts x 8 k-steps x 64 lanes x 8 halves = 48 KB
 static_assert(W_HALVES <= NTILE * STAGE, "the staged weights live in the K / V tiles' space");
 constexpr int LDS_BYTES = NTILE * STAGE * 2;
@@ -53,7 +57,7 @@ constexpr float PSH = 14.0f - (float)LAZY;
 #define PD_SB() __builtin_amdgcn_sched_barrier(0)
 
 // lab ablations (timing only, wrong results; tools/abl_tri_attn.sh): 1 no attention phase, 2 weight fragments not loaded, 4 no
-// projection MFMAs, 8 no bias fetches, 16 rows of z not loaded
+// projection MFMAs, 8 no bias fetches, 16 rows of z not loaded, 32 no output stores
 #ifdef PD_TRI_ABL
 constexpr int ABL = PD_TRI_ABL;
 #else
@@ -99,9 +103,9 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         h = slot & 3;
     }
 #ifdef PD_TRI_SKEW
-    // lab: the two blocks resident on a CU are (i, h) and (i, h + 1) (linear id L and L + 256: round-robin over 8 XCDs x 32 CUs): delay the
-    // odd heads by PD_TRI_SKEW x 8 128 cycles so that one block projects (request-bound) while the other attends (issue-bound)
-    if (h & 1) {
+    // lab: the two blocks resident on a CU are the linear ids L and L + 256 (round-robin over 8 XCDs x 32 CUs): delay every second group of
+    // 256 by PD_TRI_SKEW x 8 128 cycles so that one block projects (latency-bound) while the other attends (issue-bound)
+    if (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1) {
 #pragma unroll
         for (int k = 0; k < PD_TRI_SKEW; ++k) __builtin_amdgcn_s_sleep(127);
     }
@@ -198,15 +202,36 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         }
     };
 
+    // ---- bias tiles of the attention phase (requested at the end of the projection, section 2)
+    const int nsub = (nk + 31) >> 5;
+    const int nkt32 = ((p.bias_nk > 0 ? p.bias_nk : nk) + 31) >> 5;
+    const int nqt32 = (T + 31) >> 5;
+    const float* bias_base = p.bias + (((long long)h * nqt32 + ((wave_active ? q0 : 0) >> 5)) * nkt32) * 1024;
+    const auto rs_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias_base), 0, nkt32 * 4096, 0x00020000);
+    const int boff = lane * 16;
+    auto load_bias = [&](f32x16& s, int kt32) {
+        if constexpr (ABL & 8) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            return;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, boff, kt32 * 4096 + g * 1024, 0));
+            s[4 * g] = v[0]; s[4 * g + 1] = v[1]; s[4 * g + 2] = v[2]; s[4 * g + 3] = v[3];
+        }
+    };
+    // (the lane's output address now: row / stride arithmetic does not stay live through the attention phase)
+    float* const op = row < T ? p.o + (long long)i * bs + (long long)row * ss + h * 32 + 4 * hh : nullptr;
+    f32x16 o, sA, sB;
     // ---- 2. projection: weight fragments [2 parts][12 tiles][8 k-steps][64 lanes][8] (packing.split2_f16 of the [3 C][C] matrix)
     if constexpr (WLDS) {
-        // the first two k-steps of the wave's rows travel while the block stages the weights
-        frag zr[3][2];
-#pragma unroll
-        for (int d = 0; d < 2; ++d) { zr[d][0] = zfrag_g(d, 0); zr[d][1] = zfrag_g(d, 1); }
+        // 3 072 weight fragments of 16 bytes, six per thread: thread t takes fragments t, t + 512, ... of the head's slice, read in the
+        // order they are stored in (coalesced kilobytes): LDS [3 tiles q, k, v][2 parts][8 k-steps][64 lanes][8].  The weights (L2 hits)
+        // are requested FIRST and the first two k-steps of the wave's rows (HBM for the first head of a row) behind them: requests
+        // return in order, so the LDS stores wait for the weights only and the rows travel while the block stages and meets
+        frag zr[ZD + 1][2];
         {
-            // 3 072 fragments of 16 bytes, six per thread: thread t takes fragments t, t + 512, ... of the head's slice, read in the order
-            // they are stored in (coalesced kilobytes): LDS [3 tiles q, k, v][2 parts][8 k-steps][64 lanes][8]
             frag tmp[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
@@ -215,6 +240,10 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
                 const int t3 = tp >> 1, part = tp & 1;
                 tmp[j] = (ABL & 2) ? frag{} : reinterpret_cast<const frag*>(p.W2)[((part * 12 + 4 * t3 + h) * NKS) * 64 + sl];
             }
+            PD_SB();
+#pragma unroll
+            for (int d = 0; d < ZD; ++d) { zr[d][0] = zfrag_g(d, 0); zr[d][1] = zfrag_g(d, 1); }
+            PD_SB();
 #pragma unroll
             for (int j = 0; j < 6; ++j) *reinterpret_cast<frag*>(lds + (tid + 512 * j) * 8) = tmp[j];
         }
@@ -225,8 +254,8 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ak[r] = 0.f; av[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
-            const int c = s % 3, n = (s + 2) % 3;
-            if (s + 2 < NKS) { zr[n][0] = zfrag_g(s + 2, 0); zr[n][1] = zfrag_g(s + 2, 1); }
+            const int c = s % (ZD + 1), n = (s + ZD) % (ZD + 1);
+            if (s + ZD < NKS) { zr[n][0] = zfrag_g(s + ZD, 0); zr[n][1] = zfrag_g(s + ZD, 1); }
             PD_SB();
             const frag wqh = wl(0, s, 0), wql = wl(0, s, 1), wkh = wl(1, s, 0), wkl = wl(1, s, 1), wvh = wl(2, s, 0), wvl = wl(2, s, 1);
             aq = jmma(wqh, zr[c][1], aq);
@@ -244,6 +273,9 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         u32x2 kh[4], kl[4], vh[4], vl[4];
         pack(ak, fk, kh, kl);
         pack(av, fv, vh, vl);
+        PD_SB();
+        load_bias(sA, 0);                                               // the first two bias tiles travel while the block meets twice
+        load_bias(sB, 1);
         lds_barrier();                                                  // B: every wave has left the projection: the weights are dead
         store_k(kh, kl);
         store_v(vh, vl);
@@ -292,35 +324,15 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         store_k(ph, pl);
         pack(project(8 + h, false), fv, ph, pl);
         store_v(ph, pl);
+        PD_SB();                                                        // (not above the projection: its fragments hold the registers)
+        load_bias(sA, 0);
+        load_bias(sB, 1);
     }
 
     // ---- 3. attention over the resident tiles (the wave program of attn_pipe.hip)
-    const int nsub = (nk + 31) >> 5;
-    const int nkt32 = ((p.bias_nk > 0 ? p.bias_nk : nk) + 31) >> 5;
-    const int nqt32 = (T + 31) >> 5;
-    const float* bias_base = p.bias + (((long long)h * nqt32 + ((wave_active ? q0 : 0) >> 5)) * nkt32) * 1024;
-    const auto rs_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias_base), 0, nkt32 * 4096, 0x00020000);
-    const int boff = lane * 16;
-    auto load_bias = [&](f32x16& s, int kt32) {
-        if constexpr (ABL & 8) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            return;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, boff, kt32 * 4096 + g * 1024, 0));
-            s[4 * g] = v[0]; s[4 * g + 1] = v[1]; s[4 * g + 2] = v[2]; s[4 * g + 3] = v[3];
-        }
-    };
-    // (the lane's output address now: row / stride arithmetic does not stay live through the attention phase)
-    float* const op = row < T ? p.o + (long long)i * bs + (long long)row * ss + h * 32 + 4 * hh : nullptr;
-    f32x16 o, sA, sB;
-    PD_SB();                                                            // (not above the projection: its fragments hold the registers)
-    load_bias(sA, 0);
-    load_bias(sB, 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
+
     lds_barrier();                                                      // all keys of the (row, head) are resident
 
     const int koff = l31 * KP + 8 * hh;
@@ -486,7 +498,10 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         }
     }
 
-    if (op) {
+    // ---- 4. output, in accumulator order.  (The stores cost ~5 of 54 us - ablation 32 - and it is their bytes, not their shape: turning the
+    // wave's tile row-major through LDS so that eight lanes write one row's 128 bytes - 4 x fewer, whole-line requests, one more block
+    // barrier - measured 56.3 / 59.4 us against 57.0 / 58.6 us, profiles/r06_tri_attn_form4.txt.)
+    if (op && (!(ABL & 32) || l_run == 12345.f)) {                      // (ablation 32: no output stores)
         const float inv = inv_sv / pd_xhalf_sum(l_run);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
