@@ -45,6 +45,28 @@ __device__ __forceinline__ void block_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// lab ablations (timing only, wrong results): 1 no re-read of z in the epilogue, 2 no store of z, 4 no MFMAs, 8 rows of o not loaded,
+// 16 rows of z not loaded
+#ifdef PD_TRI_TAIL_ABL
+constexpr int TABL = PD_TRI_TAIL_ABL;
+#else
+constexpr int TABL = 0;
+#endif
+#ifndef PD_TRI_TAIL_GRID0
+#define PD_TRI_TAIL_GRID0 3     // blocks per CU of the launch, MODE 0 (47 KB of LDS)
+#endif
+#ifndef PD_TRI_TAIL_GRID1
+#define PD_TRI_TAIL_GRID1 2     // MODE 1 (71 KB)
+#endif
+__device__ __forceinline__ f32x16 tmma(f16x8 a, f16x8 b, f32x16 c, int, int, int) {
+    if constexpr (TABL & 4) { c[0] += (float)a[0] + (float)b[0]; return c; }
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+#ifndef PD_TRI_TAIL_PF
+#define PD_TRI_TAIL_PF 0        // lab: 0 = a tile's rows requested at the top of its own iteration (the round-5 form)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args p) {
     constexpr int OP = TM<MODE>::OP, PART_O = TM<MODE>::PART_O, NKS2 = TM<MODE>::NKS2, WZPART = TM<MODE>::WZPART;
@@ -70,23 +92,49 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
     const int n = 32 * wave + l31;               // this lane's output column
     const float cg = p.wg_inv[n] * inv_z_s, cz = p.wz_inv[n] * inv_o_s, bg = p.bg ? p.bg[n] : 0.f, bz = p.bz ? p.bz[n] : 0.f;
 
+    // The rows of a tile are requested ONE TILE AHEAD (round 6): a block's life was a chain of round trips - rows of z and o from HBM,
+    // barrier, weight fragments from L2, the read-modify-write of z - with two waves per SIMD to hide them (39.7 / 30.7 us per launch for
+    // 100 / 75 MB: 2.5 TB/s).  Now the requests of tile t + 1 are issued right behind the barrier that ends tile t's staging and travel
+    // under its contractions and its epilogue; same arithmetic, bit-identical results.
+    const int pr = tid >> 2, pq = tid & 3;                  // staging: four threads per row, 16-byte chunks interleaved
+    f32x4 zv[8];                                            // the thread's chunks of its z row
+    f32x4 orv[MODE == 0 ? 1 : 8];                           // MODE 1: its chunks of the attention-output row
+    float ov[MODE == 0 ? 8 : 1];                            // MODE 0: eight einsum channels of row `lane`
+    f32x4 gw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gw[i] = *reinterpret_cast<const f32x4*>(p.w_in + 4 * (pq + 4 * i));
+    auto fetch = [&](int tile) {
+        const long long row0 = (long long)tile * BM;
+        const bool live = row0 + pr < p.M;
+        const float* zr = p.z + (row0 + (live ? pr : 0)) * C_;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zv[i] = (TABL & 16) ? f32x4{1.f, 2.f, 3.f, (float)i} : *reinterpret_cast<const f32x4*>(zr + 4 * (pq + 4 * i));
+        if constexpr (MODE == 0) {
+            const bool livel = row0 + lane < p.M;
+            const float* orow = p.o + row0 + (livel ? lane : 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (TABL & 8) ? (float)e : orow[(long long)(8 * wave + e) * p.M];
+        } else {
+            const float* orow = p.o + (row0 + (live ? pr : 0)) * C_;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) orv[i] = (TABL & 8) ? f32x4{1.f, 2.f, 3.f, (float)i} : *reinterpret_cast<const f32x4*>(orow + 4 * (pq + 4 * i));
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long row0 = (long long)tile * BM;
+        if (!PD_TRI_TAIL_PF && tile != (int)blockIdx.x) fetch(tile);
         // ---- phase 0: RMSNorm of the tile's z rows (four threads per row) -> scale -> split -> sA
         {
-            const int r = tid >> 2, q = tid & 3;
+            const int r = pr, q = pq;
             const bool live = row0 + r < p.M;
-            const float* zr = p.z + (row0 + (live ? r : 0)) * C_;
-            f32x4 v[8], gw[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) gw[i] = *reinterpret_cast<const f32x4*>(p.w_in + 4 * (q + 4 * i));
             float sq = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                v[i] = *reinterpret_cast<const f32x4*>(zr + 4 * (q + 4 * i));
-                if (!live) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!live) zv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sq += v[i][e] * v[i][e];
+                for (int e = 0; e < 4; ++e) sq += zv[i][e] * zv[i][e];
             }
             sq += __shfl_xor(sq, 1);
             sq += __shfl_xor(sq, 2);
@@ -96,7 +144,7 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                 const int c = 4 * (q + 4 * i);
                 float t[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = v[i][e] * rstd * gw[i][e];
+                for (int e = 0; e < 4; ++e) t[e] = zv[i][e] * rstd * gw[i][e];
                 const pd_parts2 p0 = pd_split2h(t[0], t[1]), p1 = pd_split2h(t[2], t[3]);
                 *reinterpret_cast<u32x2*>(sA + r * LP + c) = u32x2{p0.h, p1.h};
                 *reinterpret_cast<u32x2*>(sA + PART_A + r * LP + c) = u32x2{p0.l, p1.l};
@@ -104,14 +152,12 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
         }
         if constexpr (MODE == 0) {
             // ---- phase 0b: the 32 einsum channels of the tile's rows: wave = 8 channels, lane = row (coalesced along m)
-            float ov[8];
             {
                 const bool live = row0 + lane < p.M;
-                const float* orow = p.o + row0 + (live ? lane : 0);
                 float ss = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    ov[e] = live ? orow[(long long)(8 * wave + e) * p.M] : 0.f;
+                    if (!live) ov[e] = 0.f;
                     ss += ov[e] * ov[e];
                 }
                 red[wave * BM + lane] = ss;
@@ -129,13 +175,12 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
             }
         } else {
             // ---- phase 0b: the attention output rows (row-major, no norm): scale -> split -> sO
-            const int r = tid >> 2, q = tid & 3;
+            const int r = pr, q = pq;
             const bool live = row0 + r < p.M;
-            const float* orow = p.o + (row0 + (live ? r : 0)) * C_;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = 4 * (q + 4 * i);
-                f32x4 v = *reinterpret_cast<const f32x4*>(orow + c);
+                f32x4 v = orv[i];
                 if (!live) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 const pd_parts2 p0 = pd_split2h(v[0] * o_s, v[1] * o_s), p1 = pd_split2h(v[2] * o_s, v[3] * o_s);
                 *reinterpret_cast<u32x2*>(sO + r * OP + c) = u32x2{p0.h, p1.h};
@@ -143,6 +188,8 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
             }
         }
         block_barrier();
+        if (PD_TRI_TAIL_PF && tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);      // the next tile's rows travel from here on
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- phase 1: gate logits = sA . W_g^T (K = 128), phase 2: update = sO . W_z^T (K = 32); this wave: all 64 rows x columns
         // [32 wave, +32)
@@ -169,9 +216,9 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                     const f16x8 a0 = *reinterpret_cast<const f16x8*>(abase + 32 * i * LP + 16 * ks);
                     const f16x8 a1 = *reinterpret_cast<const f16x8*>(abase + PART_A + 32 * i * LP + 16 * ks);
                     f32x16 t = accg[i];
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][1], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[ks % (PF + 1)][0], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][0], t, 0, 0, 0);
+                    t = tmma(a0, wf[ks % (PF + 1)][1], t, 0, 0, 0);
+                    t = tmma(a1, wf[ks % (PF + 1)][0], t, 0, 0, 0);
+                    t = tmma(a0, wf[ks % (PF + 1)][0], t, 0, 0, 0);
                     accg[i] = t;
                 }
             }
@@ -192,9 +239,9 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                     const f16x8 a0 = *reinterpret_cast<const f16x8*>(obase + 32 * i * OP + 16 * ks);
                     const f16x8 a1 = *reinterpret_cast<const f16x8*>(obase + PART_O + 32 * i * OP + 16 * ks);
                     f32x16 t = accz[i];
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][1], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, wf[ks % (PF + 1)][0], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, wf[ks % (PF + 1)][0], t, 0, 0, 0);
+                    t = tmma(a0, wf[ks % (PF + 1)][1], t, 0, 0, 0);
+                    t = tmma(a1, wf[ks % (PF + 1)][0], t, 0, 0, 0);
+                    t = tmma(a0, wf[ks % (PF + 1)][0], t, 0, 0, 0);
                     accz[i] = t;
                 }
             }
@@ -209,7 +256,9 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                 if (row < p.M) {
                     float* zp = p.z + row * C_ + n;
                     const float gl = accg[i][r] * cg + bg;
-                    *zp = *zp + (MODE == 0 ? pd_sigmoid(gl) : gl) * (accz[i][r] * cz + bz);
+                    const float zo = (TABL & 1) ? cg : *zp;
+                    const float zn = zo + (MODE == 0 ? pd_sigmoid(gl) : gl) * (accz[i][r] * cz + bz);
+                    if (!(TABL & 2) || zn == 12345.f) *zp = zn;
                 }
             }
         }
@@ -232,10 +281,10 @@ PD_EXPORT int pd_tri_tail(const pd_tri_tail_args* a, void* stream) {
     if (((uintptr_t)a->z | (uintptr_t)a->w_in | (uintptr_t)a->Wg | (uintptr_t)a->Wz | (a->mode ? (uintptr_t)a->o : 0)) & 15) return PD_ERR_UNSUPPORTED;
     const int ntiles = (a->M + BM - 1) / BM;
     if (a->mode == 0) {
-        const int grid = 256 * 3;
+        const int grid = 256 * PD_TRI_TAIL_GRID0;
         hipLaunchKernelGGL(tri_tail_kernel<0>, dim3(ntiles < grid ? ntiles : grid), dim3(4 * BM), TM<0>::LDS_BYTES, (hipStream_t)stream, *a);
     } else {
-        const int grid = 256 * 2;
+        const int grid = 256 * PD_TRI_TAIL_GRID1;
         hipLaunchKernelGGL(tri_tail_kernel<1>, dim3(ntiles < grid ? ntiles : grid), dim3(4 * BM), TM<1>::LDS_BYTES, (hipStream_t)stream, *a);
     }
     return pd_check_launch();
