@@ -89,7 +89,7 @@ def compile_cmd(src, out, mode=("-c",)):
         cmd[1:1] = ["-DPD_TRI_WLDS=" + os.environ["PD_TRI_WLDS"]]
     if os.environ.get("PD_TRI_ZD") and base == "tri_attn.hip":         # lab: depth of the row-fragment ring of the in-block projection
         cmd[1:1] = ["-DPD_TRI_ZD=" + os.environ["PD_TRI_ZD"]]
-    for knob in ("PD_TRI_TAIL_PF", "PD_TRI_TAIL_GRID0", "PD_TRI_TAIL_GRID1", "PD_TRI_TAIL_ABL"):      # lab: tile prefetch / blocks per CU of the triangle tails
+    for knob in ("PD_TRI_TAIL_PF", "PD_TRI_TAIL_GRID0", "PD_TRI_TAIL_GRID1", "PD_TRI_TAIL_ABL", "PD_TRI_TAIL_EPI"):      # lab: tile prefetch / blocks per CU of the triangle tails
         if os.environ.get(knob) and base == "tri_tail.hip":
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_TRI_XCD") and base == "tri_attn.hip":        # lab: 0 = the plain (row, head) block order

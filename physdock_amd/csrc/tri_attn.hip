@@ -238,7 +238,8 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
                 const int f = tid + 512 * j;                            // (tile3 * 2 + part) * 512 + s * 64 + lane'
                 const int tp = f >> 9, sl = f & 511;
                 const int t3 = tp >> 1, part = tp & 1;
-                tmp[j] = (ABL & 2) ? frag{} : reinterpret_cast<const frag*>(p.W2)[((part * 12 + 4 * t3 + h) * NKS) * 64 + sl];
+                tmp[j] = (ABL & 2) ? __builtin_bit_cast(frag, u32x4{0x2c002c00u + (unsigned)j, 0xac002c00u, 0x28002c00u, 0x2c00a400u})      // (not zeros: a matrix pipe fed zeros draws less power and clocks higher)
+                                : reinterpret_cast<const frag*>(p.W2)[((part * 12 + 4 * t3 + h) * NKS) * 64 + sl];
             }
             PD_SB();
 #pragma unroll

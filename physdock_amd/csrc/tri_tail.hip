@@ -63,6 +63,9 @@ __device__ __forceinline__ f32x16 tmma(f16x8 a, f16x8 b, f32x16 c, int, int, int
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+#ifndef PD_TRI_TAIL_EPI
+#define PD_TRI_TAIL_EPI 1       // lab: 0 = z re-read and stored in accumulator order
+#endif
 #ifndef PD_TRI_TAIL_PF
 #define PD_TRI_TAIL_PF 0        // lab: 0 = a tile's rows requested at the top of its own iteration (the round-5 form)
 #endif
@@ -100,9 +103,6 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
     f32x4 zv[8];                                            // the thread's chunks of its z row
     f32x4 orv[MODE == 0 ? 1 : 8];                           // MODE 1: its chunks of the attention-output row
     float ov[MODE == 0 ? 8 : 1];                            // MODE 0: eight einsum channels of row `lane`
-    f32x4 gw[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) gw[i] = *reinterpret_cast<const f32x4*>(p.w_in + 4 * (pq + 4 * i));
     auto fetch = [&](int tile) {
         const long long row0 = (long long)tile * BM;
         const bool live = row0 + pr < p.M;
@@ -129,6 +129,9 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
         {
             const int r = pr, q = pq;
             const bool live = row0 + r < p.M;
+            f32x4 gw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gw[i] = *reinterpret_cast<const f32x4*>(p.w_in + 4 * (q + 4 * i));
             float sq = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                 }
             }
         }
-        // ---- epilogue: z += sigmoid(gate logits) * update  (lane = column: 128-byte row segments)
+        if constexpr (PD_TRI_TAIL_EPI == 0) {
+        // ---- epilogue, round-5 form (lab): z re-read and stored in accumulator order (lane = column: 4-byte accesses, 128-byte row segments)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const long long rb = row0 + 32 * i + 4 * hh;
@@ -261,6 +265,36 @@ __global__ __launch_bounds__(4 * BM) void tri_tail_kernel(const pd_tri_tail_args
                     if (!(TABL & 2) || zn == 12345.f) *zp = zn;
                 }
             }
+        }
+        } else {
+        // ---- epilogue: z += sigmoid(gate logits) * update with z read ONCE.  The staging threads still hold their chunks of the z rows
+        // (zv: four threads per row); the accumulators hold lane = column.  Re-reading z in accumulator order cost 7.3 of 38 us and
+        // storing it 2.8 (ablations, profiles/r06_tri_tail_ablations.txt).  Here the rows pass through LDS - an fp32 tile in the space
+        // of the z operand, dead once every wave has left the contractions - : rows in (16-byte pieces), update in place in accumulator
+        // order (the same expression on the same values: bit-identical), rows out and to HBM in the 16-byte pieces they were loaded in.
+        float* const D = reinterpret_cast<float*>(sA);           // [BM][LP] floats = the bytes of sA's two parts
+        block_barrier();                                          // X: the operand tiles are dead
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(D + pr * LP + 4 * (pq + 4 * i)) = zv[i];
+        block_barrier();                                          // Y: the z rows are in D
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* dp = D + (32 * i + 4 * hh + (r & 3) + 8 * (r >> 2)) * LP + n;
+                const float gl = accg[i][r] * cg + bg;
+                const float zo = *dp;
+                const float zn = zo + (MODE == 0 ? pd_sigmoid(gl) : gl) * (accz[i][r] * cz + bz);
+                *dp = zn;
+            }
+        }
+        block_barrier();                                          // Z: the updated rows are in D
+        if (row0 + pr < p.M && (!(TABL & 2) || cg == 12345.f)) {
+            float* zr = p.z + (row0 + pr) * C_;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(zr + 4 * (pq + 4 * i)) = *reinterpret_cast<const f32x4*>(D + pr * LP + 4 * (pq + 4 * i));
+        }
         }
         block_barrier();                          // the LDS tiles are free for the next tile
     }
