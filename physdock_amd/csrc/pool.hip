@@ -26,7 +26,11 @@ constexpr int CIN = 128, ROWS = 64, PITCH = 136;          // bf16 elements per L
 constexpr int PART = ROWS * PITCH;
 constexpr int NKS = CIN / 16;
 
-__global__ __launch_bounds__(256, 4) void downscale_pool_kernel(const float* __restrict__ ba, const _Float16* __restrict__ W2,
+#ifndef PD_POOL_BPC
+#define PD_POOL_BPC 3          // blocks per CU the register budget is cut for: 3 = 168 registers, no spill (round 6, late: 4 = 128 registers, 38 spill
+                              // instructions, 122 us against 109 us per launch at 64 samples, bit-identical; profiles/r06_ab_pool_register_budget.txt)
+#endif
+__global__ __launch_bounds__(256, PD_POOL_BPC) void downscale_pool_kernel(const float* __restrict__ ba, const _Float16* __restrict__ W2,
                                                                 const float* __restrict__ w_inv, const float* __restrict__ bias,
                                                                 const int* __restrict__ tok_start,
                                                                 const float* __restrict__ add, float* __restrict__ out,
