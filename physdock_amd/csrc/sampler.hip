@@ -126,17 +126,22 @@ __global__ __launch_bounds__(256) void init_noise_kernel(float* __restrict__ x, 
 
 // ------------------------------------------------------------------ precond / denoise
 // ba[b,l,:] = Wx.(x_hat*c_in) + bx + a[l,:]                     (transformers.py:218-223)
+// I: the index type - unsigned 32-bit whenever the element count allows (round 6, late: with a 64-bit index the four divisions that turn the
+// flat index into (sample, atom, chunk) were ~300 instructions for one 16-byte store)
+template <typename I>
 __global__ __launch_bounds__(256) void precond_kernel(const float* __restrict__ x_hat, float c_in, const float* __restrict__ c_in_b,
                                                      const float* __restrict__ Wx, const float* __restrict__ bx,
                                                      const float* __restrict__ a, float* __restrict__ ba, int A, int C,
                                                      long long n4) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n4) return;
-    const int c4 = idx % (C / 4);
-    const long long row = idx / (C / 4);
-    const int l = row % A;
-    const float ci = c_in_b ? c_in_b[row / A] : c_in;
-    const float x0 = x_hat[row * 3] * ci, x1 = x_hat[row * 3 + 1] * ci, x2 = x_hat[row * 3 + 2] * ci;
+    const I idx = (I)blockIdx.x * 256 + threadIdx.x;
+    if ((long long)idx >= n4) return;
+    const I nc4 = (I)(C / 4), row = idx / nc4;
+    const int c4 = (int)(idx - row * nc4);
+    const I smp = row / (I)A;
+    const int l = (int)(row - smp * (I)A);
+    const float ci = c_in_b ? c_in_b[smp] : c_in;
+    const long long r3 = (long long)row * 3;
+    const float x0 = x_hat[r3] * ci, x1 = x_hat[r3 + 1] * ci, x2 = x_hat[r3 + 2] * ci;
     const f32x4 av = *reinterpret_cast<const f32x4*>(a + (long long)l * C + c4 * 4);
     f32x4 o;
 #pragma unroll
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void precond_kernel(const float* __restrict__ 
         const int c = c4 * 4 + e;
         o[e] = ((Wx[c * 3] * x0 + Wx[c * 3 + 1] * x1 + Wx[c * 3 + 2] * x2) + bx[c]) + av[e];
     }
-    *reinterpret_cast<f32x4*>(ba + row * C + c4 * 4) = o;
+    *reinterpret_cast<f32x4*>(ba + (long long)row * C + c4 * 4) = o;
 }
 
 // x_den = c_skip*x_hat + c_out * Wr.LN(ba)                         (transformers.py:228-233)
@@ -497,8 +502,12 @@ PD_EXPORT int pd_precond(const float* x_hat, float c_in, const float* c_in_b, co
                          const float* a, float* ba, int B, int A, int C, void* stream) {
     if (!x_hat || !Wx || !bx || !a || !ba || C % 4) return PD_ERR_ARG;
     const long long n4 = (long long)B * A * (C / 4);
-    hipLaunchKernelGGL(precond_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_hat, c_in,
-                       c_in_b, Wx, bx, a, ba, A, C, n4);
+    if (n4 + 256 < 0x7fffffffll)
+        hipLaunchKernelGGL(precond_kernel<unsigned>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_hat, c_in,
+                           c_in_b, Wx, bx, a, ba, A, C, n4);
+    else
+        hipLaunchKernelGGL(precond_kernel<long long>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_hat, c_in,
+                           c_in_b, Wx, bx, a, ba, A, C, n4);
     return pd_check_launch();
 }
 
