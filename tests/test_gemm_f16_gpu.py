@@ -369,6 +369,41 @@ def test_fused_atom_transition_vs_three_launches_and_float64(per_sample):
                               y_amax=ymax, h_amax=hmax, eps=1e-5) is False
 
 
+@pytest.mark.parametrize("B,N_", [(8, 1000), (71, 1803), (64, 40), (3, 2048 + 64)])
+def test_fused_atom_transition_with_group_boundaries_inside_tiles(B, N_):
+    """pd_transition_f16 with AdaLN groups that do not end on 64-row tiles (round 6: ONE group division per tile, the tile's two gate rows in
+    registers) and with groups SMALLER than a tile (the per-row path), against float64; rows = the whole 64-row tiles below B N_"""
+    from physdock_amd import ops
+    from physdock_amd.packing import pack_glu, split2_f16
+    Cd, hidden = 128, 384
+    rows = (B * N_) // 64 * 64
+    ngrp = (rows + N_ - 1) // N_
+    x0 = (torch.randn(rows, Cd, generator=g(1)) * 2 + 0.3)
+    tab = (0.4 * torch.randn(ngrp, 3 * Cd, generator=g(2)))
+    tab[:, Cd:2 * Cd] += 1.0                                                         # (shift | 1 + scale | gate)
+    W1 = torch.randn(hidden, Cd, generator=g(3)) / math.sqrt(Cd); W3 = torch.randn(hidden, Cd, generator=g(4)) / math.sqrt(Cd)
+    W2 = torch.randn(Cd, hidden, generator=g(5)) / math.sqrt(hidden)
+    W13 = pack_glu(W1, W3)[0].cuda()
+    tabd, W2d = tab.cuda(), W2.cuda().contiguous()
+    grp = torch.arange(rows) // N_
+    xd = x0.double()
+    y = torch.nn.functional.layer_norm(xd, (Cd,), eps=1e-5) * tab[grp, Cd:2 * Cd].double() + tab[grp, :Cd].double()
+    hcpu = torch.nn.functional.silu(y @ W1.double().T) * (y @ W3.double().T)
+    ref = xd + tab[grp, 2 * Cd:].double() * (hcpu @ W2.double().T)
+    ymax = torch.tensor([float(y.abs().max()) * 3], device="cuda")
+    hmax = torch.tensor([float(hcpu.abs().max()) * 40], device="cuda")
+    x1 = x0.cuda().clone()
+    ok = ops.transition_f16(x1, rows, Cd, hidden, shift=tabd, scale1p=tabd.data_ptr() + 4 * Cd, gate=tabd.data_ptr() + 8 * Cd,
+                            W13=split2_f16(W13), W2=split2_f16(W2d), y_amax=ymax, h_amax=hmax, eps=1e-5, rows_per_group=N_, gstride=3 * Cd)
+    assert ok and torch.isfinite(x1).all()
+    d = (ref - xd).abs().mean()
+    err = (x1.double().cpu() - ref).abs()
+    e_rms, e_max = float(err.pow(2).mean().sqrt() / d), float(err.max() / d)
+    # a row normalised or gated with its neighbour group's AdaLN row is off by O(1) of the update: the bounds below are three orders tighter
+    print(f"transition rows={rows} rows_per_group={N_}: rms error / mean|update| {e_rms:.2e}, max {e_max:.2e}")
+    assert e_rms < 1e-5 and e_max < 1e-3
+
+
 @pytest.mark.parametrize("per_sample,mode,with_y2,B,Cd", [(False, "ln", True, 64, 128), (True, "ln", True, 64, 128), (False, "rms", False, 64, 128),
                                                            (True, "ln", False, 64, 128), (False, "ln", True, 20, 128), (True, "ln", True, 24, 128),
                                                            (False, "ln", True, 64, 512), (True, "ln", True, 64, 512), (False, "rms", False, 80, 512)])
