@@ -94,6 +94,8 @@ def compile_cmd(src, out, mode=("-c",)):
             cmd[1:1] = [f"-D{knob}=" + os.environ[knob]]
     if os.environ.get("PD_POOL_BPC") and base == "pool.hip":            # lab: register budget of the fused pool (blocks per CU)
         cmd[1:1] = ["-DPD_POOL_BPC=" + os.environ["PD_POOL_BPC"]]
+    if os.environ.get("PD_TRI_ROWS2") and base == "tri_attn.hip":      # lab: two pair rows of one head per 16-wave block
+        cmd[1:1] = ["-DPD_TRI_ROWS2=" + os.environ["PD_TRI_ROWS2"]]
     if os.environ.get("PD_TRI_XCD") and base == "tri_attn.hip":        # lab: 0 = the plain (row, head) block order
         cmd[1:1] = ["-DPD_TRI_XCD=" + os.environ["PD_TRI_XCD"]]
     if os.environ.get("PD_TRI_SKEW") and base == "tri_attn.hip":       # lab: start delay of the odd-head blocks (x 8 128 cycles)

@@ -50,7 +50,15 @@ constexpr bool WLDS = PD_TRI_WLDS != 0;
 constexpr int ZD = PD_TRI_ZD;                    // form 4: k-steps of the wave's rows of z in flight ahead of the MFMAs
 constexpr int W_HALVES = 3 * 2 * NKS * 64 * 8;              // q, k, v tiles x 2 parts x 8 k-steps x 64 lanes x 8 halves = 48 KB
 static_assert(W_HALVES <= NTILE * STAGE, "the staged weights live in the K / V tiles' space");
-constexpr int LDS_BYTES = NTILE * STAGE * 2;
+// PD_TRI_ROWS2 = 1 (lab): a block of SIXTEEN waves owns TWO pair rows of one head (waves 0 - 7 row 2 ip, waves 8 - 15 row 2 ip + 1): one
+// weight stage per two rows (in the first row's K / V space), and the two rows' waves walk the same bias tiles at the same time.  156 KB
+// of LDS: one block per CU, the same four waves per SIMD.
+#ifndef PD_TRI_ROWS2
+#define PD_TRI_ROWS2 0
+#endif
+constexpr int RPB = (PD_TRI_ROWS2 != 0 && WLDS) ? 2 : 1;    // pair rows per block
+constexpr int NTHR = 512 * RPB;
+constexpr int LDS_BYTES = RPB * NTILE * STAGE * 2;
 constexpr int LAZY = 3;
 constexpr float PSH = 14.0f - (float)LAZY;
 
@@ -84,10 +92,12 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+__global__ __launch_bounds__(NTHR, RPB == 2 ? 1 : 4) void tri_attn_kernel(const pd_tri_attn_args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds_all[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_b = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave of the block
+    const int wave = wave_b & 7, grp = wave_b >> 3;                      // wave of its pair row, pair row of the block
+    unsigned short* const lds = lds_all + grp * (NTILE * STAGE);         // the row's K / V tiles (the weights: lds_all, i.e. row 0's)
     const int l31 = lane & 31, hh = lane >> 5;
     int i = blockIdx.x, h = blockIdx.y;
 #ifndef PD_TRI_XCD
@@ -102,6 +112,7 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         i = 8 * (slot >> 2) + (L & 7);
         h = slot & 3;
     }
+    i = RPB * i + grp;                                                  // (RPB = 2: the grid's x counts row PAIRS)
 #ifdef PD_TRI_SKEW
     // lab: the two blocks resident on a CU are the linear ids L and L + 256 (round-robin over 8 XCDs x 32 CUs): delay every second group of
     // 256 by PD_TRI_SKEW x 8 128 cycles so that one block projects (latency-bound) while the other attends (issue-bound)
@@ -232,10 +243,10 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
         // return in order, so the LDS stores wait for the weights only and the rows travel while the block stages and meets
         frag zr[ZD + 1][2];
         {
-            frag tmp[6];
+            frag tmp[6 / RPB];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int f = tid + 512 * j;                            // (tile3 * 2 + part) * 512 + s * 64 + lane'
+            for (int j = 0; j < 6 / RPB; ++j) {
+                const int f = tid + NTHR * j;                           // (tile3 * 2 + part) * 512 + s * 64 + lane'
                 const int tp = f >> 9, sl = f & 511;
                 const int t3 = tp >> 1, part = tp & 1;
                 tmp[j] = (ABL & 2) ? __builtin_bit_cast(frag, u32x4{0x2c002c00u + (unsigned)j, 0xac002c00u, 0x28002c00u, 0x2c00a400u})      // (not zeros: a matrix pipe fed zeros draws less power and clocks higher)
@@ -246,10 +257,10 @@ __global__ __launch_bounds__(512, 4) void tri_attn_kernel(const pd_tri_attn_args
             for (int d = 0; d < ZD; ++d) { zr[d][0] = zfrag_g(d, 0); zr[d][1] = zfrag_g(d, 1); }
             PD_SB();
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<frag*>(lds + (tid + 512 * j) * 8) = tmp[j];
+            for (int j = 0; j < 6 / RPB; ++j) *reinterpret_cast<frag*>(lds_all + (tid + NTHR * j) * 8) = tmp[j];
         }
         lds_barrier();                                                  // A: the weights are staged
-        auto wl = [&](int t3, int s, int part) { return *reinterpret_cast<const frag*>(lds + ((((t3 * 2 + part) * NKS + s) * 64 + lane) * 8)); };
+        auto wl = [&](int t3, int s, int part) { return *reinterpret_cast<const frag*>(lds_all + ((((t3 * 2 + part) * NKS + s) * 64 + lane) * 8)); };
         f32x16 aq, ak, av;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ak[r] = 0.f; av[r] = 0.f; }
@@ -530,6 +541,6 @@ PD_EXPORT int pd_tri_attention(const pd_tri_attn_args* a, void* stream) {
             return PD_ERR_LAUNCH;
         raised = true;
     }
-    hipLaunchKernelGGL(tri_attn_kernel, dim3((unsigned)a->T, CZ / 32), dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(tri_attn_kernel, dim3((unsigned)(a->T / RPB), CZ / 32), dim3(NTHR), LDS_BYTES, (hipStream_t)stream, *a);
     return pd_check_launch();
 }
