@@ -6,7 +6,7 @@ for rep in $(seq $reps); do
   for v in $vals; do
     env $knob=$v python -m physdock_amd.build tri_attn.hip > /dev/null 2>&1
     echo "== $knob=$v"
-    python tools/tri_attn_bench.py 2>&1 | grep "^tri_attention" | cut -c1-108,180-
+    python tools/tri_attn_bench.py 2>&1 | grep "^tri_attention" | sed -E "s/; pair_bias [0-9.]+ us, pair_bias_split [0-9.]+ us//"
   done
 done
 python -m physdock_amd.build tri_attn.hip > /dev/null 2>&1
